@@ -1,0 +1,138 @@
+/*
+ * mi355zk.h -- C ABI of libmi355zk.so: the MI355X (gfx950) backend for the BN254 MSM / Fr-NTT hot
+ * path of kobigurk/phase2-bn254.
+ *
+ * The reference has no FFI seam; the two Rust functions a maintainer would redirect are
+ *   bellman/src/multiexp.rs:330-355   pub fn multiexp(pool, bases, density_map, exponents)
+ *   bellman/src/domain.rs:263-272     fn best_fft(a, worker, omega, log_n)
+ *   (+ the O(m) scalings of EvaluationDomain::{ifft, coset_fft, icoset_fft}, domain.rs:159-203)
+ * INTEGRATION.md shows the Rust `extern "C"` block and the two call-site patches.
+ *
+ * Conventions (all integers little endian):
+ *   Fq / Fr element   = 32 bytes = u64[4], least-significant limb first, MONTGOMERY form x*2^256 mod p,
+ *                       fully reduced: the in-memory form of the reference's `Fq`/`Fr`, i.e. what
+ *                       `into_raw_repr()` exposes (pairing/src/bn256/ec.rs:659-660).
+ *   FrRepr (scalar)   = 32 bytes = u64[4], CANONICAL integer < r: the output of `into_repr()`
+ *                       (the element type of multiexp's `exponents`, multiexp.rs:334).
+ *   G1 affine base    = 64 bytes  x || y            (RawEncodable layout, ec.rs:653-664)
+ *   G2 affine base    = 128 bytes x.c0 || x.c1 || y.c0 || y.c1
+ *                       the ALL-ZERO record is the point at infinity (ec.rs:673-675); the shim must
+ *                       zero the record itself when `is_zero()` (the reference's raw encoder does not).
+ *   Jacobian result   = X || Y || Z (12 / 24 u64), Z == 0 <=> infinity (ec.rs:227-246).  Any
+ *                       representative of the group element may be returned (projective equality is
+ *                       by value, ec.rs:45-85).
+ *   density           = NULL for FullDensity (source.rs:80-99); else bit i of the map is
+ *                       (density[i/32] >> (i%32)) & 1, `density_bits` bits long (DensityTracker,
+ *                       source.rs:101-118).  Bases are COMPACTED: only set bits consume a base.
+ *
+ * Return codes:
+ *   0  ok
+ *   1  UnexpectedIdentity: a selected base with a non-zero exponent is infinity   (source.rs:50-52)
+ *   2  UnexpectedEof:      the bases ran out                                      (source.rs:46-48,62-64)
+ *   3  bad arguments (NULL pointer, log_n > 28 = PolynomialDegreeTooLarge domain.rs:66-79, sizes >= 2^31)
+ *  <0  device failure (details on stderr).  There is NO CPU fallback inside the library.
+ * When both error kinds are present the one at the lowest exponent index is reported (the reference's
+ * answer depends on thread scheduling there; see oracle/tmpl_multiexp.h).
+ *
+ * Threading: every entry point may be called concurrently from several host threads (the prover
+ * queues 8 multiexps before waiting, bellman/src/groth16/prover.rs:250-298); calls on one device are
+ * serialised internally.  Entry points are synchronous: the result is complete on return, which a
+ * futures-0.1 shim wraps in `future::result` (what singlecore::Worker::compute does, singlecore.rs:33-47).
+ */
+#ifndef MI355ZK_H
+#define MI355ZK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355ZK_OK 0
+#define MI355ZK_ERR_UNEXPECTED_IDENTITY 1
+#define MI355ZK_ERR_UNEXPECTED_EOF 2
+#define MI355ZK_ERR_BAD_ARGS 3
+#define MI355ZK_ERR_DEVICE (-1)
+
+/* EvaluationDomain operations (domain.rs:154-203) for mi355zk_bn254_fr_domain_op[_dev] */
+#define MI355ZK_OP_FFT 0
+#define MI355ZK_OP_IFFT 1
+#define MI355ZK_OP_COSET_FFT 2
+#define MI355ZK_OP_ICOSET_FFT 3
+
+/* ---- lifecycle.  device_ids == NULL / n_devices == 0: use the process's current HIP device.
+ * One process drives one GPU (one rank per GPU under torch.distributed / RCCL); device_ids[0] is
+ * selected with hipSetDevice.  Replaces nothing in the reference (it has no device). */
+int mi355zk_init(const int *device_ids, int n_devices);
+void mi355zk_shutdown(void);
+const char *mi355zk_version(void);
+
+/* ---- multiexp: host buffers.  Replaces bellman/src/multiexp.rs:330 `multiexp` for
+ * S = (Arc<Vec<G1Affine>>, usize) (source.rs:36-70); `base_offset` is that usize. */
+int mi355zk_bn254_g1_msm(const uint8_t *bases, size_t n_bases, size_t base_offset,
+                         const uint64_t *scalars, size_t n_scalars,
+                         const uint32_t *density, size_t density_bits,
+                         uint64_t out_xyz[12]);
+/* Same for G = G2Affine (prover.rs:297-298). */
+int mi355zk_bn254_g2_msm(const uint8_t *bases, size_t n_bases, size_t base_offset,
+                         const uint64_t *scalars, size_t n_scalars,
+                         const uint32_t *density, size_t density_bits,
+                         uint64_t out_xyz[24]);
+
+/* ---- multiexp: bases and scalars already resident in HBM (the CRS / tau-table is reused across
+ * calls: `Arc<Vec<G>>` inside groth16::Parameters, groth16/mod.rs:216-238).  `density` stays a HOST
+ * pointer (it is tiny and the library needs its prefix sums).  `stream` is a hipStream_t (NULL = the
+ * default stream); the call returns after the result has been copied back. */
+int mi355zk_bn254_g1_msm_dev(const void *d_bases, size_t n_bases, size_t base_offset,
+                             const void *d_scalars, size_t n_scalars,
+                             const uint32_t *density, size_t density_bits,
+                             void *stream, uint64_t out_xyz[12]);
+int mi355zk_bn254_g2_msm_dev(const void *d_bases, size_t n_bases, size_t base_offset,
+                             const void *d_scalars, size_t n_scalars,
+                             const uint32_t *density, size_t density_bits,
+                             void *stream, uint64_t out_xyz[24]);
+/* exponent index at which the last failing multiexp of this thread raised its error, or -1 */
+long long mi355zk_last_error_index(void);
+/* window size c and window count the library would use for n scalars (diagnostics / DESIGN.md) */
+int mi355zk_msm_window_bits(size_t n_scalars, int *n_windows);
+
+/* ---- Fr NTT.  Replaces bellman/src/domain.rs:263 `best_fft` for T = Scalar<Bn256>:
+ * a[0..2^log_n) in place, natural order in and out, `omega` of order 2^log_n (Montgomery form). */
+int mi355zk_bn254_fr_ntt(uint64_t *a, uint32_t log_n, const uint64_t omega[4]);
+/* EvaluationDomain::{fft, ifft, coset_fft, icoset_fft} (domain.rs:154-203) with the constants
+ * `from_coeffs` derives for m = 2^log_n (domain.rs:84-98: omega, omegainv, geninv = 7^-1, minv). */
+int mi355zk_bn254_fr_domain_op(uint64_t *a, uint32_t log_n, int op);
+int mi355zk_bn254_fr_fft(uint64_t *a, uint32_t log_n);
+int mi355zk_bn254_fr_ifft(uint64_t *a, uint32_t log_n);
+int mi355zk_bn254_fr_coset_fft(uint64_t *a, uint32_t log_n);
+int mi355zk_bn254_fr_icoset_fft(uint64_t *a, uint32_t log_n);
+/* device-resident variants: asynchronous on `stream` (no host synchronisation). */
+int mi355zk_bn254_fr_ntt_dev(void *d_a, uint32_t log_n, const uint64_t omega[4], void *stream);
+int mi355zk_bn254_fr_domain_op_dev(void *d_a, uint32_t log_n, int op, void *stream);
+/* the domain constants themselves (Montgomery form), for callers that keep their own EvaluationDomain */
+int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_t omegainv[4], uint64_t geninv[4], uint64_t minv[4]);
+
+/* ---- batch fixed-base scalar multiplication out[i] = k[i] * P, affine (all-zero = infinity).
+ * Building block of the per-point `batch_exp` path (powersoftau/src/batched_accumulator.rs:1130-1181,
+ * SURVEY 8f row 1); used here to synthesise tau-table-like bases on the device. */
+int mi355zk_bn254_g1_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[8], const void *d_scalars, size_t n, void *stream);
+int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[16], const void *d_scalars, size_t n, void *stream);
+
+/* ---- plain device-memory helpers so that a C / Rust caller needs no HIP bindings of its own */
+int mi355zk_malloc(void **d_ptr, size_t bytes);
+int mi355zk_free(void *d_ptr);
+int mi355zk_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int mi355zk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+int mi355zk_sync(void *stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg.
+ * names: "msm_digits" "msm_sort" "msm_accumulate" "msm_reduce" "ntt_pass" "ntt_scale" */
+void mi355zk_prof_enable(int on);
+void mi355zk_prof_reset(void);
+int mi355zk_prof_get(const char *kernel, double *total_ms, long *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355ZK_H */

@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's interface for the accelerated path (thin; all compute is in
+libmi355zk.so through the C ABI).  The C++ twin of this file is host/bellman.hpp.
+
+Reference interface mirrored (same names, argument meaning, error behaviour):
+  bellman/src/multiexp.rs:330-340   multiexp(pool, bases, density_map, exponents) -> Future<Projective>
+  bellman/src/source.rs:36-140      (Arc<Vec<G>>, usize) source builder, FullDensity, DensityTracker
+  bellman/src/domain.rs:30-203      EvaluationDomain::{from_coeffs, fft, ifft, coset_fft, icoset_fft, ...}
+  bellman/src/multicore.rs:17-72    Worker
+  bellman/src/cs.rs:156-173         SynthesisError variants raised on this path
+
+Data may live on the host (numpy uint64 arrays -> host-buffer entry points) or already in HBM
+(torch CUDA tensors of dtype int64/uint64 -> `_dev` entry points on torch's current stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+FR_S = 28  # Fr::S, pairing/src/bn256/fr.rs:31-34
+
+
+class SynthesisError(Exception):
+    """bellman/src/cs.rs:156-173 (the variants this path can raise)."""
+
+    UNEXPECTED_IDENTITY = "UnexpectedIdentity"          # source.rs:50-52
+    IO_UNEXPECTED_EOF = "IoError(UnexpectedEof)"        # source.rs:46-48,62-64
+    POLYNOMIAL_DEGREE_TOO_LARGE = "PolynomialDegreeTooLarge"  # domain.rs:66-79
+
+    def __init__(self, kind: str, index: int = -1):
+        super().__init__(kind if index < 0 else f"{kind} at exponent {index}")
+        self.kind = kind
+        self.index = index
+
+
+class DeviceError(RuntimeError):
+    """HIP failure inside libmi355zk (no reference counterpart; there is no CPU fallback)."""
+
+
+class Worker:
+    """bellman/src/multicore.rs:17-35.  The reference's Worker is a CPU thread pool; here it names
+    the GPU the calling process drives (one process per GPU) and the stream work is issued on."""
+
+    def __init__(self, device: int | None = None):
+        self.device = device
+        ids = (C.c_int * 1)(device) if device is not None else None
+        rc = _lib.load().mi355zk_init(ids, 1 if device is not None else 0)
+        if rc != 0:
+            raise DeviceError(f"mi355zk_init failed (rc={rc})")
+
+    def log_num_cpus(self) -> int:  # multicore.rs:37-39; serial/parallel FFT split is moot on the GPU
+        return 0
+
+
+class FullDensity:
+    """source.rs:80-99"""
+
+    def get_query_size(self):
+        return None
+
+    def words(self):
+        return None, 0
+
+
+class DensityTracker:
+    """source.rs:101-140 (BitVec-backed in the reference; here a numpy uint32 word array with the
+    ABI's bit order: bit i = word i/32, bit i%32)."""
+
+    def __init__(self):
+        self._bits: list[bool] = []
+        self.total_density = 0
+
+    def add_element(self):
+        self._bits.append(False)
+
+    def inc(self, idx: int):
+        if not self._bits[idx]:
+            self._bits[idx] = True
+            self.total_density += 1
+
+    def get_total_density(self) -> int:
+        return self.total_density
+
+    def get_query_size(self):
+        return len(self._bits)
+
+    @classmethod
+    def from_bools(cls, bools) -> "DensityTracker":
+        d = cls()
+        d._bits = [bool(b) for b in bools]
+        d.total_density = sum(d._bits)
+        return d
+
+    def words(self):
+        n = len(self._bits)
+        w = np.zeros((n + 31) // 32 or 1, dtype=np.uint32)
+        if n:
+            bits = np.asarray(self._bits, dtype=np.uint8)
+            pad = np.zeros(w.size * 32, dtype=np.uint8)
+            pad[:n] = bits
+            w[:] = np.packbits(pad.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
+        return w, n
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Ready:
+    """A completed future (futures 0.1 `future::result`): multiexp() is synchronous here, which is
+    what singlecore::Worker::compute already is in the reference (singlecore.rs:33-47)."""
+
+    def __init__(self, value=None, error: Exception | None = None):
+        self._value, self._error = value, error
+
+    def wait(self):
+        if self._error is not None:
+            raise self._error
+        return self._value
+
+
+def multiexp(pool: Worker, bases, density_map, exponents) -> _Ready:
+    """bellman/src/multiexp.rs:330.  `bases` = (array, offset) like `(Arc<Vec<G>>, usize)`:
+    array of shape (n_bases, 8) u64 for G1Affine raw records or (n_bases, 16) for G2Affine;
+    `exponents` = (n, 4) u64 canonical FrRepr; `density_map` = FullDensity() or a DensityTracker.
+    Returns a ready future whose wait() yields the Jacobian X||Y||Z limbs (12 / 24 u64)."""
+    arr, offset = bases
+    qs = density_map.get_query_size()
+    n_exp = int(exponents.shape[0])
+    if qs is not None:
+        assert qs == n_exp  # multiexp.rs:347-352
+    words, dbits = density_map.words()
+    lib = _lib.load()
+    if _is_torch(arr):
+        import torch
+
+        assert arr.is_cuda and exponents.is_cuda and arr.is_contiguous() and exponents.is_contiguous()
+        limbs = arr.shape[1]
+        group = {8: 1, 16: 2}[limbs]
+        out = np.zeros(12 * group, dtype=np.uint64)
+        fn = lib.mi355zk_bn254_g1_msm_dev if group == 1 else lib.mi355zk_bn254_g2_msm_dev
+        with torch.cuda.device(arr.device):
+            rc = fn(C.c_void_p(arr.data_ptr()), arr.shape[0], offset, C.c_void_p(exponents.data_ptr()), n_exp,
+                    words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits, _stream_ptr(),
+                    out.ctypes.data_as(C.c_void_p))
+    else:
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        exponents = np.ascontiguousarray(exponents, dtype=np.uint64)
+        limbs = arr.shape[1] if arr.ndim == 2 else 8
+        group = {8: 1, 16: 2}[limbs]
+        out = np.zeros(12 * group, dtype=np.uint64)
+        fn = lib.mi355zk_bn254_g1_msm if group == 1 else lib.mi355zk_bn254_g2_msm
+        rc = fn(arr.ctypes.data_as(C.c_void_p), arr.shape[0], offset, exponents.ctypes.data_as(C.c_void_p), n_exp,
+                words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits, out.ctypes.data_as(C.c_void_p))
+    if rc == _lib.OK:
+        return _Ready(out)
+    idx = int(lib.mi355zk_last_error_index())
+    if rc == _lib.ERR_UNEXPECTED_IDENTITY:
+        return _Ready(error=SynthesisError(SynthesisError.UNEXPECTED_IDENTITY, idx))
+    if rc == _lib.ERR_UNEXPECTED_EOF:
+        return _Ready(error=SynthesisError(SynthesisError.IO_UNEXPECTED_EOF, idx))
+    if rc == _lib.ERR_BAD_ARGS:
+        return _Ready(error=ValueError("mi355zk: bad arguments"))
+    return _Ready(error=DeviceError(f"mi355zk device failure rc={rc}"))
+
+
+class EvaluationDomain:
+    """bellman/src/domain.rs:30-203 for G = Scalar<Bn256>: coefficients are (m, 4) u64 Montgomery Fr
+    limbs, either a numpy array or a torch CUDA tensor (int64 view)."""
+
+    def __init__(self, coeffs, exp: int):
+        self.coeffs = coeffs
+        self.exp = exp
+
+    @classmethod
+    def from_coeffs(cls, coeffs) -> "EvaluationDomain":
+        n = int(coeffs.shape[0])
+        if n > (1 << FR_S) - 1:  # domain.rs:66-68
+            raise SynthesisError(SynthesisError.POLYNOMIAL_DEGREE_TOO_LARGE)
+        m, exp = 1, 0
+        while m < n:  # domain.rs:70-79
+            m *= 2
+            exp += 1
+            if exp > FR_S:
+                raise SynthesisError(SynthesisError.POLYNOMIAL_DEGREE_TOO_LARGE)
+        if m != n:  # coeffs.resize(m, G::group_zero()), domain.rs:89
+            if _is_torch(coeffs):
+                import torch
+
+                pad = torch.zeros((m - n, 4), dtype=coeffs.dtype, device=coeffs.device)
+                coeffs = torch.cat([coeffs, pad]).contiguous()
+            else:
+                coeffs = np.concatenate([np.asarray(coeffs, dtype=np.uint64), np.zeros((m - n, 4), dtype=np.uint64)])
+        elif not _is_torch(coeffs):
+            coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).copy()
+        return cls(coeffs, exp)
+
+    def as_ref(self):
+        return self.coeffs
+
+    def into_coeffs(self):
+        return self.coeffs
+
+    def _op(self, op: int):
+        lib = _lib.load()
+        if _is_torch(self.coeffs):
+            import torch
+
+            assert self.coeffs.is_cuda and self.coeffs.is_contiguous()
+            with torch.cuda.device(self.coeffs.device):
+                rc = lib.mi355zk_bn254_fr_domain_op_dev(C.c_void_p(self.coeffs.data_ptr()), self.exp, op, _stream_ptr())
+        else:
+            rc = lib.mi355zk_bn254_fr_domain_op(self.coeffs.ctypes.data_as(C.c_void_p), self.exp, op)
+        if rc != 0:
+            raise DeviceError(f"mi355zk NTT failed rc={rc}")
+
+    def fft(self, worker: Worker):  # domain.rs:154
+        self._op(_lib.OP_FFT)
+
+    def ifft(self, worker: Worker):  # domain.rs:159
+        self._op(_lib.OP_IFFT)
+
+    def coset_fft(self, worker: Worker):  # domain.rs:191
+        self._op(_lib.OP_COSET_FFT)
+
+    def icoset_fft(self, worker: Worker):  # domain.rs:197
+        self._op(_lib.OP_ICOSET_FFT)
+
+
+def best_fft(a, worker: Worker, omega, log_n: int):
+    """bellman/src/domain.rs:263: in-place transform of `a` (numpy (2^log_n, 4) u64) with root `omega`."""
+    rc = _lib.load().mi355zk_bn254_fr_ntt(a.ctypes.data_as(C.c_void_p), log_n,
+                                          np.ascontiguousarray(omega, dtype=np.uint64).ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise DeviceError(f"mi355zk NTT failed rc={rc}")

@@ -1,0 +1,450 @@
+// C ABI of libmi355zk.so (include/mi355zk.h): argument checking, the Source/Density contract of
+// bellman/src/source.rs, H2D/D2H staging for the host-buffer entry points, domain constants of
+// bellman/src/domain.rs:52-99, and the kernel-timing hooks used by bench.py.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355zk.h"
+#include "curve.hpp"
+#include "device_util.hpp"
+
+namespace zk {
+// ntt.hip
+int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st);
+int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st);
+void ntt_release_all();
+int ntt_configure();
+// msm.hip
+int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index);
+int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index);
+void msm_release_g1();
+void msm_release_g2();
+void msm_geometry(uint64_t n, uint32_t* c, uint32_t* W);
+
+// ------------------------------------------------------------------------------------------------
+// profiling hooks
+namespace {
+struct ProfSlot {
+  std::string name;
+  double total_ms = 0;
+  long count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  hipEvent_t open = nullptr;
+};
+std::mutex g_prof_mu;
+std::vector<ProfSlot> g_prof;
+bool g_prof_on = false;
+}  // namespace
+
+void prof_enable(bool on) { g_prof_on = on; }
+bool prof_enabled() { return g_prof_on; }
+int prof_slot(const char* name) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (size_t i = 0; i < g_prof.size(); ++i)
+    if (g_prof[i].name == name) return (int)i;
+  g_prof.emplace_back();
+  g_prof.back().name = name;
+  return (int)g_prof.size() - 1;
+}
+void prof_begin(int slot, hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  g_prof[slot].open = e;
+}
+void prof_end(int slot, hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof[slot].open) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  g_prof[slot].pending.emplace_back(g_prof[slot].open, e);
+  g_prof[slot].open = nullptr;
+}
+void prof_collect() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& s : g_prof) {
+    for (auto& pr : s.pending) {
+      if (hipEventSynchronize(pr.second) == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+          s.total_ms += ms;
+          s.count += 1;
+        }
+      }
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    s.pending.clear();
+  }
+}
+bool prof_get(const char* name, double* total_ms, long* count) {
+  prof_collect();
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& s : g_prof)
+    if (s.name == name) {
+      *total_ms = s.total_ms;
+      *count = s.count;
+      return true;
+    }
+  return false;
+}
+void prof_reset() {
+  prof_collect();
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& s : g_prof) {
+    s.total_ms = 0;
+    s.count = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch fixed-base scalar multiplication (input synthesis + SURVEY 8f row 1 building block)
+template <class F>
+__global__ void __launch_bounds__(256) batch_mul_kernel(Affine<F>* __restrict__ out, Affine<F> base, const uint32_t* __restrict__ scalars,
+                                                       uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) s[l] = scalars[i * 8 + l];
+  XYZZ<F> acc = XYZZ<F>::zero();
+  if (!base.is_zero()) {
+    bool found = false;
+    for (int bit = 255; bit >= 0; --bit) {
+      bool b = (s[bit >> 5] >> (bit & 31)) & 1;
+      if (found) acc = xyzz_double(acc);
+      else found = b;
+      if (b) xyzz_add_mixed(acc, base.x, base.y, false);
+    }
+  }
+  out[i] = xyzz_to_affine(acc);
+}
+
+template <class F>
+int batch_mul(void* d_out, const uint64_t* base_raw, const void* d_scalars, size_t n, void* stream) {
+  if (!d_out || !base_raw || (!d_scalars && n)) return ZK_ERR_BAD_ARGS;
+  if (n == 0) return ZK_OK;
+  Affine<F> base;
+  std::memcpy(&base, base_raw, sizeof base);
+  hipLaunchKernelGGL(batch_mul_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (Affine<F>*)d_out, base,
+                     (const uint32_t*)d_scalars, (uint64_t)n);
+  ZK_HIP(hipGetLastError());
+  return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// domain constants (host arithmetic, same field code as the kernels)
+namespace {
+
+Fr fr_from_u64(uint64_t v) {
+  Fr c = Fr::zero();
+  c.l[0] = (uint32_t)v;
+  c.l[1] = (uint32_t)(v >> 32);
+  return from_canonical(c);
+}
+
+// ff_derive: ROOT_OF_UNITY = GENERATOR^((r-1) >> S) with GENERATOR = 7, S = 28 (fr.rs:3-6,31-34)
+Fr fr_root_of_unity() {
+  uint32_t e[8];
+  for (int i = 0; i < 8; ++i) e[i] = FrParams::P[i];
+  e[0] -= 1;
+  for (int i = 0; i < 8; ++i) e[i] = (e[i] >> 28) | (i < 7 ? e[i + 1] << 4 : 0);
+  return pow_limbs(fr_from_u64(7), e, 8);
+}
+
+struct DomainConsts {
+  Fr omega, omegainv, geninv, minv, gen;
+};
+
+// EvaluationDomain::from_coeffs for m = 2^exp (domain.rs:61-98)
+int domain_consts(uint32_t exp, DomainConsts* d) {
+  if (exp > 28) return ZK_ERR_BAD_ARGS;  // PolynomialDegreeTooLarge (domain.rs:75-77)
+  static const Fr rou = fr_root_of_unity();
+  Fr w = rou;
+  for (uint32_t i = exp; i < 28; ++i) w = sqr(w);
+  d->omega = w;
+  d->omegainv = inv(w);
+  d->gen = fr_from_u64(7);
+  d->geninv = inv(d->gen);
+  d->minv = inv(fr_from_u64(1ull << exp));
+  return ZK_OK;
+}
+
+int domain_op_dev(Fr* d_a, uint32_t log_n, int op, hipStream_t st) {
+  DomainConsts D;
+  int rc = domain_consts(log_n, &D);
+  if (rc) return rc;
+  switch (op) {
+    case MI355ZK_OP_FFT:  // domain.rs:154-157
+      return ntt_run(d_a, log_n, D.omega, st);
+    case MI355ZK_OP_IFFT:  // domain.rs:159-174: best_fft(omegainv) then *= minv
+      rc = ntt_run(d_a, log_n, D.omegainv, st);
+      if (rc) return rc;
+      return ntt_scale(d_a, log_n, D.minv, nullptr, st);
+    case MI355ZK_OP_COSET_FFT:  // domain.rs:191-195: distribute_powers(g) then fft
+      rc = ntt_scale(d_a, log_n, Fr::one(), &D.gen, st);
+      if (rc) return rc;
+      return ntt_run(d_a, log_n, D.omega, st);
+    case MI355ZK_OP_ICOSET_FFT:  // domain.rs:197-203: ifft then distribute_powers(geninv)
+      rc = ntt_run(d_a, log_n, D.omegainv, st);
+      if (rc) return rc;
+      return ntt_scale(d_a, log_n, D.minv, &D.geninv, st);
+    default:
+      return ZK_ERR_BAD_ARGS;
+  }
+}
+
+thread_local long long t_last_err_index = -1;
+
+// Source / QueryDensity contract (source.rs:36-118, multiexp.rs:92): returns the number of exponents
+// to process, the exponent index of the first UnexpectedEof (or -1) and, for a density map, the
+// per-word exclusive prefix popcounts.
+struct DensityPlan {
+  uint64_t n = 0;
+  long long eof_index = -1;
+  std::vector<uint32_t> prefix;
+};
+
+int plan_density(size_t n_bases, size_t base_offset, size_t n_scalars, const uint32_t* density, size_t density_bits, DensityPlan* P) {
+  uint64_t n = n_scalars;
+  if (density != nullptr && density_bits < n) n = density_bits;  // zip() stops at the shorter (multiexp.rs:92)
+  P->n = n;
+  uint64_t avail = base_offset < n_bases ? n_bases - base_offset : 0;
+  if (density == nullptr) {
+    if (n > avail) P->eof_index = (long long)avail;
+    return ZK_OK;
+  }
+  uint64_t words = (n + 31) / 32;
+  P->prefix.resize(words ? words : 1);
+  uint64_t used = 0;
+  for (uint64_t w = 0; w < words; ++w) {
+    P->prefix[w] = (uint32_t)used;
+    uint32_t v = density[w];
+    if (w == words - 1 && (n & 31)) v &= (1u << (n & 31)) - 1u;
+    uint32_t pc = (uint32_t)__builtin_popcount(v);
+    if (P->eof_index < 0 && used + pc > avail) {
+      // the (avail - used + 1)-th set bit of this word is the first exponent without a base
+      uint64_t need = avail - used;
+      for (uint32_t b = 0; b < 32; ++b)
+        if ((v >> b) & 1) {
+          if (need == 0) { P->eof_index = (long long)(w * 32 + b); break; }
+          --need;
+        }
+    }
+    used += pc;
+  }
+  return ZK_OK;
+}
+
+template <int GROUP>
+int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                  const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz) {
+  t_last_err_index = -1;
+  if (!out_xyz || (n_scalars && !d_scalars) || (n_bases && !d_bases)) return ZK_ERR_BAD_ARGS;
+  if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  hipStream_t st = (hipStream_t)stream;
+  DensityPlan P;
+  int rc = plan_density(n_bases, base_offset, n_scalars, density, density_bits, &P);
+  if (rc) return rc;
+  uint64_t n = P.eof_index >= 0 ? (uint64_t)P.eof_index : P.n;  // exponents before the first Eof
+  uint32_t* d_density = nullptr;
+  uint32_t* d_prefix = nullptr;
+  if (density != nullptr && n > 0) {
+    size_t words = (n + 31) / 32;
+    ZK_HIP(hipMalloc(&d_density, words * 8));
+    d_prefix = d_density + words;
+    ZK_HIP(hipMemcpyAsync(d_density, density, words * 4, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_prefix, P.prefix.data(), words * 4, hipMemcpyHostToDevice, st));
+  }
+  long long err_index = -1;
+  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index);
+  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index);
+  if (d_density) (void)hipFree(d_density);
+  if (rc == ZK_ERR_UNEXPECTED_IDENTITY) { t_last_err_index = err_index; return rc; }
+  if (rc != ZK_OK) return rc;
+  if (P.eof_index >= 0) { t_last_err_index = P.eof_index; return ZK_ERR_UNEXPECTED_EOF; }
+  return ZK_OK;
+}
+
+template <int GROUP>
+int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
+                   const uint32_t* density, size_t density_bits, uint64_t* out_xyz) {
+  if (!out_xyz || (n_scalars && !scalars) || (n_bases && !bases)) return ZK_ERR_BAD_ARGS;
+  const size_t bsz = GROUP == 1 ? 64 : 128;
+  void* d_bases = nullptr;
+  void* d_scalars = nullptr;
+  if (n_bases) {
+    ZK_HIP(hipMalloc(&d_bases, n_bases * bsz));
+    ZK_HIP(hipMemcpy(d_bases, bases, n_bases * bsz, hipMemcpyHostToDevice));
+  }
+  if (n_scalars) {
+    hipError_t e = hipMalloc(&d_scalars, n_scalars * 32);
+    if (e == hipSuccess) e = hipMemcpy(d_scalars, scalars, n_scalars * 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_bases); (void)hipFree(d_scalars); ZK_HIP(e); }
+  }
+  int rc = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, nullptr, out_xyz);
+  (void)hipFree(d_bases);
+  (void)hipFree(d_scalars);
+  return rc;
+}
+
+int ntt_host(uint64_t* a, uint32_t log_n, int op, const uint64_t* omega) {
+  if (!a) return ZK_ERR_BAD_ARGS;
+  if (log_n > 28) return ZK_ERR_BAD_ARGS;
+  size_t bytes = (size_t)32 << log_n;
+  void* d = nullptr;
+  ZK_HIP(hipMalloc(&d, bytes));
+  int rc;
+  hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(d); ZK_HIP(e); }
+  if (omega) {
+    Fr w;
+    std::memcpy(&w, omega, 32);
+    rc = ntt_run((Fr*)d, log_n, w, nullptr);
+  } else {
+    rc = domain_op_dev((Fr*)d, log_n, op, nullptr);
+  }
+  if (rc == ZK_OK) {
+    e = hipMemcpy(a, d, bytes, hipMemcpyDeviceToHost);  // synchronises with the null stream
+    if (e != hipSuccess) { (void)hipFree(d); ZK_HIP(e); }
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int mi355zk_init(const int* device_ids, int n_devices) {
+  if (device_ids != nullptr && n_devices > 0) ZK_HIP(hipSetDevice(device_ids[0]));
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  ZK_HIP(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "[mi355zk] device %d is %s; this library contains gfx950 code only\n", dev, prop.gcnArchName);
+    return ZK_ERR_DEVICE;
+  }
+  return ntt_configure();
+}
+
+void mi355zk_shutdown(void) {
+  ntt_release_all();
+  msm_release_g1();
+  msm_release_g2();
+}
+
+const char* mi355zk_version(void) { return "mi355zk 0.1 (gfx950)"; }
+
+int mi355zk_bn254_g1_msm(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
+                         const uint32_t* density, size_t density_bits, uint64_t out_xyz[12]) {
+  return msm_host_entry<1>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+}
+int mi355zk_bn254_g2_msm(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
+                         const uint32_t* density, size_t density_bits, uint64_t out_xyz[24]) {
+  return msm_host_entry<2>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+}
+int mi355zk_bn254_g1_msm_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                             const uint32_t* density, size_t density_bits, void* stream, uint64_t out_xyz[12]) {
+  return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+}
+int mi355zk_bn254_g2_msm_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                             const uint32_t* density, size_t density_bits, void* stream, uint64_t out_xyz[24]) {
+  return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+}
+long long mi355zk_last_error_index(void) { return t_last_err_index; }
+int mi355zk_msm_window_bits(size_t n_scalars, int* n_windows) {
+  uint32_t c = 0, W = 0;
+  msm_geometry(n_scalars, &c, &W);
+  if (n_windows) *n_windows = (int)W;
+  return (int)c;
+}
+
+int mi355zk_bn254_fr_ntt(uint64_t* a, uint32_t log_n, const uint64_t omega[4]) {
+  if (!omega) return ZK_ERR_BAD_ARGS;
+  return ntt_host(a, log_n, -1, omega);
+}
+int mi355zk_bn254_fr_domain_op(uint64_t* a, uint32_t log_n, int op) {
+  if (op < 0 || op > 3) return ZK_ERR_BAD_ARGS;
+  return ntt_host(a, log_n, op, nullptr);
+}
+int mi355zk_bn254_fr_fft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_FFT, nullptr); }
+int mi355zk_bn254_fr_ifft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_IFFT, nullptr); }
+int mi355zk_bn254_fr_coset_fft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_COSET_FFT, nullptr); }
+int mi355zk_bn254_fr_icoset_fft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_ICOSET_FFT, nullptr); }
+int mi355zk_bn254_fr_ntt_dev(void* d_a, uint32_t log_n, const uint64_t omega[4], void* stream) {
+  if (!d_a || !omega || log_n > 28) return ZK_ERR_BAD_ARGS;
+  Fr w;
+  std::memcpy(&w, omega, 32);
+  return ntt_run((Fr*)d_a, log_n, w, (hipStream_t)stream);
+}
+int mi355zk_bn254_fr_domain_op_dev(void* d_a, uint32_t log_n, int op, void* stream) {
+  if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;
+  return domain_op_dev((Fr*)d_a, log_n, op, (hipStream_t)stream);
+}
+int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_t omegainv[4], uint64_t geninv[4], uint64_t minv[4]) {
+  DomainConsts D;
+  int rc = domain_consts(log_n, &D);
+  if (rc) return rc;
+  if (omega) std::memcpy(omega, &D.omega, 32);
+  if (omegainv) std::memcpy(omegainv, &D.omegainv, 32);
+  if (geninv) std::memcpy(geninv, &D.geninv, 32);
+  if (minv) std::memcpy(minv, &D.minv, 32);
+  return ZK_OK;
+}
+
+int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[8], const void* d_scalars, size_t n, void* stream) {
+  return batch_mul<Fq>(d_out_affine, base_affine, d_scalars, n, stream);
+}
+int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[16], const void* d_scalars, size_t n, void* stream) {
+  return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
+}
+
+int mi355zk_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return ZK_ERR_BAD_ARGS;
+  ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return ZK_OK;
+}
+int mi355zk_free(void* d_ptr) {
+  ZK_HIP(hipFree(d_ptr));
+  return ZK_OK;
+}
+int mi355zk_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  ZK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return ZK_OK;
+}
+int mi355zk_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  ZK_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return ZK_OK;
+}
+int mi355zk_sync(void* stream) {
+  ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return ZK_OK;
+}
+
+void mi355zk_prof_enable(int on) { prof_enable(on != 0); }
+void mi355zk_prof_reset(void) { prof_reset(); }
+int mi355zk_prof_get(const char* kernel, double* total_ms, long* count) {
+  double t = 0;
+  long c = 0;
+  bool ok = kernel && prof_get(kernel, &t, &c);
+  if (total_ms) *total_ms = t;
+  if (count) *count = c;
+  return ok ? ZK_OK : ZK_ERR_BAD_ARGS;
+}
+
+}  // extern "C"

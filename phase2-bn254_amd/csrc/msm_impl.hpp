@@ -1,0 +1,420 @@
+#pragma once
+// Pippenger multi-scalar multiplication over BN254 G1 / G2 for gfx950 (MI355X).
+//
+// Replaces, behind the C ABI of include/mi355zk.h, the reference's
+//   bellman/src/multiexp.rs:330-355  multiexp()          (window choice, density contract)
+//   bellman/src/multiexp.rs:53-157   multiexp_inner()    (bucket fill, summation by parts, window join)
+//   bellman/src/source.rs:36-70      (Arc<Vec<G>>, usize) Source: cursor + error semantics
+// and the group law underneath (pairing/src/bn256/ec.rs:301-536).
+//
+// MI355X design (DESIGN.md "MSM"), not the reference's one-thread-per-window scan:
+//   1. msm_digits_kernel      every scalar -> W signed c-bit digits; one (bucket key, base index|sign)
+//                             pair per window; identity-base check (source.rs:50-52) fused in.
+//   2. radix sort by key      (rocPRIM device radix sort; HBM-bound, ~3 passes over 8 B/pair)
+//   3. msm_bounds_kernel      first/last position of every bucket in the sorted pair list
+//   4. msm_accumulate_kernel  ONE LANE PER BUCKET for all W * 2^(c-1) buckets at once (2^19 lanes at
+//                             2^20 points): gathers its affine bases and folds them into an XYZZ
+//                             accumulator held in VGPRs (8M+2S per point) -- the dominant kernel.
+//   5. msm_reduce_kernel(s)   sum_k k*B_k per window: chunked running sums + small scalar fix-up,
+//                             then an LDS tree per window.
+//   6. host                   join of W window sums: c doublings + add per window (multiexp.rs:146-154).
+// The result is a group element; the reference compares/normalises projective points by value
+// (ec.rs:45-85, 596-629), so parity is defined on the affine normalisation.
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // before rocprim: its texture iterator calls the host memset
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "curve.hpp"
+#include "device_util.hpp"
+
+namespace zk {
+
+namespace {  // one copy per translation unit (msm_g1.hip / msm_g2.hip): compiled in parallel
+
+constexpr uint32_t SIGN_BIT = 0x80000000u;
+
+struct MsmGeom {
+  uint32_t c;        // window bits
+  uint32_t W;        // windows
+  uint32_t nb;       // buckets per window = 2^(c-1)
+  uint32_t invalid;  // key of "no contribution" = W * nb
+};
+
+template <class F>
+__device__ __forceinline__ Affine<F> load_affine(const Affine<F>* p) {
+  // sizeof(Affine<F>) is 64 (G1) or 128 (G2): 4 / 8 x 16-byte loads
+  Affine<F> r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(Affine<F>) / 16); ++i) d[i] = q[i];
+  return r;
+}
+
+template <class T>
+__device__ __forceinline__ void store_vec(T* p, const T& v) {
+  const uint4* s = reinterpret_cast<const uint4*>(&v);
+  uint4* d = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 16); ++i) d[i] = s[i];
+}
+template <class T>
+__device__ __forceinline__ T load_vec(const T* p) {
+  T r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 16); ++i) d[i] = q[i];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. digits.  density == nullptr: FullDensity (source.rs:80-99): base of exponent i is base_offset+i.
+//    Otherwise bit i of `density` selects exponent i and the bases are compacted (source.rs:101-118):
+//    rank(i) = dprefix[i/32] + popc(density[i/32] & ((1<<i%32)-1)).
+template <class F>
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, const Affine<F>* __restrict__ bases,
+                                                        uint64_t n, uint64_t base_offset, const uint32_t* __restrict__ density,
+                                                        const uint32_t* __restrict__ dprefix, MsmGeom G, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, unsigned long long* __restrict__ err_index) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool active = true;
+  uint64_t bi = base_offset + i;
+  if (density != nullptr) {
+    uint32_t wd = density[i >> 5];
+    active = (wd >> (i & 31)) & 1;
+    bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
+  }
+  uint32_t s[9];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  uint4 s0 = sp[0], s1 = sp[1];
+  s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
+  uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
+  if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
+    for (uint32_t w = 0; w < G.W; ++w) keys[(uint64_t)w * n + i] = G.invalid;
+    return;
+  }
+  // a selected base with a non-zero exponent must not be the identity (source.rs:50-52)
+  if (load_affine(bases + bi).is_zero()) atomicMin(err_index, (unsigned long long)i);
+  uint32_t carry = 0;
+  const uint32_t mask = (1u << G.c) - 1u;
+  for (uint32_t w = 0; w < G.W; ++w) {
+    uint32_t bit = w * G.c;
+    uint32_t limb = bit >> 5, off = bit & 31;
+    uint64_t two = limb < 8 ? ((uint64_t)s[limb] | ((uint64_t)s[limb + 1] << 32)) : 0ull;
+    uint32_t d = ((uint32_t)(two >> off) & mask) + carry;
+    uint32_t neg = 0;
+    carry = 0;
+    if (d > G.nb) {  // d in (2^(c-1), 2^c]  ->  d - 2^c in (-2^(c-1), 0]
+      d = (1u << G.c) - d;
+      neg = (d != 0) ? SIGN_BIT : 0;
+      carry = 1;
+    }
+    uint64_t o = (uint64_t)w * n + i;
+    keys[o] = d ? (w * G.nb + d - 1) : G.invalid;
+    vals[o] = (uint32_t)bi | neg;
+  }
+}
+
+// 3. bucket boundaries in the sorted pair list
+__global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t invalid,
+                                                        uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t k = keys[j];
+  if (k >= invalid) return;
+  if (j == 0 || keys[j - 1] != k) first[k] = (uint32_t)j;
+  if (j + 1 == m || keys[j + 1] != k) last[k] = (uint32_t)j + 1;
+}
+
+// 4. one lane per bucket
+template <class F>
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                                            const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                            uint32_t n_buckets, XYZZ<F>* __restrict__ buckets) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) return;
+  XYZZ<F> acc = XYZZ<F>::zero();
+  uint32_t j = first[b], e = last[b];
+  for (; j < e; ++j) {
+    uint32_t v = vals[j];
+    Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
+    xyzz_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+  }
+  store_vec(buckets + b, acc);
+}
+
+// 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
+//    split the index x = ch*L + y:   sum_x (x+off) B[x] = sum_ch A[ch] + L * sum_ch ch * S[ch]
+//    with A[ch] = sum_y (y+off) B[ch*L+y] (running sums) and S[ch] = sum_y B[ch*L+y]; the second term
+//    is the same problem on the L-times shorter array S with off = 0.  Each level is one launch of
+//    msm_reduce_level_kernel (a lane per chunk) plus a per-window sum of its A[]; the host applies
+//    the powers of L (log2 L doublings per level) while it joins the windows.
+//    The two running-sum additions share ONE inlined xyzz_add (selected operands): these kernels are
+//    not hot, and a single call site keeps the gfx950 code size / compile time down (Fq2 above all).
+template <class F>
+__global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t L, uint32_t off,
+                                                              uint32_t W, XYZZ<F>* __restrict__ outA, XYZZ<F>* __restrict__ outS) {
+  uint32_t chunks = (count + L - 1) / L;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= chunks * W) return;
+  uint32_t w = t / chunks, ch = t % chunks;
+  uint32_t lo = ch * L, hi = lo + L < count ? lo + L : count;
+  const XYZZ<F>* B = in + (uint64_t)w * count;
+  XYZZ<F> run = XYZZ<F>::zero(), acc = XYZZ<F>::zero();
+  uint32_t steps = 2 * (hi - lo);
+  for (uint32_t it = 0; it < steps; ++it) {
+    uint32_t x = hi - 1 - (it >> 1);
+    // off == 1: run += B[x]; acc += run   (weights y+1)      off == 0: acc += run; run += B[x]   (weights y)
+    bool do_acc = ((it & 1) != 0) == (off != 0);
+    XYZZ<F> a = do_acc ? acc : run;
+    XYZZ<F> b = do_acc ? run : load_vec(B + x);
+    xyzz_add(a, b);
+    if (do_acc) acc = a;
+    else run = a;
+  }
+  store_vec(outA + t, acc);
+  store_vec(outS + t, run);
+}
+
+// out[w] = sum_{i < count} in[w*count + i]   (one workgroup per window; strided serial sums, then an LDS tree)
+template <class F>
+__global__ void __launch_bounds__(128) msm_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, XYZZ<F>* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const XYZZ<F>* P = in + (uint64_t)blockIdx.x * count;
+  XYZZ<F> acc = XYZZ<F>::zero();
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) xyzz_add(acc, load_vec(P + i));
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      XYZZ<F> a = sh[threadIdx.x];
+      xyzz_add(a, sh[threadIdx.x + s]);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_vec(out + blockIdx.x, sh[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+struct Workspace {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+std::mutex g_ws_mu;                 // serialises MSM calls sharing a device workspace
+std::map<int, Workspace> g_ws;      // per device
+
+int ws_reserve(int dev, size_t bytes, void** out) {
+  Workspace& w = g_ws[dev];
+  if (w.bytes < bytes) {
+    if (w.p) ZK_HIP(hipFree(w.p));
+    w.p = nullptr;
+    w.bytes = 0;
+    ZK_HIP(hipMalloc(&w.p, bytes));
+    w.bytes = bytes;
+  }
+  *out = w.p;
+  return 0;
+}
+
+void ws_release_all() {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (auto& kv : g_ws) {
+    (void)hipSetDevice(kv.first);
+    (void)hipFree(kv.second.p);
+  }
+  g_ws.clear();
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Window size.  The reference uses c = ceil(ln n) (multiexp.rs:341-345), sized for its
+// one-thread-per-window scan.  Here every bucket of every window is a lane, so c trades
+// W*n mixed adds (10 mul each) against W*2^(c-1) buckets to reduce (~35 mul each) while keeping
+// enough buckets to fill 256 CUs.  Override: env MI355ZK_MSM_C.
+MsmGeom choose_geom(uint64_t n, int group) {
+  static const char* env = std::getenv("MI355ZK_MSM_C");
+  uint32_t best_c = 0;
+  double best = 1e300;
+  for (uint32_t c = 4; c <= 24; ++c) {
+    double W = std::ceil(254.0 / c) + ((254 % c) == 0 ? 1 : 0);
+    double nbk = std::ldexp(1.0, (int)c - 1);
+    double cost = W * (10.0 * (double)n + 40.0 * nbk);
+    // occupancy term: fewer than ~2^17 bucket lanes leaves CUs idle during accumulation
+    double lanes = W * nbk;
+    if (lanes < 131072.0) cost *= (1.0 + 0.5 * (131072.0 / lanes - 1.0));
+    if (cost < best) { best = cost; best_c = c; }
+  }
+  (void)group;
+  if (env) {
+    int v = std::atoi(env);
+    if (v >= 2 && v <= 24) best_c = (uint32_t)v;
+  }
+  MsmGeom G;
+  G.c = best_c;
+  G.W = (254 + best_c - 1) / best_c + ((254 % best_c) == 0 ? 1 : 0);
+  G.nb = 1u << (best_c - 1);
+  G.invalid = G.W * G.nb;
+  return G;
+}
+
+template <class F>
+int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n,
+               const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out) {
+  *out = Jacobian<F>::zero();
+  *err_index_out = -1;
+  if (n == 0) return ZK_OK;
+  if (n_bases > 0x7fffffffull || n > 0x7fffffffull) return ZK_ERR_BAD_ARGS;
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  const MsmGeom G = choose_geom(n, (int)(sizeof(F) / sizeof(Fq)));
+  const uint64_t m = n * G.W;
+  if (m > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
+  const uint32_t n_buckets = G.W * G.nb;
+  // reduction levels (see msm_reduce_level_kernel): cnt_0 = nb, cnt_{i+1} = ceil(cnt_i / L)
+  const uint32_t L = 8, LOG_L = 3;
+  uint32_t lvl_cnt[16], lvl_chunks[16], n_levels = 0;
+  uint64_t total_chunks = 0;
+  for (uint32_t cnt = G.nb;; cnt = lvl_chunks[n_levels - 1]) {
+    lvl_cnt[n_levels] = cnt;
+    lvl_chunks[n_levels] = (cnt + L - 1) / L;
+    total_chunks += lvl_chunks[n_levels];
+    ++n_levels;
+    if (lvl_chunks[n_levels - 1] == 1) break;
+  }
+
+  int key_bits = 1;
+  while ((1ull << key_bits) <= G.invalid) ++key_bits;
+
+  size_t sort_tmp_bytes = 0;
+  ZK_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                   (uint32_t*)nullptr, (size_t)m, 0, key_bits, st));
+
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  size_t o_keys_a = take(m * 4), o_keys_b = take(m * 4), o_vals_a = take(m * 4), o_vals_b = take(m * 4);
+  size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4);
+  size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
+  size_t o_partA = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
+  size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
+  size_t o_wsums = take((size_t)G.W * n_levels * sizeof(XYZZ<F>));
+  size_t o_err = take(8);
+  size_t o_sort = take(sort_tmp_bytes);
+
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  void* base = nullptr;
+  int rc = ws_reserve(dev, off, &base);
+  if (rc) return rc;
+  char* ws = (char*)base;
+  uint32_t* keys_a = (uint32_t*)(ws + o_keys_a);
+  uint32_t* keys_b = (uint32_t*)(ws + o_keys_b);
+  uint32_t* vals_a = (uint32_t*)(ws + o_vals_a);
+  uint32_t* vals_b = (uint32_t*)(ws + o_vals_b);
+  uint32_t* first = (uint32_t*)(ws + o_first);
+  uint32_t* last = (uint32_t*)(ws + o_last);
+  XYZZ<F>* buckets = (XYZZ<F>*)(ws + o_buckets);
+  XYZZ<F>* partA = (XYZZ<F>*)(ws + o_partA);
+  XYZZ<F>* partS = (XYZZ<F>*)(ws + o_partS);
+  XYZZ<F>* wsums = (XYZZ<F>*)(ws + o_wsums);
+  unsigned long long* d_err = (unsigned long long*)(ws + o_err);
+
+  ZK_HIP(hipMemsetAsync(d_err, 0xff, 8, st));
+  ZK_HIP(hipMemsetAsync(first, 0, (size_t)(n_buckets + 1) * 4, st));
+  ZK_HIP(hipMemsetAsync(last, 0, (size_t)(n_buckets + 1) * 4, st));
+
+  static const bool debug = std::getenv("MI355ZK_DEBUG") != nullptr;
+  auto checkpoint = [&](const char* what) -> int {
+    if (!debug) return 0;
+    ZK_HIP(hipStreamSynchronize(st));
+    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u L=%u: %s done\n", (int)(sizeof(F) / sizeof(Fq)),
+                 (unsigned long long)n, G.c, G.W, n_buckets, L, what);
+    return 0;
+  };
+  static const int slot_digits = prof_slot("msm_digits"), slot_sort = prof_slot("msm_sort"),
+                   slot_acc = prof_slot("msm_accumulate"), slot_red = prof_slot("msm_reduce");
+
+  prof_begin(slot_digits, st);
+  hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_bases, n, base_offset,
+                     d_density, d_dprefix, G, keys_a, vals_a, d_err);
+  ZK_HIP(hipGetLastError());
+  prof_end(slot_digits, st);
+  if (checkpoint("digits")) return ZK_ERR_DEVICE;
+
+  prof_begin(slot_sort, st);
+  ZK_HIP(rocprim::radix_sort_pairs((void*)(ws + o_sort), sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, key_bits, st));
+  hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys_b, m, G.invalid, first, last);
+  ZK_HIP(hipGetLastError());
+  prof_end(slot_sort, st);
+  if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
+
+  prof_begin(slot_acc, st);
+  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, d_bases, vals_b, first, last, n_buckets,
+                     buckets);
+  ZK_HIP(hipGetLastError());
+  prof_end(slot_acc, st);
+  if (checkpoint("accumulate")) return ZK_ERR_DEVICE;
+
+  prof_begin(slot_red, st);
+  {
+    const XYZZ<F>* in = buckets;
+    uint64_t o = 0;
+    for (uint32_t lv = 0; lv < n_levels; ++lv) {
+      uint32_t threads = lvl_chunks[lv] * G.W;
+      XYZZ<F>* A = partA + o * G.W;
+      XYZZ<F>* S = partS + o * G.W;
+      hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], L, lv == 0 ? 1u : 0u,
+                         G.W, A, S);
+      ZK_HIP(hipGetLastError());
+      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(G.W), dim3(128), 128 * sizeof(XYZZ<F>), st, A, lvl_chunks[lv], wsums + (uint64_t)lv * G.W);
+      ZK_HIP(hipGetLastError());
+      in = S;
+      o += lvl_chunks[lv];
+    }
+  }
+  prof_end(slot_red, st);
+  if (checkpoint("reduce")) return ZK_ERR_DEVICE;
+
+  std::vector<XYZZ<F>> h_wsums((size_t)G.W * n_levels);
+  unsigned long long h_err = 0;
+  ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_levels * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  if (h_err != ~0ull) {
+    *err_index_out = (long long)h_err;
+    return ZK_ERR_UNEXPECTED_IDENTITY;
+  }
+  // window sum T_w = A_0 + L*(A_1 + L*(A_2 + ...)), then the join of the windows, most significant
+  // first: c doublings + add per window (multiexp.rs:146-154)
+  auto window_sum = [&](uint32_t w) {
+    Jacobian<F> t = xyzz_to_jacobian(h_wsums[(size_t)(n_levels - 1) * G.W + w]);
+    for (int lv = (int)n_levels - 2; lv >= 0; --lv) {
+      for (uint32_t k = 0; k < LOG_L; ++k) jac_double(t);
+      jac_add(t, xyzz_to_jacobian(h_wsums[(size_t)lv * G.W + w]));
+    }
+    return t;
+  };
+  Jacobian<F> acc = window_sum(G.W - 1);
+  for (int w = (int)G.W - 2; w >= 0; --w) {
+    for (uint32_t k = 0; k < G.c; ++k) jac_double(acc);
+    jac_add(acc, window_sum((uint32_t)w));
+  }
+  *out = acc;
+  return ZK_OK;
+}
+
+}  // namespace
+
+}  // namespace zk

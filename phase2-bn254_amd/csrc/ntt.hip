@@ -1,0 +1,376 @@
+// Radix-2 number-theoretic transform over BN254 Fr for gfx950 (MI355X).
+//
+// Replaces, behind the C ABI of include/mi355zk.h, the reference's
+//   bellman/src/domain.rs:263-376  best_fft / serial_fft / parallel_fft   (-> ntt_run)
+//   bellman/src/domain.rs:159-203  ifft scaling, distribute_powers, coset_fft, icoset_fft
+// for `Scalar<Bn256>` elements (bellman/src/group.rs:53-82): 32-byte Montgomery Fr limbs, natural
+// order in, natural order out, in place.
+//
+// Algorithm (not the reference's): a size-N transform is factored N = N_1 * ... * N_R (R <= 3,
+// N_p <= 1024) Cooley-Tukey style.  Pass p transforms digit p of the index for G adjacent
+// "columns" at once: a workgroup stages a G x N_p tile (<= 4096 elements, 128 KiB) in LDS as eight
+// 32-bit limb planes (conflict-free ds_read_b32 for unit-stride lanes), runs log2(N_p) DIF stages
+// there, multiplies by the inter-pass twiddle omega^(T_p*k_p*rest) and writes back.  The last pass
+// writes straight to the natural-order position (fused digit-reversal), with the G tile rows chosen
+// so that both its loads and its stores are >= 128-byte contiguous.  HBM traffic: 64 B per element
+// per pass (R passes) -- DESIGN.md "NTT".  The mathematical result X[k] = sum_i a[i] w^(ik) is
+// unique, and Fr elements are kept fully reduced, so the output limbs are bit-identical to
+// serial_fft's.
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "curve.hpp"
+#include "device_util.hpp"
+
+namespace zk {
+
+namespace {
+
+constexpr int NTT_MAX_LOG_NP = 10;   // 1024-point sub-transform per tile row
+constexpr int NTT_TILE_ELEMS = 4096; // G * N_p
+constexpr int NTT_THREADS = 1024;
+
+struct NttPassParams {
+  uint32_t log_np;       // log2(N_p)
+  uint32_t g;            // rows (batch) per tile
+  uint64_t in_xs, in_gs; // element strides (in elements) of transform index / batch index on load
+  uint64_t out_xs, out_gs;
+  // tile -> base offsets: tile id = hi * tiles_lo + lo
+  uint64_t tiles_lo;
+  uint64_t in_hi_stride, in_lo_stride;
+  uint64_t out_hi_stride, out_lo_stride;
+  uint32_t load_x_fastest;  // lane order on load: 1 = transform index fastest (last pass)
+  // inter-pass twiddle  w^(tw_mul * k * (lo*g + gidx)) ; tw_mul == 0 -> none
+  uint64_t tw_mul;
+  uint32_t tw_h;            // two-level split: w^e = A[e >> h] * B[e & (2^h - 1)]
+};
+
+__device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t plane, uint32_t idx) {
+  Fr r;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) r.l[l] = lds[l * plane + idx];
+  return r;
+}
+__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t plane, uint32_t idx, const Fr& v) {
+#pragma unroll
+  for (int l = 0; l < 8; ++l) lds[l * plane + idx] = v.l[l];
+}
+__device__ __forceinline__ Fr gload(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// One pass over one tile.  roots[x] = w_p^x for x < N_p/2 (w_p = omega^(N/N_p)).
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, NttPassParams P,
+                                                              const Fr* __restrict__ roots, const Fr* __restrict__ twA,
+                                                              const Fr* __restrict__ twB) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t np = 1u << P.log_np;
+  const uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
+  const uint32_t plane = P.g * pitch;
+  const uint32_t elems = P.g * np;
+  const uint64_t tile = blockIdx.x;
+  const uint64_t hi = tile / P.tiles_lo, lo = tile % P.tiles_lo;
+  const Fr* src = in + hi * P.in_hi_stride + lo * P.in_lo_stride;
+  Fr* dst = out + hi * P.out_hi_stride + lo * P.out_lo_stride;
+
+  for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
+    uint32_t x, g;
+    if (P.load_x_fastest) { x = e & (np - 1); g = e >> P.log_np; }
+    else { g = e % P.g; x = e / P.g; }
+    lds_store(lds, plane, g * pitch + x, gload(src + x * P.in_xs + g * P.in_gs));
+  }
+  __syncthreads();
+
+  // DIF stages: natural order in, bit-reversed order out (within each row)
+  const uint32_t half = elems >> 1;
+  for (int s = (int)P.log_np - 1; s >= 0; --s) {
+    const uint32_t m = 1u << s;
+    for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
+      uint32_t g = b >> (P.log_np - 1);
+      uint32_t bf = b & ((np >> 1) - 1);
+      uint32_t j = bf & (m - 1);
+      uint32_t i0 = g * pitch + ((bf >> s) << (s + 1)) + j;
+      uint32_t i1 = i0 + m;
+      Fr u = lds_load(lds, plane, i0);
+      Fr v = lds_load(lds, plane, i1);
+      Fr d = sub(u, v);
+      if (s != 0) d = mul(d, gload(roots + ((uint64_t)j << (P.log_np - 1 - s))));  // j == 0 only when s == 0 -> w = 1
+      lds_store(lds, plane, i0, add(u, v));
+      lds_store(lds, plane, i1, d);
+    }
+    __syncthreads();
+  }
+
+  for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
+    uint32_t g = e % P.g, k = e / P.g;
+    Fr v = lds_load(lds, plane, g * pitch + bitrev(k, P.log_np));
+    if (P.tw_mul != 0 && k != 0) {
+      uint64_t rest = lo * P.g + g;
+      if (rest != 0) {
+        uint64_t ex = P.tw_mul * k * rest;
+        Fr w = mul(gload(twA + (ex >> P.tw_h)), gload(twB + (ex & ((1ull << P.tw_h) - 1))));
+        v = mul(v, w);
+      }
+    }
+    gstore(dst + k * P.out_xs + g * P.out_gs, v);
+  }
+}
+
+// tab[j] = base^(j * step), j < count
+__global__ void ntt_pow_table_kernel(Fr* tab, Fr base, uint64_t step, uint64_t count) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  tab[j] = pow_u64(base, j * step);
+}
+
+// a[i] *= c * gA[i >> h] * gB[i & mask]   (gA == nullptr: a[i] *= c)
+__global__ void ntt_scale_kernel(Fr* a, uint64_t n, Fr c, const Fr* __restrict__ gA, const Fr* __restrict__ gB, uint32_t h) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr v = gload(a + i);
+  Fr w = c;
+  if (gA != nullptr) w = mul(w, mul(gload(gA + (i >> h)), gload(gB + (i & ((1ull << h) - 1)))));
+  gstore(a + i, mul(v, w));
+}
+
+struct Key {
+  int dev;
+  uint32_t log_n;
+  uint32_t w[8];
+  bool operator<(const Key& o) const {
+    if (dev != o.dev) return dev < o.dev;
+    if (log_n != o.log_n) return log_n < o.log_n;
+    for (int i = 0; i < 8; ++i)
+      if (w[i] != o.w[i]) return w[i] < o.w[i];
+    return false;
+  }
+};
+
+// Per (device, log_n, omega) tables; built once and kept (the prover reuses one domain size for
+// every fft of a proof: bellman/src/groth16/prover.rs:217-241).
+struct PowTables {
+  uint32_t h = 0;          // w^e = A[e >> h] * B[e & (2^h-1)], e < 2^log_n
+  Fr* A = nullptr;
+  Fr* B = nullptr;
+  Fr* roots[NTT_MAX_LOG_NP + 1] = {};  // roots[b][x] = (w^(N/2^b))^x, x < 2^(b-1)
+};
+
+std::mutex g_mu;
+std::map<Key, PowTables> g_tables;
+
+int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_roots, const uint32_t* bs, int nb, PowTables** out) {
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  Key key;
+  key.dev = dev;
+  key.log_n = log_n;
+  for (int i = 0; i < 8; ++i) key.w[i] = w.l[i];
+  std::lock_guard<std::mutex> lk(g_mu);
+  PowTables& T = g_tables[key];
+  bool built = false;
+  if (T.A == nullptr) {
+    built = true;
+    T.h = (log_n + 1) / 2;
+    uint64_t nB = 1ull << T.h, nA = 1ull << (log_n - T.h);
+    ZK_HIP(hipMalloc(&T.A, nA * sizeof(Fr)));
+    ZK_HIP(hipMalloc(&T.B, nB * sizeof(Fr)));
+    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, st, T.A, w, nB, nA);
+    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, st, T.B, w, 1ull, nB);
+    ZK_HIP(hipGetLastError());
+  }
+  if (want_roots) {
+    for (int p = 0; p < nb; ++p) {
+      uint32_t b = bs[p];
+      if (b == 0 || T.roots[b] != nullptr) continue;
+      built = true;
+      uint64_t cnt = 1ull << (b - 1);
+      ZK_HIP(hipMalloc(&T.roots[b], cnt * sizeof(Fr)));
+      hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.roots[b], w, 1ull << (log_n - b), cnt);
+      ZK_HIP(hipGetLastError());
+    }
+  }
+  if (built) ZK_HIP(hipStreamSynchronize(st));  // one-time: tables may be used from other streams later
+  *out = &T;
+  return 0;
+}
+
+struct ScratchBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+std::map<int, ScratchBuf> g_scratch;  // per device; guarded by g_run_mu
+std::mutex g_run_mu;                  // serialises NTT calls that share the scratch buffer
+
+std::once_flag g_cfg_once;
+int g_cfg_rc = 0;
+
+}  // namespace
+
+// the tile kernel stages up to 4 x 1025 x 32 B = 128 KiB in dynamic LDS (gfx950: 160 KiB per CU)
+int ntt_configure() {
+  std::call_once(g_cfg_once, [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(ntt_pass_kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
+      g_cfg_rc = ZK_ERR_DEVICE;
+    }
+  });
+  return g_cfg_rc;
+}
+
+void ntt_release_all() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_tables) {
+    (void)hipSetDevice(kv.first.dev);
+    (void)hipFree(kv.second.A);
+    (void)hipFree(kv.second.B);
+    for (auto* r : kv.second.roots) (void)hipFree(r);
+  }
+  g_tables.clear();
+  std::lock_guard<std::mutex> lk2(g_run_mu);
+  for (auto& kv : g_scratch) {
+    (void)hipSetDevice(kv.first);
+    (void)hipFree(kv.second.p);
+  }
+  g_scratch.clear();
+}
+
+// d_a: 2^log_n Fr elements on the current device.  X[k] = sum_i a[i] * omega^(i*k), in place.
+int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st) {
+  if (log_n == 0) return 0;
+  if (log_n > 30) return ZK_ERR_BAD_ARGS;
+  const uint64_t n = 1ull << log_n;
+  // factor the index: R passes of b[p] bits, b[0] most significant digit (DESIGN.md "NTT")
+  uint32_t b[3];
+  int R = (int)((log_n + NTT_MAX_LOG_NP - 1) / NTT_MAX_LOG_NP);
+  for (int p = 0; p < R; ++p) b[p] = log_n / R + ((uint32_t)p < log_n % R ? 1 : 0);
+
+  int rc = ntt_configure();
+  if (rc) return rc;
+  PowTables* T = nullptr;
+  rc = build_pow_tables(st, log_n, omega, true, b, R, &T);
+  if (rc) return rc;
+  static const int slot_pass = prof_slot("ntt_pass");
+
+  std::lock_guard<std::mutex> run_lk(g_run_mu);
+  Fr* scratch = nullptr;
+  if (R > 1) {
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    ScratchBuf& sb = g_scratch[dev];
+    if (sb.bytes < n * sizeof(Fr)) {
+      if (sb.p) ZK_HIP(hipFree(sb.p));
+      sb.p = nullptr;
+      sb.bytes = 0;
+      ZK_HIP(hipMalloc(&sb.p, n * sizeof(Fr)));
+      sb.bytes = n * sizeof(Fr);
+    }
+    scratch = (Fr*)sb.p;
+  }
+
+  // S[p] = prod_{q>p} N_q ; Tm[p] = prod_{q<p} N_q
+  uint64_t S[3], Tm[3];
+  for (int p = 0; p < R; ++p) {
+    S[p] = 1;
+    Tm[p] = 1;
+    for (int q = p + 1; q < R; ++q) S[p] <<= b[q];
+    for (int q = 0; q < p; ++q) Tm[p] <<= b[q];
+  }
+
+  for (int p = 0; p < R; ++p) {
+    NttPassParams P{};
+    P.log_np = b[p];
+    const uint64_t np = 1ull << b[p];
+    const Fr* src;
+    Fr* dst;
+    if (R == 1) { src = d_a; dst = d_a; }
+    else if (p == 0) { src = d_a; dst = scratch; }
+    else if (p == R - 1) { src = scratch; dst = d_a; }
+    else { src = scratch; dst = scratch; }
+    uint64_t tiles;
+    if (p < R - 1 || R == 1) {
+      // columns: G adjacent low positions share a tile
+      uint64_t G = NTT_TILE_ELEMS / np;
+      if (G > S[p]) G = S[p];
+      P.g = (uint32_t)G;
+      P.in_xs = P.out_xs = S[p];
+      P.in_gs = P.out_gs = 1;
+      P.tiles_lo = S[p] / G;
+      P.in_hi_stride = P.out_hi_stride = np * S[p];
+      P.in_lo_stride = P.out_lo_stride = G;
+      P.load_x_fastest = (G == 1);
+      P.tw_mul = (R == 1) ? 0 : Tm[p];
+      P.tw_h = T->h;
+      tiles = Tm[p] * P.tiles_lo;
+    } else {
+      // last pass: G rows with adjacent k_1; hi = k_1 group, lo = middle digit (R == 3) else 0
+      uint64_t N1 = 1ull << b[0];
+      uint64_t G = NTT_TILE_ELEMS / np;
+      if (G > N1) G = N1;
+      P.g = (uint32_t)G;
+      P.in_xs = 1;
+      P.in_gs = S[0];
+      P.out_xs = n >> b[p];
+      P.out_gs = 1;
+      uint64_t mid = (R == 3) ? (1ull << b[1]) : 1;
+      P.tiles_lo = mid;
+      P.in_hi_stride = G * S[0];
+      P.in_lo_stride = np;      // middle digit k_2 sits at stride S[1] = N_3 = np
+      P.out_hi_stride = G;
+      P.out_lo_stride = N1;     // k_2 * T_2 = k_2 * N_1
+      P.load_x_fastest = 1;
+      P.tw_mul = 0;
+      tiles = (N1 / G) * mid;
+    }
+    uint32_t pitch = np >= 32 ? (uint32_t)np + 1 : (uint32_t)np;
+    size_t lds_bytes = (size_t)P.g * pitch * 32;
+    uint32_t threads = (uint32_t)((P.g * np) / 2);
+    if (threads > NTT_THREADS) threads = NTT_THREADS;
+    if (threads < 64) threads = 64;
+    prof_begin(slot_pass, st);
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, T->B);
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_pass, st);
+  }
+  return 0;
+}
+
+// a[i] *= c * g^i  (g == nullptr: a[i] *= c).  distribute_powers (domain.rs:176-189) and the ifft
+// scaling (domain.rs:163-173) in one elementwise kernel.
+int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st) {
+  const uint64_t n = 1ull << log_n;
+  const Fr* A = nullptr;
+  const Fr* B = nullptr;
+  uint32_t h = 0;
+  if (g != nullptr && log_n > 0) {
+    PowTables* T = nullptr;
+    int rc = build_pow_tables(st, log_n, *g, false, nullptr, 0, &T);
+    if (rc) return rc;
+    A = T->A;
+    B = T->B;
+    h = T->h;
+  }
+  static const int slot_scale = prof_slot("ntt_scale");
+  prof_begin(slot_scale, st);
+  hipLaunchKernelGGL(ntt_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, n, c, A, B, h);
+  ZK_HIP(hipGetLastError());
+  prof_end(slot_scale, st);
+  return 0;
+}
+
+}  // namespace zk
