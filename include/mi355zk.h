@@ -119,6 +119,14 @@ int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_
 int mi355zk_bn254_g1_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[8], const void *d_scalars, size_t n, void *stream);
 int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[16], const void *d_scalars, size_t n, void *stream);
 
+/* ---- host-side group helpers on Jacobian results: acc += other (CurveProjective::add_assign,
+ * ec.rs:360-454) -- how per-GPU partial sums are joined after the all-gather -- and into_affine
+ * (ec.rs:596-629; infinity -> all-zero record). */
+int mi355zk_bn254_g1_add(uint64_t acc_xyz[12], const uint64_t other_xyz[12]);
+int mi355zk_bn254_g2_add(uint64_t acc_xyz[24], const uint64_t other_xyz[24]);
+int mi355zk_bn254_g1_to_affine(uint64_t out_xy[8], const uint64_t xyz[12]);
+int mi355zk_bn254_g2_to_affine(uint64_t out_xy[16], const uint64_t xyz[24]);
+
 /* ---- plain device-memory helpers so that a C / Rust caller needs no HIP bindings of its own */
 int mi355zk_malloc(void **d_ptr, size_t bytes);
 int mi355zk_free(void *d_ptr);

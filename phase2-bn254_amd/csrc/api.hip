@@ -414,6 +414,53 @@ int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affin
   return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
 }
 
+// host-side group helpers (joining per-GPU partial sums, normalising results)
+int mi355zk_bn254_g1_add(uint64_t acc_xyz[12], const uint64_t other_xyz[12]) {
+  if (!acc_xyz || !other_xyz) return ZK_ERR_BAD_ARGS;
+  G1Jacobian a, b;
+  std::memcpy(&a, acc_xyz, sizeof a);
+  std::memcpy(&b, other_xyz, sizeof b);
+  jac_add(a, b);
+  std::memcpy(acc_xyz, &a, sizeof a);
+  return ZK_OK;
+}
+int mi355zk_bn254_g2_add(uint64_t acc_xyz[24], const uint64_t other_xyz[24]) {
+  if (!acc_xyz || !other_xyz) return ZK_ERR_BAD_ARGS;
+  G2Jacobian a, b;
+  std::memcpy(&a, acc_xyz, sizeof a);
+  std::memcpy(&b, other_xyz, sizeof b);
+  jac_add(a, b);
+  std::memcpy(acc_xyz, &a, sizeof a);
+  return ZK_OK;
+}
+// into_affine (ec.rs:596-629); infinity -> all-zero record
+int mi355zk_bn254_g1_to_affine(uint64_t out_xy[8], const uint64_t xyz[12]) {
+  if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;
+  G1Jacobian p;
+  std::memcpy(&p, xyz, sizeof p);
+  G1Affine r{Fq::zero(), Fq::zero()};
+  if (!p.is_zero()) {
+    Fq zi = inv(p.z), zi2 = sqr(zi);
+    r.x = mul(p.x, zi2);
+    r.y = mul(p.y, mul(zi2, zi));
+  }
+  std::memcpy(out_xy, &r, sizeof r);
+  return ZK_OK;
+}
+int mi355zk_bn254_g2_to_affine(uint64_t out_xy[16], const uint64_t xyz[24]) {
+  if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;
+  G2Jacobian p;
+  std::memcpy(&p, xyz, sizeof p);
+  G2Affine r{Fq2::zero(), Fq2::zero()};
+  if (!p.is_zero()) {
+    Fq2 zi = inv(p.z), zi2 = sqr(zi);
+    r.x = mul(p.x, zi2);
+    r.y = mul(p.y, mul(zi2, zi));
+  }
+  std::memcpy(out_xy, &r, sizeof r);
+  return ZK_OK;
+}
+
 int mi355zk_malloc(void** d_ptr, size_t bytes) {
   if (!d_ptr) return ZK_ERR_BAD_ARGS;
   ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));

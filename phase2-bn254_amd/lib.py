@@ -39,6 +39,10 @@ SIGNATURES = {
     "mi355zk_bn254_fr_domain_constants": (_i, [_u32, _vp, _vp, _vp, _vp]),
     "mi355zk_bn254_g1_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_g1_add": (_i, [_vp, _vp]),
+    "mi355zk_bn254_g2_add": (_i, [_vp, _vp]),
+    "mi355zk_bn254_g1_to_affine": (_i, [_vp, _vp]),
+    "mi355zk_bn254_g2_to_affine": (_i, [_vp, _vp]),
     "mi355zk_malloc": (_i, [C.POINTER(_vp), _sz]),
     "mi355zk_free": (_i, [_vp]),
     "mi355zk_memcpy_h2d": (_i, [_vp, _vp, _sz]),

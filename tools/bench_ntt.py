@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Secondary metric: 2^log_n-element Fr NTT (fft / ifft / coset_fft) on one MI355X, data resident in HBM."""
+import argparse, ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import phase2_bn254_amd as zk, inputs
+
+ap = argparse.ArgumentParser(); ap.add_argument("--log-n", type=int, default=20); ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--check", action="store_true")
+a = ap.parse_args()
+L = zk.lib.load(); w = zk.Worker(0)
+n = 1 << a.log_n
+host = inputs.random_fr_mont(n, seed=5)
+d = torch.from_numpy(host.view(np.int64)).cuda()
+res = {}
+for op in ("fft", "ifft", "coset_fft", "icoset_fft"):
+    dom = zk.EvaluationDomain(d.clone(), a.log_n)
+    getattr(dom, op)(w); torch.cuda.synchronize()
+    L.mi355zk_prof_reset(); L.mi355zk_prof_enable(1)
+    t = time.perf_counter()
+    for _ in range(a.iters): getattr(dom, op)(w)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / a.iters
+    L.mi355zk_prof_enable(0)
+    ms, cnt = C.c_double(), C.c_long(); L.mi355zk_prof_get(b"ntt_pass", C.byref(ms), C.byref(cnt))
+    passes = cnt.value / a.iters
+    res[op] = {"ms": round(dt * 1e3, 4), "Melem_per_s": round(n / dt / 1e6, 1), "ntt_pass_ms_avg": round(ms.value / max(cnt.value, 1), 4), "passes": passes,
+               "hbm_GBs_algorithmic": round(64 * n * passes / (ms.value / a.iters * 1e-3) / 1e9, 1) if cnt.value else None}
+if a.check:
+    import oracle_lib as O
+    dom = zk.EvaluationDomain(d.clone(), a.log_n); dom.fft(w)
+    want = O.fr_domain_op(host, a.log_n, "fft").reshape(-1, 4)
+    res["fft_matches_oracle"] = bool(np.array_equal(dom.coeffs.cpu().numpy().view(np.uint64), want))
+print(json.dumps({"log_n": a.log_n, **res}))
