@@ -113,15 +113,7 @@ def main() -> int:
         if world == 1:
             return part
         # the path's one exchange step: all-gather of the 96-byte partials, then local EC adds
-        mine = torch.from_numpy(part.view(np.int64)).to(dev)
-        allp = torch.empty((world, 12), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allp, mine)
-        allp = allp.cpu().numpy().view(np.uint64)
-        acc = allp[0].copy()
-        for r in range(1, world):
-            rc = L.mi355zk_bn254_g1_add(acc.ctypes.data_as(C.c_void_p), np.ascontiguousarray(allp[r]).ctypes.data_as(C.c_void_p))
-            assert rc == 0
-        return acc
+        return zk.shard.allgather_join(part, device=dev)
 
     for _ in range(args.warmup):
         step()
@@ -151,6 +143,17 @@ def main() -> int:
         ms, cnt = C.c_double(), C.c_long()
         L.mi355zk_prof_get(name.encode(), C.byref(ms), C.byref(cnt))
         kern[name] = (ms.value / cnt.value) if cnt.value else None
+
+    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc pass (counters cannot be
+    # read from inside this process); the committed figure is reported when it was taken on this workload.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload_log_n") == log_n and pmc.get("n_gpus") == world:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     out = None
     if rank == 0:
@@ -182,7 +185,7 @@ def main() -> int:
                        "parallelism": "point-range shards x%d, all-gather of 96-B partials" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6) if achieved else None,
-                         "traffic": None,
+                         "traffic": traffic,
                          "kernel_ms": {k: (round(v, 4) if v is not None else None) for k, v in kern.items()},
                          "alu_model": {"fq_mul_per_s": fq_mul_per_s, "note": "W*10 Fq mul per scalar-mul in msm_accumulate; MSM is integer-ALU bound (SURVEY 8d)"}},
             "result_affine_x_limb0": hex(int(aff[0])),

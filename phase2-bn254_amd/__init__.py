@@ -3,13 +3,14 @@
 Layout:
   csrc/           hand-written HIP kernels + the C ABI (include/mi355zk.h) -> libmi355zk.so
   lib.py          ctypes loader (fails loudly when the library is missing)
+  shard.py        multi-GPU point-range sharding + the all-gather/join exchange step
   bellman.py      host-side mirror of the reference's interface for this path:
                   multiexp(), FullDensity, DensityTracker, EvaluationDomain, SynthesisError
 
 The directory name carries a hyphen (it is the reference's name); import it through the
 repo-root shim module `phase2_bn254_amd`.
 """
-from . import lib  # noqa: F401
+from . import lib, shard  # noqa: F401
 from .bellman import (  # noqa: F401
     DensityTracker,
     EvaluationDomain,

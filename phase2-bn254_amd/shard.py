@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of the multiexp: one process per GPU, contiguous point ranges,
+ONE exchange step -- an all-gather of the Jacobian partial sums (96 B for G1, 192 B for G2) over
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) followed
+by world-1 group additions on every rank.
+
+A literal all-reduce(SUM) of limbs is not the group law, so the north-star's "all-reduce of partial
+bucket sums" is realised as all-gather + local EC adds.  The reference has no counterpart (it is a
+single process): the join is the same `add_assign` that joins windows in multiexp.rs:146-154.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
+    """[start, end) of rank's contiguous slice of n points; remainders go to the first ranks."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def density_base_offsets(density_bits, world: int) -> list[int]:
+    """For a density map, the index of the first base each rank's slice consumes (prefix popcount):
+    bases are compacted, so slice d starts at the number of set bits before its first exponent."""
+    bits = np.asarray(density_bits, dtype=np.uint8)
+    csum = np.concatenate([[0], np.cumsum(bits)])
+    return [int(csum[shard_range(len(bits), world, r)[0]]) for r in range(world)]
+
+
+def join_partials(partials: np.ndarray) -> np.ndarray:
+    """sum of (world, 12|24) u64 Jacobian points with the library's host-side add_assign."""
+    partials = np.ascontiguousarray(partials, dtype=np.uint64)
+    group = {12: 1, 24: 2}[partials.shape[1]]
+    add = _lib.load().mi355zk_bn254_g1_add if group == 1 else _lib.load().mi355zk_bn254_g2_add
+    acc = partials[0].copy()
+    for r in range(1, partials.shape[0]):
+        rc = add(acc.ctypes.data_as(C.c_void_p), np.ascontiguousarray(partials[r]).ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"mi355zk add failed rc={rc}")
+    return acc
+
+
+def allgather_join(partial: np.ndarray, device=None, group=None) -> np.ndarray:
+    """The exchange step: every rank contributes its Jacobian partial, every rank gets the total."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return np.ascontiguousarray(partial, dtype=np.uint64)
+    mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64))
+    if device is not None:
+        mine = mine.to(device)
+    allp = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(allp, mine, group=group)
+    return join_partials(allp.cpu().numpy().view(np.uint64).reshape(world, -1))

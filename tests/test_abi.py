@@ -1,0 +1,85 @@
+"""The C-ABI library loads and exports every symbol include/mi355zk.h declares (no GPU needed), and the
+pure-host entry points work without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import bn254_model as M
+import inputs
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mi355zk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355zk_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in zk.lib.SIGNATURES, f"{n} declared in the header but not bound in lib.py"
+    assert sorted(zk.lib.SIGNATURES) == names
+    assert lib.mi355zk_version().startswith(b"mi355zk")
+
+
+def test_bad_arguments_are_rejected_without_a_device():
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    out = np.zeros(12, np.uint64)
+    assert lib.mi355zk_bn254_g1_msm(None, 4, 0, None, 4, None, 0, out.ctypes.data_as(C.c_void_p)) == zk.lib.ERR_BAD_ARGS
+    assert lib.mi355zk_bn254_fr_fft(None, 4) == zk.lib.ERR_BAD_ARGS
+    a = np.zeros((2, 4), np.uint64)
+    assert lib.mi355zk_bn254_fr_fft(a.ctypes.data_as(C.c_void_p), 29) == zk.lib.ERR_BAD_ARGS  # > Fr::S (domain.rs:75-77)
+    assert lib.mi355zk_bn254_fr_domain_op(a.ctypes.data_as(C.c_void_p), 1, 7) == zk.lib.ERR_BAD_ARGS
+
+
+def test_domain_constants_host_arithmetic_matches_oracle():
+    """mi355zk_bn254_fr_domain_constants runs the library's own host-side Fr code (the same source as the
+    kernels, compiled for the host): omega / omegainv / geninv / minv of from_coeffs (domain.rs:84-98)."""
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    for log_n in (0, 1, 10, 20, 28):
+        outs = [np.zeros(4, np.uint64) for _ in range(4)]
+        assert lib.mi355zk_bn254_fr_domain_constants(log_n, *[o.ctypes.data_as(C.c_void_p) for o in outs]) == 0
+        for got, want in zip(outs, O.fr_domain(log_n)):
+            assert np.array_equal(got, want)
+    assert lib.mi355zk_bn254_fr_domain_constants(29, None, None, None, None) == zk.lib.ERR_BAD_ARGS
+
+
+def test_host_group_helpers_match_oracle():
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    for G, add, to_aff, gen in ((O.G1, lib.mi355zk_bn254_g1_add, lib.mi355zk_bn254_g1_to_affine, inputs.G1_GEN_RAW),
+                                (O.G2, lib.mi355zk_bn254_g2_add, lib.mi355zk_bn254_g2_to_affine, inputs.G2_GEN_RAW)):
+        a = G.mul(G.from_affine(gen), M.to_limbs(12345))
+        b = G.mul(G.from_affine(gen), M.to_limbs(M.R_ORDER - 7))
+        zero = G.from_affine(np.zeros(G.aff, np.uint64))
+        for x, y in ((a, b), (a, a), (a, zero), (zero, b), (a, G.mul(G.from_affine(gen), M.to_limbs(M.R_ORDER - 12345)))):
+            acc = x.copy()
+            assert add(acc.ctypes.data_as(C.c_void_p), np.ascontiguousarray(y).ctypes.data_as(C.c_void_p)) == 0
+            aff = np.zeros(G.aff, np.uint64)
+            assert to_aff(aff.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(aff, G.to_affine(G.add(x, y)))
+
+
+def test_window_geometry_is_sane():
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    for n in (1, 100, 1 << 16, 1 << 20, 1 << 26):
+        nw = C.c_int()
+        c = lib.mi355zk_msm_window_bits(n, C.byref(nw))
+        assert 2 <= c <= 24 and nw.value * c >= 254 and (nw.value - 1) * c < 254 + c

@@ -1,0 +1,159 @@
+"""GPU parity tests for the multiexp path, all through the C ABI (libmi355zk.so):
+bit-exact (after affine normalisation, which is how the reference defines equality of projective
+points: ec.rs:45-85, 596-629) against the committed golden vectors and the CPU oracle, the Source /
+density error contract, and size-independent properties at BASELINE.json's full sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as GU
+import inputs
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _density(zk, c):
+    return zk.DensityTracker.from_bools(c["density"]) if c["density"] is not None else zk.FullDensity()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_golden_vectors(zk, worker, group):
+    G = O.G1 if group == 1 else O.G2
+    for c in GU.msm_cases(group):
+        fut = zk.multiexp(worker, (c["bases"], c["base_offset"]), _density(zk, c), c["scalars"])
+        if c["rc"] == 0:
+            assert np.array_equal(G.to_affine(fut.wait()), c["expected"]), c["name"]
+        else:
+            with pytest.raises(zk.SynthesisError) as e:
+                fut.wait()
+            want = zk.SynthesisError.UNEXPECTED_IDENTITY if c["rc"] == 1 else zk.SynthesisError.IO_UNEXPECTED_EOF
+            assert e.value.kind == want, c["name"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 100, 1000, 5000, 1 << 14])
+def test_g1_matches_oracle(zk, worker, n):
+    bases = inputs.bases_progression_cpu(1, n, seed=n)
+    scalars = inputs.random_scalars(n, seed=7 * n + 1)
+    rc, want = O.G1.multiexp(bases, scalars, threads=8)
+    assert rc == 0
+    got = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+
+
+@pytest.mark.parametrize("n", [1, 33, 500, 4096])
+def test_g2_matches_oracle(zk, worker, n):
+    bases = inputs.bases_progression_cpu(2, n, seed=n)
+    scalars = inputs.random_scalars(n, seed=11 * n + 1)
+    rc, want = O.G2.multiexp(bases, scalars, threads=8)
+    assert rc == 0
+    got = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert np.array_equal(O.G2.to_affine(got), O.G2.to_affine(want))
+
+
+def test_density_half_and_offset_matches_oracle(zk, worker):
+    """BASELINE config 2's DensityTracker variant (~50 % density) with a non-zero source offset."""
+    n = 3000
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, size=n).astype(bool)
+    used = int(bits.sum())
+    bases = inputs.bases_progression_cpu(1, used + 5, seed=31)
+    scalars = inputs.random_scalars(n, seed=32)
+    scalars[::17] = 0
+    scalars[5::23] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    rc, want = O.G1.multiexp(bases, scalars, density=GU.density_words(bits), density_bits=n, base_offset=5)
+    assert rc == 0
+    got = zk.multiexp(worker, (bases, 5), zk.DensityTracker.from_bools(bits), scalars).wait()
+    assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+
+
+def test_error_index_and_order(zk, worker):
+    bases = inputs.bases_cpu(1, 6, seed=5)
+    scalars = inputs.random_scalars(8, seed=6)
+    bases[2] = 0
+    with pytest.raises(zk.SynthesisError) as e:  # identity at 2 beats Eof at 6
+        zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == 2
+    scalars[2] = 0  # zero exponent: the identity base is skipped without being looked at (multiexp.rs:95-96)
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == 6
+    rc, _ = O.G1.multiexp(bases, scalars)
+    assert rc == 2
+
+
+def test_empty_input_is_identity(zk, worker):
+    got = zk.multiexp(worker, (np.zeros((0, 8), np.uint64), 0), zk.FullDensity(), np.zeros((0, 4), np.uint64)).wait()
+    assert not got[8:12].any()  # Z == 0
+
+
+def test_skewed_scalars_one_heavy_bucket(zk, worker):
+    """All scalars equal: every point of a window lands in ONE bucket (worst-case load imbalance)."""
+    n = 20000
+    bases = inputs.bases_progression_cpu(1, n, seed=41)
+    scalars = np.tile(inputs.random_scalars(1, seed=42), (n, 1))
+    rc, want = O.G1.multiexp(bases, scalars, threads=8)
+    got = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert rc == 0 and np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+
+
+def test_deterministic_run_twice(zk, worker):
+    n = 50000
+    bases = inputs.bases_progression_cpu(1, n, seed=51)
+    scalars = inputs.random_scalars(n, seed=52)
+    a = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    b = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert np.array_equal(a, b)
+
+
+def _dev_inputs(zk, log_n, seed):
+    """2^log_n bases k_i*G and scalars generated on the device (as bench.py does)."""
+    import torch
+
+    import bench
+
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    scalars = bench.gen_scalars(n, seed, dev)
+    k = bench.gen_scalars(n, seed + 1, dev)
+    bases = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    rc = zk.lib.load().mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n,
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    return bases, scalars, k
+
+
+def test_batch_mul_matches_oracle(zk, worker):
+    bases, _, k = _dev_inputs(zk, 9, seed=61)
+    want = O.G1.mul_many_affine(inputs.G1_GEN_RAW, k.cpu().numpy().view(np.uint64))
+    assert np.array_equal(bases.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_full_size_device_resident_properties(zk, worker, log_n):
+    """BASELINE config 2 (2^20) and beyond, inputs resident in HBM.  Size-independent checks:
+      - bases are k_i*G, so MSM(s, k*G) == (sum s_i*k_i mod r) * G        (closed form, via the oracle's mul)
+      - additivity over point ranges: MSM(all) == MSM(first half) + MSM(second half)
+      - the 2^14 prefix equals the CPU oracle's multiexp bit for bit."""
+    import bn254_model as M
+
+    bases, scalars, k = _dev_inputs(zk, log_n, seed=71 + log_n)
+    n = 1 << log_n
+    total = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    hs = scalars.cpu().numpy().view(np.uint64)
+    hk = k.cpu().numpy().view(np.uint64)
+    to_int = lambda a: sum(a[:, i].astype(object) << (64 * i) for i in range(4))  # noqa: E731
+    dot = int(sum(s * kk for s, kk in zip(to_int(hs), to_int(hk))) % M.R_ORDER)
+    want = O.G1.mul(O.G1.from_affine(inputs.G1_GEN_RAW), M.to_limbs(dot))
+    assert np.array_equal(O.G1.to_affine(total), O.G1.to_affine(want))
+    h = n // 2
+    a = zk.multiexp(worker, (bases[:h], 0), zk.FullDensity(), scalars[:h]).wait()
+    b = zk.multiexp(worker, (bases, h), zk.FullDensity(), scalars[h:]).wait()  # second half through the source offset
+    assert np.array_equal(O.G1.to_affine(zk.shard.join_partials(np.stack([a, b]))), O.G1.to_affine(total))
+    m = 1 << 14
+    rc, ref = O.G1.multiexp(bases[:m].cpu().numpy().view(np.uint64), hs[:m], threads=8)
+    got = zk.multiexp(worker, (bases[:m], 0), zk.FullDensity(), scalars[:m]).wait()
+    assert rc == 0 and np.array_equal(O.G1.to_affine(got), O.G1.to_affine(ref))
