@@ -113,6 +113,15 @@ int mi355zk_bn254_fr_domain_op_dev(void *d_a, uint32_t log_n, int op, void *stre
 /* the domain constants themselves (Montgomery form), for callers that keep their own EvaluationDomain */
 int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_t omegainv[4], uint64_t geninv[4], uint64_t minv[4]);
 
+/* ---- elementwise Fr operations of EvaluationDomain on device-resident data (asynchronous on `stream`):
+ * a[i] *= b[i] (mul_assign, domain.rs:236-249) and a[i] -= b[i] (sub_assign, domain.rs:251-260). */
+int mi355zk_bn254_fr_mul_assign_dev(void *d_a, const void *d_b, size_t n, void *stream);
+int mi355zk_bn254_fr_sub_assign_dev(void *d_a, const void *d_b, size_t n, void *stream);
+/* Measured Montgomery-product rate of this library (the integer-ALU roofline the kernels are priced
+ * against): `blocks` x 256 lanes each run 4 independent chains of `iters` products.  which: 0 Fq, 1 Fr.
+ * out[0..3] = a*b^iters (Montgomery arithmetic, lane 0, chain 0) for a parity check; *ms = kernel time. */
+int mi355zk_ubench_fp_mul(int which, uint32_t blocks, uint32_t iters, const uint64_t a[4], const uint64_t b[4], uint64_t out[16], float *ms);
+
 /* ---- batch fixed-base scalar multiplication out[i] = k[i] * P, affine (all-zero = infinity).
  * Building block of the per-point `batch_exp` path (powersoftau/src/batched_accumulator.rs:1130-1181,
  * SURVEY 8f row 1); used here to synthesise tau-table-like bases on the device. */

@@ -148,10 +148,17 @@ ZK_HD Fp<PR> neg(const Fp<PR>& a) {
   return r;
 }
 
-// Montgomery product a*b*2^-256 mod p, fully reduced.  CIOS over 32-bit limbs; the (carry + t[j])
-// sums stay below 2^64 so every step is one v_mad_u64_u32 plus one 64-bit add, no carry flags.
+// Montgomery product a*b*2^-256 mod p, fully reduced.
+//   device (gfx950): finely-integrated product scanning in inline asm (mont_mul_gfx950.inc, generated by
+//     tools/gen_mont_mul.py): per 32x32 partial product one v_mad_u64_u32 (64-bit accumulate) + one
+//     v_addc_co_u32 into the third accumulator word, no moves: 136 mad + 136 addc + 8 v_mul_lo_u32.
+//   host: portable CIOS (the (carry + t[j]) sums stay below 2^64, so no carry flags are needed).
 template <class PR>
 ZK_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_PORTABLE_MUL)
+#include "mont_mul_gfx950.inc"
+  return reduce_once(r);
+#else
   uint32_t t[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) t[i] = 0;
@@ -185,6 +192,7 @@ ZK_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.l[i] = t[i];
   return reduce_once(r);
+#endif
 }
 
 template <class PR>

@@ -1,0 +1,107 @@
+// Elementwise Fr kernels of the path's callers and the field-multiplier microbenchmark.
+//   EvaluationDomain::mul_assign  bellman/src/domain.rs:236-249  (pointwise product, prover.rs:221-236)
+//   EvaluationDomain::sub_assign  bellman/src/domain.rs:251-260
+// plus mi355zk_ubench_fp_mul: the measured Montgomery-product rate of this library on the device -- the
+// integer-ALU roofline the MSM / NTT kernels are priced against.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/mi355zk.h"
+#include "curve.hpp"
+#include "device_util.hpp"
+
+namespace zk {
+namespace {
+
+__device__ __forceinline__ Fr ld(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st(Fr* p, const Fr& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// op 0: a *= b   op 1: a -= b
+__global__ void __launch_bounds__(256) fr_pointwise_kernel(Fr* __restrict__ a, const Fr* __restrict__ b, uint64_t n, int op) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    Fr x = ld(a + i), y = ld(b + i);
+    st(a + i, op == 0 ? mul(x, y) : sub(x, y));
+  }
+}
+
+// every lane runs `iters` dependent products x <- x * y on 4 independent chains (ILP like the group law)
+template <class PR>
+__global__ void __launch_bounds__(256) fp_mul_ubench_kernel(Fp<PR> a, Fp<PR> b, uint32_t iters, Fp<PR>* out) {
+  Fp<PR> x0 = a, x1 = b, x2 = add(a, b), x3 = sub(a, b);
+  x0.l[0] ^= 0;  // keep lanes identical: the result of chain 0 is checked against the oracle
+  for (uint32_t i = 0; i < iters; ++i) {
+    x0 = mul(x0, b);
+    x1 = mul(x1, a);
+    x2 = mul(x2, b);
+    x3 = mul(x3, a);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = x0;
+    out[1] = x1;
+    out[2] = x2;
+    out[3] = x3;
+  }
+  // defeat dead-code elimination for the other lanes without memory traffic
+  if ((x1.l[0] ^ x2.l[1] ^ x3.l[2]) == 0x9e3779b9u && x0.l[7] == 0xffffffffu) out[4 + (blockIdx.x & 3)] = x1;
+}
+
+template <class PR>
+int ubench(uint32_t blocks, uint32_t iters, const uint64_t* a_raw, const uint64_t* b_raw, uint64_t* out_raw, float* ms) {
+  Fp<PR> a, b;
+  std::memcpy(&a, a_raw, 32);
+  std::memcpy(&b, b_raw, 32);
+  Fp<PR>* d_out = nullptr;
+  ZK_HIP(hipMalloc(&d_out, 8 * sizeof(Fp<PR>)));
+  hipEvent_t e0, e1;
+  ZK_HIP(hipEventCreate(&e0));
+  ZK_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(fp_mul_ubench_kernel<PR>, dim3(blocks), dim3(256), 0, 0, a, b, iters, d_out);  // warm-up
+  ZK_HIP(hipDeviceSynchronize());
+  ZK_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(fp_mul_ubench_kernel<PR>, dim3(blocks), dim3(256), 0, 0, a, b, iters, d_out);
+  ZK_HIP(hipEventRecord(e1, 0));
+  ZK_HIP(hipEventSynchronize(e1));
+  ZK_HIP(hipEventElapsedTime(ms, e0, e1));
+  ZK_HIP(hipMemcpy(out_raw, d_out, 4 * sizeof(Fp<PR>), hipMemcpyDeviceToHost));
+  ZK_HIP(hipFree(d_out));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ZK_OK;
+}
+
+int pointwise(void* d_a, const void* d_b, size_t n, void* stream, int op) {
+  if ((!d_a || !d_b) && n) return ZK_ERR_BAD_ARGS;
+  if (n == 0) return ZK_OK;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(fr_pointwise_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (Fr*)d_a, (const Fr*)d_b, (uint64_t)n, op);
+  ZK_HIP(hipGetLastError());
+  return ZK_OK;
+}
+
+}  // namespace
+}  // namespace zk
+
+extern "C" {
+
+int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 0); }
+int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 1); }
+
+int mi355zk_ubench_fp_mul(int which, uint32_t blocks, uint32_t iters, const uint64_t a[4], const uint64_t b[4], uint64_t out[16], float* ms) {
+  if (!a || !b || !out || !ms) return ZK_ERR_BAD_ARGS;
+  return which == 0 ? zk::ubench<zk::FqParams>(blocks, iters, a, b, out, ms) : zk::ubench<zk::FrParams>(blocks, iters, a, b, out, ms);
+}
+
+}  // extern "C"
