@@ -122,6 +122,13 @@ int mi355zk_bn254_fr_sub_assign_dev(void *d_a, const void *d_b, size_t n, void *
  * out[0..3] = a*b^iters (Montgomery arithmetic, lane 0, chain 0) for a parity check; *ms = kernel time. */
 int mi355zk_ubench_fp_mul(int which, uint32_t blocks, uint32_t iters, const uint64_t a[4], const uint64_t b[4], uint64_t out[16], float *ms);
 
+/* ---- self-test hooks: the kernels' "U-form" arithmetic (29-bit lazy limbs, csrc/fieldu.hpp, curveu.hpp)
+ * compiled for the HOST, so that it can be checked against the oracle / big-int model without a GPU. */
+int mi355zk_selftest_u_mul(int which, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]);
+int mi355zk_selftest_u_sub(int which, int k, int s, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]);
+int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9], const uint32_t in_u[9], uint64_t out_std[4]);
+int mi355zk_selftest_g1_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[16]);
+
 /* ---- batch fixed-base scalar multiplication out[i] = k[i] * P, affine (all-zero = infinity).
  * Building block of the per-point `batch_exp` path (powersoftau/src/batched_accumulator.rs:1130-1181,
  * SURVEY 8f row 1); used here to synthesise tau-table-like bases on the device. */

@@ -8,7 +8,7 @@
 #include <cstring>
 
 #include "../../include/mi355zk.h"
-#include "curve.hpp"
+#include "curveu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -94,7 +94,82 @@ int pointwise(void* d_a, const void* d_b, size_t n, void* stream, int op) {
 }  // namespace
 }  // namespace zk
 
+// ---- host-side self-test hooks for the U-form arithmetic (same source as the kernels, compiled for the host)
+template <class PR>
+static void selftest_u_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  zk::FpU<PR> x, y;
+  std::memcpy(&x, a, 36);
+  std::memcpy(&y, b, 36);
+  zk::FpU<PR> r = zk::u_mul(x, y);
+  std::memcpy(out, &r, 36);
+}
+template <class PR>
+static int selftest_u_sub(int k, int s, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  zk::FpU<PR> x, y, r;
+  std::memcpy(&x, a, 36);
+  std::memcpy(&y, b, 36);
+  if (k == 1 && s == 1) r = zk::u_sub<1, 1>(x, y);
+  else if (k == 2 && s == 1) r = zk::u_sub<2, 1>(x, y);
+  else if (k == 4 && s == 1) r = zk::u_sub<4, 1>(x, y);
+  else if (k == 4 && s == 2) r = zk::u_sub<4, 2>(x, y);
+  else if (k == 4 && s == 3) r = zk::u_sub<4, 3>(x, y);
+  else if (k == 8 && s == 1) r = zk::u_sub<8, 1>(x, y);
+  else return ZK_ERR_BAD_ARGS;
+  std::memcpy(out, &r, 36);
+  return ZK_OK;
+}
+
 extern "C" {
+
+// a, b, out: 9 u32 limbs (radix 2^29).  which: 0 Fq, 1 Fr.  out = a*b*2^-261 mod p (N-form, lazily reduced)
+int mi355zk_selftest_u_mul(int which, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
+  if (!a || !b || !out) return ZK_ERR_BAD_ARGS;
+  if (which == 0) selftest_u_mul<zk::FqParams>(a, b, out);
+  else selftest_u_mul<zk::FrParams>(a, b, out);
+  return ZK_OK;
+}
+// out = carry(a + k*p - b) for the (k, s) pairs the kernels use
+int mi355zk_selftest_u_sub(int which, int k, int s, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
+  if (!a || !b || !out) return ZK_ERR_BAD_ARGS;
+  return which == 0 ? selftest_u_sub<zk::FqParams>(k, s, a, b, out) : selftest_u_sub<zk::FrParams>(k, s, a, b, out);
+}
+// memory format <-> U limbs round trip pieces: out_u = u_from_std(a);  out_std = u_to_std_lt2p(in_u) (needs in_u < 2p, N-form)
+int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9], const uint32_t in_u[9], uint64_t out_std[4]) {
+  if (which == 0) {
+    if (a_std && out_u) { zk::Fq x; std::memcpy(&x, a_std, 32); zk::FqU u = zk::u_from_std(x); std::memcpy(out_u, &u, 36); }
+    if (in_u && out_std) { zk::FqU u; std::memcpy(&u, in_u, 36); zk::Fq x = zk::u_to_std_lt2p(u); std::memcpy(out_std, &x, 32); }
+  } else {
+    if (a_std && out_u) { zk::Fr x; std::memcpy(&x, a_std, 32); zk::FrU u = zk::u_from_std(x); std::memcpy(out_u, &u, 36); }
+    if (in_u && out_std) { zk::FrU u; std::memcpy(&u, in_u, 36); zk::Fr x = zk::u_to_std_lt2p(u); std::memcpy(out_std, &x, 32); }
+  }
+  return ZK_OK;
+}
+// bucket accumulation of n signed affine G1 points on the HOST: mode 0 = saturated-limb XYZZ (curve.hpp),
+// mode 1 = U-form XYZZ (curveu.hpp).  out = memory-format XYZZ (X, Y, ZZ, ZZZ; 16 u64).
+int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const uint8_t* negate, size_t n, uint64_t out_xyzz[16]) {
+  if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
+  if (!out_xyzz) return ZK_ERR_BAD_ARGS;
+  zk::G1XYZZ r;
+  if (mode == 0) {
+    zk::G1XYZZ acc = zk::G1XYZZ::zero();
+    for (size_t i = 0; i < n; ++i) {
+      zk::G1Affine p;
+      std::memcpy(&p, affine_pts + 8 * i, 64);
+      zk::xyzz_add_mixed(acc, p.x, p.y, negate[i] != 0);
+    }
+    r = acc;
+  } else {
+    zk::XYZZU<zk::FqParams> acc = zk::XYZZU<zk::FqParams>::zero();
+    for (size_t i = 0; i < n; ++i) {
+      zk::G1Affine p;
+      std::memcpy(&p, affine_pts + 8 * i, 64);
+      zk::xyzzu_add_mixed(acc, p.x, p.y, negate[i] != 0);
+    }
+    r = zk::xyzzu_to_std(acc);
+  }
+  std::memcpy(out_xyzz, &r, sizeof r);
+  return ZK_OK;
+}
 
 int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 0); }
 int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 1); }

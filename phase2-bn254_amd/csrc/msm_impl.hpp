@@ -32,7 +32,9 @@
 #include <mutex>
 #include <vector>
 
-#include "curve.hpp"
+#include <type_traits>
+
+#include "curveu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -136,21 +138,32 @@ __global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restr
   if (j + 1 == m || keys[j + 1] != k) last[k] = (uint32_t)j + 1;
 }
 
-// 4. one lane per bucket
+// 4. one lane per bucket.  G1 runs on U-form arithmetic (curveu.hpp: 29-bit lazy limbs, one v_mad_u64_u32
+//    per partial product, no carry flags); G2 still uses the saturated-limb XYZZ of curve.hpp.
 template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                             uint32_t n_buckets, XYZZ<F>* __restrict__ buckets) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_buckets) return;
-  XYZZ<F> acc = XYZZ<F>::zero();
   uint32_t j = first[b], e = last[b];
-  for (; j < e; ++j) {
-    uint32_t v = vals[j];
-    Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
-    xyzz_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+  if constexpr (std::is_same<F, Fq>::value) {
+    XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
+    for (; j < e; ++j) {
+      uint32_t v = vals[j];
+      Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
+      xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+    }
+    store_vec(buckets + b, xyzzu_to_std(acc));
+  } else {
+    XYZZ<F> acc = XYZZ<F>::zero();
+    for (; j < e; ++j) {
+      uint32_t v = vals[j];
+      Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
+      xyzz_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+    }
+    store_vec(buckets + b, acc);
   }
-  store_vec(buckets + b, acc);
 }
 
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:

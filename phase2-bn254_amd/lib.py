@@ -40,6 +40,10 @@ SIGNATURES = {
     "mi355zk_bn254_fr_mul_assign_dev": (_i, [_vp, _vp, _sz, _vp]),
     "mi355zk_bn254_fr_sub_assign_dev": (_i, [_vp, _vp, _sz, _vp]),
     "mi355zk_ubench_fp_mul": (_i, [_i, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_float)]),
+    "mi355zk_selftest_u_mul": (_i, [_i, _vp, _vp, _vp]),
+    "mi355zk_selftest_u_sub": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "mi355zk_selftest_u_pack": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "mi355zk_selftest_g1_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_add": (_i, [_vp, _vp]),

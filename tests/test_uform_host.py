@@ -1,0 +1,156 @@
+"""The kernels' U-form arithmetic (29-bit lazy limbs: csrc/fieldu.hpp, curveu.hpp) compiled for the HOST
+and checked against Python big ints / the oracle, including the stated limb and value bounds."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import bn254_model as M
+import inputs
+import oracle_lib as O
+
+MASK = (1 << 29) - 1
+rnd = random.Random(29)
+MODS = [(0, M.Q), (1, M.R_ORDER)]
+
+
+def limbs29(v, n=9):
+    return [(v >> (29 * i)) & MASK for i in range(n - 1)] + [v >> (29 * (n - 1))]
+
+
+def val(l):
+    return sum(int(x) << (29 * i) for i, x in enumerate(l))
+
+
+def redundant(v, extra_bits):
+    """a non-normalised limb vector with the same value: limbs up to 2^(29+extra_bits)"""
+    l = limbs29(v)
+    for i in range(8):
+        if l[i + 1] > 0:
+            take = rnd.randrange(0, min(l[i + 1], (1 << extra_bits) - 1) + 1)
+            l[i + 1] -= take
+            l[i] += take << 29
+    assert val(l) == v
+    return l
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import phase2_bn254_amd as zk
+
+    return zk.lib.load()
+
+
+def _u32(l):
+    return np.array(l, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("which,p", MODS)
+def test_u_mul(lib, which, p):
+    rinv = pow(1 << 261, -1, p)
+    for trial in range(400):
+        # values up to 10p, limbs up to 2^30 (the loosest operands the kernels feed u_mul)
+        va, vb = rnd.randrange(10 * p), rnd.randrange(10 * p)
+        a = _u32(redundant(va, 1) if trial % 2 else limbs29(va))
+        b = _u32(redundant(vb, 1) if trial % 3 == 0 else limbs29(vb))
+        out = np.zeros(9, np.uint32)
+        assert lib.mi355zk_selftest_u_mul(which, a.ctypes.data, b.ctypes.data, out.ctypes.data) == 0
+        r = val(out)
+        assert r % p == va * vb * rinv % p
+        assert r < va * vb // (1 << 261) + p + 1 and r < 2 * p   # the bound the callers rely on
+        assert all(int(x) <= MASK for x in out[:8])                # N-form
+    # extreme limbs: one operand N-form with all limbs 2^29-1 (value ~2^261 is out of range for the value bound but not for the accumulator)
+    a = _u32([MASK] * 8 + [(10 * p) >> 232])
+    b = _u32([(1 << 30) - 1] * 8 + [0])
+    out = np.zeros(9, np.uint32)
+    lib.mi355zk_selftest_u_mul(which, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    assert val(out) % p == val(a) * val(b) * rinv % p
+
+
+@pytest.mark.parametrize("which,p", MODS)
+@pytest.mark.parametrize("k,s", [(1, 1), (2, 1), (4, 1), (4, 2), (4, 3), (8, 1)])
+def test_u_sub(lib, which, p, k, s):
+    for _ in range(200):
+        va = rnd.randrange(2 * p)
+        vb = rnd.randrange(k * p + 1)
+        a = _u32(limbs29(va))
+        bl = limbs29(vb)
+        if s > 1:  # b with limbs up to s * 2^29
+            bl = redundant(vb, 1) if s == 2 else [x for x in redundant(vb, 1)]
+        b = _u32(bl)
+        assert all(x < s * (1 << 29) for x in bl[:8])
+        out = np.zeros(9, np.uint32)
+        assert lib.mi355zk_selftest_u_sub(which, k, s, a.ctypes.data, b.ctypes.data, out.ctypes.data) == 0
+        assert val(out) == va + k * p - vb
+        assert all(int(x) <= MASK for x in out[:8])
+    # boundary: b == k*p exactly and a == 0
+    a, b, out = _u32([0] * 9), _u32(limbs29(k * p)), np.zeros(9, np.uint32)
+    lib.mi355zk_selftest_u_sub(which, k, s, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    assert val(out) == 0
+
+
+@pytest.mark.parametrize("which,p", MODS)
+def test_u_pack_roundtrip_and_canonical_reduce(lib, which, p):
+    for v in [0, 1, p - 1, rnd.randrange(p), rnd.randrange(p)]:
+        a = np.array(M.to_limbs(v), dtype=np.uint64)
+        u = np.zeros(9, np.uint32)
+        lib.mi355zk_selftest_u_pack(which, a.ctypes.data, u.ctypes.data, None, None)
+        assert val(u) == v
+    for v in [0, 1, p - 1, p, p + 1, 2 * p - 1, rnd.randrange(2 * p)]:
+        u = _u32(limbs29(v))
+        out = np.zeros(4, np.uint64)
+        lib.mi355zk_selftest_u_pack(which, None, None, u.ctypes.data, out.ctypes.data)
+        assert M.from_limbs(out) == v % p
+
+
+def _xyzz_to_affine(x):
+    X, Y, ZZ, ZZZ = (M.from_mont(M.from_limbs(x[4 * i:4 * i + 4]), M.Q) for i in range(4))
+    if ZZ == 0:
+        return None
+    return (X * pow(ZZ, -1, M.Q) % M.Q, Y * pow(ZZ, -1 if False else -1, M.Q) * 0 + Y * pow(ZZZ, -1, M.Q) % M.Q)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_g1_bucket_accumulation_on_host(lib, mode):
+    """sum of signed points, incl. the same point twice in a row (doubling branch), P then -P (infinity) and
+    restarting from infinity: saturated XYZZ (mode 0) and U-form XYZZ (mode 1) against the big-int model."""
+    n = 40
+    raw = inputs.bases_cpu(1, n, seed=123)
+    pts = [M.g1_affine_from_raw(r) for r in raw]
+    seq = [(0, 0), (0, 0), (1, 0), (1, 1), (2, 1), (2, 0), (3, 0)]           # dbl; add; cancel ...
+    seq += [(i, rnd.randrange(2)) for i in range(4, n)]
+    seq += [(5, 0), (5, 0), (5, 1), (5, 1)]
+    for prefix in (1, 2, 4, 6, 7, len(seq)):
+        sub = seq[:prefix]
+        arr = np.ascontiguousarray(np.stack([raw[i] for i, _ in sub]))
+        neg = np.array([s for _, s in sub], dtype=np.uint8)
+        out = np.zeros(16, np.uint64)
+        assert lib.mi355zk_selftest_g1_accumulate(mode, arr.ctypes.data, neg.ctypes.data, len(sub), out.ctypes.data) == 0
+        want = None
+        for i, s in sub:
+            want = M.ec_add(M.FQ_OPS, want, M.ec_neg(M.FQ_OPS, pts[i]) if s else pts[i])
+        assert _xyzz_to_affine(out) == want, (mode, prefix)
+        # coordinates are canonical (< q) in the memory format
+        assert all(M.from_limbs(out[4 * i:4 * i + 4]) < M.Q for i in range(4))
+
+
+def test_u_accumulation_long_chain_keeps_invariants(lib):
+    """2000 random signed additions through the U-form accumulator == the saturated accumulator == model."""
+    n = 2000
+    raw = inputs.bases_progression_cpu(1, n, seed=321)
+    neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
+    outs = []
+    for mode in (0, 1):
+        out = np.zeros(16, np.uint64)
+        assert lib.mi355zk_selftest_g1_accumulate(mode, raw.ctypes.data, neg.ctypes.data, n, out.ctypes.data) == 0
+        outs.append(_xyzz_to_affine(out))
+    assert outs[0] == outs[1] and outs[0] is not None
+    acc = O.G1.from_affine(np.zeros(8, np.uint64))
+    for i in range(n):
+        pt = raw[i].copy()
+        if neg[i]:
+            y = M.from_limbs(pt[4:])
+            pt[4:] = M.to_limbs((M.Q - y) % M.Q)
+        acc = O.G1.add_mixed(acc, pt)
+    assert M.g1_jac_from_raw(acc) == outs[1]
