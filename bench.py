@@ -72,17 +72,25 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer
+    # GPUs than ranks (ranks then share devices); the driver's multi-GPU run uses nccl (= RCCL over xGMI).
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import phase2_bn254_amd as zk
     import inputs
 
     L = zk.lib.load()
-    worker = zk.Worker(local_rank)
+    worker = zk.Worker(dev_index)
 
     log_n = args.log_n
     n_total = 1 << log_n
@@ -113,7 +121,7 @@ def main() -> int:
         if world == 1:
             return part
         # the path's one exchange step: all-gather of the 96-byte partials, then local EC adds
-        return zk.shard.allgather_join(part, device=dev)
+        return zk.shard.allgather_join(part, device=dev if backend == "nccl" else None)
 
     for _ in range(args.warmup):
         step()
@@ -133,7 +141,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     L.mi355zk_prof_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -15,6 +15,7 @@
 namespace zk {
 // ntt.hip
 int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st);
+int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, const Fr* post_c, const Fr* post_g, hipStream_t st);
 int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st);
 void ntt_release_all();
 int ntt_configure();
@@ -187,18 +188,12 @@ int domain_op_dev(Fr* d_a, uint32_t log_n, int op, hipStream_t st) {
   switch (op) {
     case MI355ZK_OP_FFT:  // domain.rs:154-157
       return ntt_run(d_a, log_n, D.omega, st);
-    case MI355ZK_OP_IFFT:  // domain.rs:159-174: best_fft(omegainv) then *= minv
-      rc = ntt_run(d_a, log_n, D.omegainv, st);
-      if (rc) return rc;
-      return ntt_scale(d_a, log_n, D.minv, nullptr, st);
-    case MI355ZK_OP_COSET_FFT:  // domain.rs:191-195: distribute_powers(g) then fft
-      rc = ntt_scale(d_a, log_n, Fr::one(), &D.gen, st);
-      if (rc) return rc;
-      return ntt_run(d_a, log_n, D.omega, st);
-    case MI355ZK_OP_ICOSET_FFT:  // domain.rs:197-203: ifft then distribute_powers(geninv)
-      rc = ntt_run(d_a, log_n, D.omegainv, st);
-      if (rc) return rc;
-      return ntt_scale(d_a, log_n, D.minv, &D.geninv, st);
+    case MI355ZK_OP_IFFT:  // domain.rs:159-174: best_fft(omegainv), then *= minv (fused into the last pass)
+      return ntt_run_scaled(d_a, log_n, D.omegainv, nullptr, &D.minv, nullptr, st);
+    case MI355ZK_OP_COSET_FFT:  // domain.rs:191-195: distribute_powers(g) (fused into the first pass), then fft
+      return ntt_run_scaled(d_a, log_n, D.omega, &D.gen, nullptr, nullptr, st);
+    case MI355ZK_OP_ICOSET_FFT:  // domain.rs:197-203: ifft, then distribute_powers(geninv) (both fused into the last pass)
+      return ntt_run_scaled(d_a, log_n, D.omegainv, nullptr, &D.minv, &D.geninv, st);
     default:
       return ZK_ERR_BAD_ARGS;
   }

@@ -199,14 +199,19 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __
   store_vec(outS + t, run);
 }
 
-// out[w] = sum_{i < count} in[w*count + i]   (one workgroup per window; strided serial sums, then an LDS tree)
+// out[w*nblk + blk] = sum of slice `blk` (of `per_block` elements) of in[w*count .. (w+1)*count).
+// Launched as grid (nblk, W): strided serial sums of <= per_block/128 elements per lane, then an LDS tree.
+// Applied repeatedly until one element per window is left.
 template <class F>
-__global__ void __launch_bounds__(128) msm_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, XYZZ<F>* __restrict__ out) {
+__global__ void __launch_bounds__(128) msm_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t per_block,
+                                                     XYZZ<F>* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const XYZZ<F>* P = in + (uint64_t)blockIdx.x * count;
+  const uint32_t w = blockIdx.y, blk = blockIdx.x;
+  const XYZZ<F>* P = in + (uint64_t)w * count;
+  uint32_t lo = blk * per_block, hi = lo + per_block < count ? lo + per_block : count;
   XYZZ<F> acc = XYZZ<F>::zero();
-  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) xyzz_add(acc, load_vec(P + i));
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) xyzz_add(acc, load_vec(P + i));
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(128) msm_sum_kernel(const XYZZ<F>* __restrict_
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_vec(out + blockIdx.x, sh[0]);
+  if (threadIdx.x == 0) store_vec(out + (uint64_t)w * gridDim.x + blk, sh[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,6 +329,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_partA = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
   size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
   size_t o_wsums = take((size_t)G.W * n_levels * sizeof(XYZZ<F>));
+  const uint32_t SUM_PER_BLOCK = 1024;  // 128 lanes x 8 elements
+  size_t o_sumtmp = take((size_t)G.W * ((lvl_chunks[0] + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK + 1) * 2 * sizeof(XYZZ<F>));
   size_t o_err = take(8);
   size_t o_sort = take(sort_tmp_bytes);
 
@@ -342,6 +349,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   XYZZ<F>* partA = (XYZZ<F>*)(ws + o_partA);
   XYZZ<F>* partS = (XYZZ<F>*)(ws + o_partS);
   XYZZ<F>* wsums = (XYZZ<F>*)(ws + o_wsums);
+  XYZZ<F>* sumtmp = (XYZZ<F>*)(ws + o_sumtmp);
   unsigned long long* d_err = (unsigned long long*)(ws + o_err);
 
   ZK_HIP(hipMemsetAsync(d_err, 0xff, 8, st));
@@ -391,8 +399,22 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], L, lv == 0 ? 1u : 0u,
                          G.W, A, S);
       ZK_HIP(hipGetLastError());
-      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(G.W), dim3(128), 128 * sizeof(XYZZ<F>), st, A, lvl_chunks[lv], wsums + (uint64_t)lv * G.W);
-      ZK_HIP(hipGetLastError());
+      {  // wsums[lv][w] = sum_ch A[w][ch], by repeated blocked sums
+        const XYZZ<F>* src = A;
+        uint32_t cnt = lvl_chunks[lv];
+        uint32_t half = (lvl_chunks[0] + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK + 1;
+        int flip = 0;
+        for (;;) {
+          uint32_t nblk = (cnt + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK;
+          XYZZ<F>* dst = nblk == 1 ? wsums + (uint64_t)lv * G.W : sumtmp + (uint64_t)flip * half * G.W;
+          hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(nblk, G.W), dim3(128), 128 * sizeof(XYZZ<F>), st, src, cnt, SUM_PER_BLOCK, dst);
+          ZK_HIP(hipGetLastError());
+          if (nblk == 1) break;
+          src = dst;
+          cnt = nblk;
+          flip ^= 1;
+        }
+      }
       in = S;
       o += lvl_chunks[lv];
     }

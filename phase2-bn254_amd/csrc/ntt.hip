@@ -2,27 +2,34 @@
 //
 // Replaces, behind the C ABI of include/mi355zk.h, the reference's
 //   bellman/src/domain.rs:263-376  best_fft / serial_fft / parallel_fft   (-> ntt_run)
-//   bellman/src/domain.rs:159-203  ifft scaling, distribute_powers, coset_fft, icoset_fft
+//   bellman/src/domain.rs:159-203  ifft scaling, distribute_powers, coset_fft, icoset_fft (fused in)
 // for `Scalar<Bn256>` elements (bellman/src/group.rs:53-82): 32-byte Montgomery Fr limbs, natural
 // order in, natural order out, in place.
 //
 // Algorithm (not the reference's): a size-N transform is factored N = N_1 * ... * N_R (R <= 3,
 // N_p <= 1024) Cooley-Tukey style.  Pass p transforms digit p of the index for G adjacent
-// "columns" at once: a workgroup stages a G x N_p tile (<= 4096 elements, 128 KiB) in LDS as eight
-// 32-bit limb planes (conflict-free ds_read_b32 for unit-stride lanes), runs log2(N_p) DIF stages
-// there, multiplies by the inter-pass twiddle omega^(T_p*k_p*rest) and writes back.  The last pass
-// writes straight to the natural-order position (fused digit-reversal), with the G tile rows chosen
-// so that both its loads and its stores are >= 128-byte contiguous.  HBM traffic: 64 B per element
-// per pass (R passes) -- DESIGN.md "NTT".  The mathematical result X[k] = sum_i a[i] w^(ik) is
-// unique, and Fr elements are kept fully reduced, so the output limbs are bit-identical to
-// serial_fft's.
+// "columns" at once: a workgroup stages a G x N_p tile (<= 4096 elements) in LDS as NINE 29-bit limb
+// planes (U-form, fieldu.hpp; unit-stride lanes -> conflict-free ds_read_b32), runs log2(N_p) DIT stages
+// there, multiplies by the inter-pass twiddle omega^(T_p*k_p*rest) and writes back in the 32-byte
+// memory format.  The last pass writes straight to the natural-order position (fused digit reversal),
+// with the G tile rows chosen so that both its loads and its stores are >= 128-byte contiguous.
+// distribute_powers (coset) is fused into the first pass's load, the 1/m and g^-k scalings into the
+// last pass's store.  HBM traffic: 64 B per element per pass (R passes) -- DESIGN.md "NTT".
+//
+// U-form bookkeeping (fieldu.hpp): data stays in the memory format's 2^256 domain the whole time --
+// u_mul(data, tw) with the twiddle tables kept in the 2^261 domain returns data*tw in the 2^256
+// domain -- so loads and stores only re-pack bits.  DIT butterflies (a + w b, a - w b) grow values
+// linearly: V_s <= V_0 + 2 s p <= 24p after 10 stages, far below u_mul's 2^261-related limits; limbs
+// are carried every 4th stage (the bound of each call is noted at the call).
+// The mathematical result X[k] = sum_i a[i] w^(ik) is unique and the stored elements are fully
+// reduced, so the output bytes are identical to serial_fft's.
 #include <hip/hip_runtime.h>
 
 #include <map>
 #include <mutex>
 #include <vector>
 
-#include "curve.hpp"
+#include "fieldu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -43,20 +50,39 @@ struct NttPassParams {
   uint64_t in_hi_stride, in_lo_stride;
   uint64_t out_hi_stride, out_lo_stride;
   uint32_t load_x_fastest;  // lane order on load: 1 = transform index fastest (last pass)
-  // inter-pass twiddle  w^(tw_mul * k * (lo*g + gidx)) ; tw_mul == 0 -> none
+  // inter-pass twiddle  w^(tw_mul * k * (lo*g + gidx)) ; tw_mul == 0 -> none (last pass)
   uint64_t tw_mul;
   uint32_t tw_h;            // two-level split: w^e = A[e >> h] * B[e & (2^h - 1)]
+  uint32_t pre;             // first pass of coset_fft: element i *= g^i   (preA/preB, split pre_h)
+  uint32_t pre_h;
+  uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h)
+  uint32_t post_h;
 };
 
-__device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t plane, uint32_t idx) {
-  Fr r;
-#pragma unroll
-  for (int l = 0; l < 8; ++l) r.l[l] = lds[l * plane + idx];
+// table entry: U-form element in the 2^261 domain, padded to 48 B for three 16-byte loads
+struct alignas(16) UTab {
+  uint32_t l[12];
+};
+
+__device__ __forceinline__ FrU tab_load(const UTab* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2];
+  FrU r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x;
   return r;
 }
-__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t plane, uint32_t idx, const Fr& v) {
+
+__device__ __forceinline__ FrU lds_load(const uint32_t* lds, uint32_t plane, uint32_t idx) {
+  FrU r;
 #pragma unroll
-  for (int l = 0; l < 8; ++l) lds[l * plane + idx] = v.l[l];
+  for (int l = 0; l < 9; ++l) r.l[l] = lds[l * plane + idx];
+  return r;
+}
+__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t plane, uint32_t idx, const FrU& v) {
+#pragma unroll
+  for (int l = 0; l < 9; ++l) lds[l * plane + idx] = v.l[l];
 }
 __device__ __forceinline__ Fr gload(const Fr* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -76,8 +102,10 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 
 // One pass over one tile.  roots[x] = w_p^x for x < N_p/2 (w_p = omega^(N/N_p)).
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, NttPassParams P,
-                                                              const Fr* __restrict__ roots, const Fr* __restrict__ twA,
-                                                              const Fr* __restrict__ twB) {
+                                                              const UTab* __restrict__ roots, const UTab* __restrict__ twA,
+                                                              const UTab* __restrict__ twB, const UTab* __restrict__ preA,
+                                                              const UTab* __restrict__ preB, const UTab* __restrict__ postA,
+                                                              const UTab* __restrict__ postB, FrU post_c) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t np = 1u << P.log_np;
   const uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
@@ -85,67 +113,87 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   const uint32_t elems = P.g * np;
   const uint64_t tile = blockIdx.x;
   const uint64_t hi = tile / P.tiles_lo, lo = tile % P.tiles_lo;
-  const Fr* src = in + hi * P.in_hi_stride + lo * P.in_lo_stride;
-  Fr* dst = out + hi * P.out_hi_stride + lo * P.out_lo_stride;
+  const uint64_t in_base = hi * P.in_hi_stride + lo * P.in_lo_stride;
+  const uint64_t out_base = hi * P.out_hi_stride + lo * P.out_lo_stride;
 
+  // load (bit-reversed placement inside each row: the DIT stages below then finish in natural order)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
     uint32_t x, g;
     if (P.load_x_fastest) { x = e & (np - 1); g = e >> P.log_np; }
     else { g = e % P.g; x = e / P.g; }
-    lds_store(lds, plane, g * pitch + x, gload(src + x * P.in_xs + g * P.in_gs));
+    const uint64_t gi = in_base + x * P.in_xs + g * P.in_gs;
+    FrU v = u_from_std(gload(in + gi));                                   // < p, N
+    if (P.pre) {                                                          // distribute_powers (domain.rs:176-189)
+      FrU w = u_mul(tab_load(preA + (gi >> P.pre_h)), tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));  // g^i, < 2p
+      v = u_mul(v, w);                                                    // < 2p, N
+    }
+    lds_store(lds, plane, g * pitch + bitrev(x, P.log_np), v);
   }
   __syncthreads();
 
-  // DIF stages: natural order in, bit-reversed order out (within each row)
+  // DIT stages.  Entering stage s every element is < (4 + 2s) p with limbs < ((s & 3) + 1) * 2^29.
   const uint32_t half = elems >> 1;
-  for (int s = (int)P.log_np - 1; s >= 0; --s) {
+  for (uint32_t s = 0; s < P.log_np; ++s) {
     const uint32_t m = 1u << s;
+    const bool carry_now = (s & 3) == 3;
     for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
       uint32_t g = b >> (P.log_np - 1);
       uint32_t bf = b & ((np >> 1) - 1);
       uint32_t j = bf & (m - 1);
       uint32_t i0 = g * pitch + ((bf >> s) << (s + 1)) + j;
       uint32_t i1 = i0 + m;
-      Fr u = lds_load(lds, plane, i0);
-      Fr v = lds_load(lds, plane, i1);
-      Fr d = sub(u, v);
-      if (s != 0) d = mul(d, gload(roots + ((uint64_t)j << (P.log_np - 1 - s))));  // j == 0 only when s == 0 -> w = 1
-      lds_store(lds, plane, i0, add(u, v));
-      lds_store(lds, plane, i1, d);
+      FrU u = lds_load(lds, plane, i0);
+      FrU t = lds_load(lds, plane, i1);
+      if (s != 0) t = u_mul(t, tab_load(roots + ((uint64_t)j << (P.log_np - 1 - s))));  // limbs < 4*2^29 times N: ok; < 2p, N
+      else t = u_carry(t);                                                // stage 0: w = 1; inputs are N already (no-op carry keeps the form explicit)
+      FrU sum = u_add(u, t);                                              // limbs grow by 2^29, value by 2p
+      if (carry_now) sum = u_carry(sum);
+      FrU dif = u_sub<2, 1>(u, t);                                        // t < 2p N; u limbs < 4*2^29 < 2^32 - 2^30 - 16: ok.  N out
+      lds_store(lds, plane, i0, sum);
+      lds_store(lds, plane, i1, dif);
     }
     __syncthreads();
   }
 
+  // store: one more product brings the value below 2p (inter-pass twiddle, or the post scale / one on the last pass)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
     uint32_t g = e % P.g, k = e / P.g;
-    Fr v = lds_load(lds, plane, g * pitch + bitrev(k, P.log_np));
-    if (P.tw_mul != 0 && k != 0) {
-      uint64_t rest = lo * P.g + g;
-      if (rest != 0) {
-        uint64_t ex = P.tw_mul * k * rest;
-        Fr w = mul(gload(twA + (ex >> P.tw_h)), gload(twB + (ex & ((1ull << P.tw_h) - 1))));
-        v = mul(v, w);
-      }
+    FrU v = lds_load(lds, plane, g * pitch + k);                          // < 24p, limbs < 4*2^29
+    const uint64_t go = out_base + k * P.out_xs + g * P.out_gs;
+    FrU w;
+    if (P.tw_mul != 0) {
+      uint64_t ex = P.tw_mul * k * (lo * P.g + g);
+      w = u_mul(tab_load(twA + (ex >> P.tw_h)), tab_load(twB + (ex & ((1ull << P.tw_h) - 1))));
+    } else if (P.post == 2) {                                             // minv * ginv^k (icoset_fft, domain.rs:197-203)
+      w = u_mul(tab_load(postA + (go >> P.post_h)), tab_load(postB + (go & ((1ull << P.post_h) - 1))));
+      w = u_mul(w, post_c);
+    } else {
+      w = post_c;                                                         // one (fft / coset_fft) or minv (ifft, domain.rs:163-173)
     }
-    gstore(dst + k * P.out_xs + g * P.out_gs, v);
+    gstore(out + go, u_to_std_lt2p(u_mul(v, w)));                          // 24 * 2 * 0.006 + 1 < 2p
   }
 }
 
-// tab[j] = base^(j * step), j < count
-__global__ void ntt_pow_table_kernel(Fr* tab, Fr base, uint64_t step, uint64_t count) {
+// tab[j] = base^(j * step) in U-form, 2^261 domain:  u_mul(x * 2^256, 2^266) = x * 2^261
+__global__ void ntt_pow_table_kernel(UTab* tab, Fr base, uint64_t step, uint64_t count) {
   uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
-  tab[j] = pow_u64(base, j * step);
+  FrU u = u_mul(u_from_std(pow_u64(base, j * step)), UPow2<FrParams, 266>::get());
+  UTab t;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t.l[i] = u.l[i];
+  t.l[9] = t.l[10] = t.l[11] = 0;
+  tab[j] = t;
 }
 
-// a[i] *= c * gA[i >> h] * gB[i & mask]   (gA == nullptr: a[i] *= c)
-__global__ void ntt_scale_kernel(Fr* a, uint64_t n, Fr c, const Fr* __restrict__ gA, const Fr* __restrict__ gB, uint32_t h) {
+// a[i] *= c * gA[i >> h] * gB[i & mask]   (gA == nullptr: a[i] *= c);  c in the memory format
+__global__ void ntt_scale_kernel(Fr* a, uint64_t n, Fr c, const UTab* __restrict__ gA, const UTab* __restrict__ gB, uint32_t h) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr v = gload(a + i);
-  Fr w = c;
-  if (gA != nullptr) w = mul(w, mul(gload(gA + (i >> h)), gload(gB + (i & ((1ull << h) - 1)))));
-  gstore(a + i, mul(v, w));
+  FrU v = u_from_std(gload(a + i));
+  FrU w = u_mul(u_from_std(c), UPow2<FrParams, 266>::get());            // c * 2^261
+  if (gA != nullptr) w = u_mul(w, u_mul(tab_load(gA + (i >> h)), tab_load(gB + (i & ((1ull << h) - 1)))));
+  gstore(a + i, u_to_std_lt2p(u_mul(v, w)));
 }
 
 struct Key {
@@ -165,9 +213,9 @@ struct Key {
 // every fft of a proof: bellman/src/groth16/prover.rs:217-241).
 struct PowTables {
   uint32_t h = 0;          // w^e = A[e >> h] * B[e & (2^h-1)], e < 2^log_n
-  Fr* A = nullptr;
-  Fr* B = nullptr;
-  Fr* roots[NTT_MAX_LOG_NP + 1] = {};  // roots[b][x] = (w^(N/2^b))^x, x < 2^(b-1)
+  UTab* A = nullptr;
+  UTab* B = nullptr;
+  UTab* roots[NTT_MAX_LOG_NP + 1] = {};  // roots[b][x] = (w^(N/2^b))^x, x < 2^(b-1)
 };
 
 std::mutex g_mu;
@@ -187,8 +235,8 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
     built = true;
     T.h = (log_n + 1) / 2;
     uint64_t nB = 1ull << T.h, nA = 1ull << (log_n - T.h);
-    ZK_HIP(hipMalloc(&T.A, nA * sizeof(Fr)));
-    ZK_HIP(hipMalloc(&T.B, nB * sizeof(Fr)));
+    ZK_HIP(hipMalloc(&T.A, nA * sizeof(UTab)));
+    ZK_HIP(hipMalloc(&T.B, nB * sizeof(UTab)));
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, st, T.A, w, nB, nA);
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, st, T.B, w, 1ull, nB);
     ZK_HIP(hipGetLastError());
@@ -199,7 +247,7 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
       if (b == 0 || T.roots[b] != nullptr) continue;
       built = true;
       uint64_t cnt = 1ull << (b - 1);
-      ZK_HIP(hipMalloc(&T.roots[b], cnt * sizeof(Fr)));
+      ZK_HIP(hipMalloc(&T.roots[b], cnt * sizeof(UTab)));
       hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.roots[b], w, 1ull << (log_n - b), cnt);
       ZK_HIP(hipGetLastError());
     }
@@ -221,7 +269,7 @@ int g_cfg_rc = 0;
 
 }  // namespace
 
-// the tile kernel stages up to 4 x 1025 x 32 B = 128 KiB in dynamic LDS (gfx950: 160 KiB per CU)
+// the tile kernel stages up to 4 x 1025 x 36 B = 144 KiB in dynamic LDS (gfx950: 160 KiB per CU)
 int ntt_configure() {
   std::call_once(g_cfg_once, [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -250,9 +298,18 @@ void ntt_release_all() {
   g_scratch.clear();
 }
 
-// d_a: 2^log_n Fr elements on the current device.  X[k] = sum_i a[i] * omega^(i*k), in place.
-int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st) {
-  if (log_n == 0) return 0;
+int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st);
+
+static FrU to_u261(const Fr& x) { return u_mul(u_from_std(x), UPow2<FrParams, 266>::get()); }  // host: x*2^256 -> x*2^261
+
+// d_a: 2^log_n Fr elements on the current device, in place:
+//   a[i] *= pre_g^i (if pre_g)  ->  X[k] = sum_i a[i] * omega^(i*k)  ->  X[k] *= post_c * post_g^k (if given).
+int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, const Fr* post_c, const Fr* post_g, hipStream_t st) {
+  if (log_n == 0) {
+    // single element: X[0] = a[0] * post_c
+    if (post_c == nullptr) return 0;
+    return ntt_scale(d_a, 0, *post_c, nullptr, st);
+  }
   if (log_n > 30) return ZK_ERR_BAD_ARGS;
   const uint64_t n = 1ull << log_n;
   // factor the index: R passes of b[p] bits, b[0] most significant digit (DESIGN.md "NTT")
@@ -265,6 +322,11 @@ int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st) {
   PowTables* T = nullptr;
   rc = build_pow_tables(st, log_n, omega, true, b, R, &T);
   if (rc) return rc;
+  PowTables* Tpre = nullptr;
+  PowTables* Tpost = nullptr;
+  if (pre_g) { rc = build_pow_tables(st, log_n, *pre_g, false, nullptr, 0, &Tpre); if (rc) return rc; }
+  if (post_g) { rc = build_pow_tables(st, log_n, *post_g, false, nullptr, 0, &Tpost); if (rc) return rc; }
+  const FrU post_cu = to_u261(post_c ? *post_c : Fr::one());
   static const int slot_pass = prof_slot("ntt_pass");
 
   std::lock_guard<std::mutex> run_lk(g_run_mu);
@@ -337,25 +399,30 @@ int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st) {
       P.tw_mul = 0;
       tiles = (N1 / G) * mid;
     }
+    if (p == 0 && Tpre) { P.pre = 1; P.pre_h = Tpre->h; }
+    if (p == R - 1) { P.post = Tpost ? 2 : 1; P.post_h = Tpost ? Tpost->h : 0; }
     uint32_t pitch = np >= 32 ? (uint32_t)np + 1 : (uint32_t)np;
-    size_t lds_bytes = (size_t)P.g * pitch * 32;
+    size_t lds_bytes = (size_t)P.g * pitch * 36;
     uint32_t threads = (uint32_t)((P.g * np) / 2);
     if (threads > NTT_THREADS) threads = NTT_THREADS;
     if (threads < 64) threads = 64;
     prof_begin(slot_pass, st);
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, T->B);
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, T->B,
+                       Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr, post_cu);
     ZK_HIP(hipGetLastError());
     prof_end(slot_pass, st);
   }
   return 0;
 }
 
-// a[i] *= c * g^i  (g == nullptr: a[i] *= c).  distribute_powers (domain.rs:176-189) and the ifft
-// scaling (domain.rs:163-173) in one elementwise kernel.
+int ntt_run(Fr* d_a, uint32_t log_n, const Fr& omega, hipStream_t st) { return ntt_run_scaled(d_a, log_n, omega, nullptr, nullptr, nullptr, st); }
+
+// a[i] *= c * g^i  (g == nullptr: a[i] *= c): standalone elementwise form of distribute_powers
+// (domain.rs:176-189) / the ifft scaling (domain.rs:163-173); the domain ops use the fused forms above.
 int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st) {
   const uint64_t n = 1ull << log_n;
-  const Fr* A = nullptr;
-  const Fr* B = nullptr;
+  const UTab* A = nullptr;
+  const UTab* B = nullptr;
   uint32_t h = 0;
   if (g != nullptr && log_n > 0) {
     PowTables* T = nullptr;
