@@ -138,32 +138,81 @@ __global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restr
   if (j + 1 == m || keys[j + 1] != k) last[k] = (uint32_t)j + 1;
 }
 
-// 4. one lane per bucket.  G1 runs on U-form arithmetic (curveu.hpp: 29-bit lazy limbs, one v_mad_u64_u32
-//    per partial product, no carry flags); G2 still uses the saturated-limb XYZZ of curve.hpp.
-template <class F>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
-                                                            const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                            uint32_t n_buckets, XYZZ<F>* __restrict__ buckets) {
+// 3b. size[b] = last[b] - first[b], id[b] = b : sorted by size (descending) so that the 64 lanes of a wave
+//     own buckets of (nearly) equal length -- bucket sizes are Poisson distributed and a wave runs as long
+//     as its longest lane -- and so that the few very long buckets of a skewed input come first.
+__global__ void __launch_bounds__(256) msm_sizes_kernel(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                       uint32_t n_buckets, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ids) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_buckets) return;
-  uint32_t j = first[b], e = last[b];
+  sizes[b] = last[b] - first[b];
+  ids[b] = b;
+}
+
+constexpr uint32_t MSM_HEAVY_BLOCKS = 4096;  // at most this many buckets get a whole workgroup
+
+template <class F>
+__device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
+                                                  uint32_t stride) {
   if constexpr (std::is_same<F, Fq>::value) {
     XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
-    for (; j < e; ++j) {
+    for (; j < e; j += stride) {
       uint32_t v = vals[j];
       Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
       xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
-    store_vec(buckets + b, xyzzu_to_std(acc));
+    return xyzzu_to_std(acc);
   } else {
     XYZZ<F> acc = XYZZ<F>::zero();
-    for (; j < e; ++j) {
+    for (; j < e; j += stride) {
       uint32_t v = vals[j];
       Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
       xyzz_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
-    store_vec(buckets + b, acc);
+    return acc;
   }
+}
+
+// 4a. heavy buckets (longer than `heavy`): one workgroup per bucket, 256 strided partial sums + LDS tree.
+//     Keeps a skewed scalar distribution (many equal scalars -> one huge bucket per window) from
+//     serialising on a single lane.
+template <class F>
+__global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                                                  const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                                  const uint32_t* __restrict__ order, uint32_t heavy,
+                                                                  XYZZ<F>* __restrict__ buckets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t b = order[blockIdx.x];
+  const uint32_t j0 = first[b], e = last[b];
+  if (e - j0 <= heavy) return;  // uniform per workgroup
+  sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x);
+  __syncthreads();
+  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      XYZZ<F> a = sh[threadIdx.x];
+      xyzz_add(a, sh[threadIdx.x + s]);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_vec(buckets + b, sh[0]);
+}
+
+// 4b. one lane per bucket, buckets taken in size order.  G1 runs on U-form arithmetic (curveu.hpp: 29-bit
+//     lazy limbs, one v_mad_u64_u32 per partial product, no carry flags); G2 still uses the saturated-limb
+//     XYZZ of curve.hpp.
+template <class F>
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                                            const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                            const uint32_t* __restrict__ order, uint32_t heavy, uint32_t n_buckets,
+                                                            XYZZ<F>* __restrict__ buckets) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_buckets) return;
+  const uint32_t b = order[i];
+  const uint32_t j = first[b], e = last[b];
+  if (i < MSM_HEAVY_BLOCKS && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
+  store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1));
 }
 
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
@@ -317,14 +366,21 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   int key_bits = 1;
   while ((1ull << key_bits) <= G.invalid) ++key_bits;
 
-  size_t sort_tmp_bytes = 0;
+  size_t sort_tmp_bytes = 0, sort2_tmp_bytes = 0;
   ZK_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                    (uint32_t*)nullptr, (size_t)m, 0, key_bits, st));
+  int size_bits = 1;
+  while (size_bits < 32 && (1ull << size_bits) <= n) ++size_bits;  // a bucket holds at most n entries
+  ZK_HIP(rocprim::radix_sort_pairs_desc(nullptr, sort2_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (uint32_t*)nullptr, (size_t)n_buckets, 0, size_bits, st));
+  if (sort2_tmp_bytes > sort_tmp_bytes) sort_tmp_bytes = sort2_tmp_bytes;
 
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   size_t o_keys_a = take(m * 4), o_keys_b = take(m * 4), o_vals_a = take(m * 4), o_vals_b = take(m * 4);
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4);
+  size_t o_sizes_a = take((size_t)n_buckets * 4), o_sizes_b = take((size_t)n_buckets * 4);
+  size_t o_ids_a = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
   size_t o_partA = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
   size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
@@ -345,6 +401,10 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t* vals_b = (uint32_t*)(ws + o_vals_b);
   uint32_t* first = (uint32_t*)(ws + o_first);
   uint32_t* last = (uint32_t*)(ws + o_last);
+  uint32_t* sizes_a = (uint32_t*)(ws + o_sizes_a);
+  uint32_t* sizes_b = (uint32_t*)(ws + o_sizes_b);
+  uint32_t* ids_a = (uint32_t*)(ws + o_ids_a);
+  uint32_t* order = (uint32_t*)(ws + o_ids_b);
   XYZZ<F>* buckets = (XYZZ<F>*)(ws + o_buckets);
   XYZZ<F>* partA = (XYZZ<F>*)(ws + o_partA);
   XYZZ<F>* partS = (XYZZ<F>*)(ws + o_partS);
@@ -378,13 +438,25 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   ZK_HIP(rocprim::radix_sort_pairs((void*)(ws + o_sort), sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, key_bits, st));
   hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys_b, m, G.invalid, first, last);
   ZK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(msm_sizes_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, st, first, last, n_buckets, sizes_a, ids_a);
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(rocprim::radix_sort_pairs_desc((void*)(ws + o_sort), sort_tmp_bytes, sizes_a, sizes_b, ids_a, order, (size_t)n_buckets, 0, size_bits, st));
   prof_end(slot_sort, st);
   if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
 
   prof_begin(slot_acc, st);
-  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, d_bases, vals_b, first, last, n_buckets,
-                     buckets);
-  ZK_HIP(hipGetLastError());
+  {
+    // a bucket is "heavy" when it is far longer than the mean: it then gets a workgroup instead of a lane
+    uint64_t mean = n / G.nb + 1;
+    uint32_t heavy = (uint32_t)(mean * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean * 8 + 1024);
+    uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
+    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, d_bases, vals_b, first, last, order,
+                       heavy, buckets);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, d_bases, vals_b, first, last, order, heavy,
+                       n_buckets, buckets);
+    ZK_HIP(hipGetLastError());
+  }
   prof_end(slot_acc, st);
   if (checkpoint("accumulate")) return ZK_ERR_DEVICE;
 
