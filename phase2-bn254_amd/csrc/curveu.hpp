@@ -13,7 +13,7 @@
 // (2) BOUNDS.  Every value is annotated "< k p" and every limb vector "N" (limbs 0..7 < 2^29) or "< s*2^29";
 //     they are exactly the preconditions of u_mul / u_sub in fieldu.hpp.  c = p/2^261 < 0.0060 is the factor
 //     by which a product of two values (in units of p) shrinks:  u_mul(a, b) < (a/p)(b/p) * 0.006 p + p.
-//     Accumulator invariant:  X < 6p,  Y < 4p,  ZZ < 2p,  ZZZ < 2p,  all N-form.
+//     Accumulator invariant:  X < 6p,  Y < 2p,  ZZ < 2p,  ZZZ < 2p,  all N-form.
 //     Infinity is ZZ == literal zero limbs.
 #pragma once
 
@@ -53,18 +53,17 @@ ZK_HD XYZZU<PR> xyzzu_double_affine(const FpU<PR>& x2, const FpU<PR>& y2) {
   FpU<PR> x = u_mul(x2, C);                   // x * 2^261, < 2p, N
   FpU<PR> y = u_mul(y2, C);                   // y * 2^261, < 2p, N
   FpU<PR> u = u_dbl(y);                       // < 4p, limbs < 2^30
-  FpU<PR> v = u_mul(u, u);                    // < 1.1p
+  FpU<PR> v = u_mul(u, u);                    // < 1.1p   (u is not N-form: plain product)
   FpU<PR> w = u_mul(u, v);                    // < 1.1p
   FpU<PR> s = u_mul(x, v);                    // < 1.1p
-  FpU<PR> xx = u_mul(x, x);                   // < 1.1p
+  FpU<PR> xx = u_sqr(x);                      // < 1.1p
   FpU<PR> m = u_carry(u_add(u_dbl(xx), xx));  // 3*xx < 3.3p, N after the carry
-  FpU<PR> mm = u_mul(m, m);                   // < 1.1p
+  FpU<PR> mm = u_sqr(m);                      // < 1.1p
   XYZZU<PR> r;
   r.x = u_sub<4, 2>(mm, u_dbl(s));            // 2s < 2.2p <= 4p, limbs < 2^30;  X < 5.1p
   FpU<PR> d = u_sub<8, 1>(s, r.x);            // < 9.1p
-  FpU<PR> a = u_mul(m, d);                    // < 1.2p
-  FpU<PR> b = u_mul(w, y);                    // < 1.1p
-  r.y = u_sub<2, 1>(a, b);                    // < 3.2p
+  FpU<PR> ny = u_sub<2, 1>(FpU<PR>::zero(), y);  // 2p - y, N
+  r.y = u_mul2(m, d, w, ny);                  // M*D - W*y: (3.3*9.1 + 1.1*2) c + 1 < 1.2p  (invariant Y < 2p)
   r.zz = u_mul(v, C);                         // v * 2^266, < 2p
   r.zzz = u_mul(w, C);
   return r;
@@ -91,17 +90,16 @@ ZK_HD void xyzzu_add_mixed(XYZZU<PR>& acc, const Fp<PR>& x2s, const Fp<PR>& y2s,
   FpU<PR> u2 = u_mul(x2, acc.zz);                           // < 2p
   FpU<PR> s2 = u_mul(y2, acc.zzz);                          // < 2p
   FpU<PR> p = u_sub<8, 1>(u2, acc.x);                       // X < 6p <= 8p;   P < 10p, N
-  FpU<PR> r = u_sub<4, 1>(s2, acc.y);                       // Y < 4p;         R < 6p, N
-  FpU<PR> pp = u_mul(p, p);                                 // 100c + 1 < 1.6p
+  FpU<PR> r = u_sub<2, 1>(s2, acc.y);                       // Y < 2p;         R < 4p, N
+  FpU<PR> pp = u_sqr(p);                                    // 100c + 1 < 1.6p
   FpU<PR> ppp = u_mul(p, pp);                               // < 1.1p
   FpU<PR> q = u_mul(acc.x, pp);                             // < 1.06p
-  FpU<PR> rr = u_mul(r, r);                                 // 36c + 1 < 1.22p
+  FpU<PR> rr = u_sqr(r);                                    // 16c + 1 < 1.1p
   FpU<PR> t = u_add(ppp, u_dbl(q));                         // < 3.3p <= 4p, limbs < 3 * 2^29
-  FpU<PR> x3 = u_sub<4, 3>(rr, t);                          // < 5.3p  (invariant X < 6p)
+  FpU<PR> x3 = u_sub<4, 3>(rr, t);                          // < 5.1p  (invariant X < 6p)
   FpU<PR> d = u_sub<8, 1>(q, x3);                           // < 9.1p
-  FpU<PR> a1 = u_mul(r, d);                                 // 6 * 9.1 c + 1 < 1.33p
-  FpU<PR> b1 = u_mul(acc.y, ppp);                           // < 1.03p
-  FpU<PR> y3 = u_sub<2, 1>(a1, b1);                         // < 3.4p  (invariant Y < 4p)
+  FpU<PR> ny1 = u_sub<2, 1>(FpU<PR>::zero(), acc.y);        // 2p - Y1 in (0, 2p], N
+  FpU<PR> y3 = u_mul2(r, d, ny1, ppp);                      // R*D - Y1*PPP: (4*9.1 + 2*1.1) c + 1 < 1.24p  (invariant Y < 2p)
   FpU<PR> zz3 = u_mul(acc.zz, pp);                          // < 2p
   FpU<PR> zzz3 = u_mul(acc.zzz, ppp);                       // < 2p
   if (u_is_zero_lt2p(zz3)) {

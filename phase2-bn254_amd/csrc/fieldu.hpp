@@ -226,9 +226,74 @@ ZK_HD FpU<PR> u_mul(const FpU<PR>& a, const FpU<PR>& b) {
   return r;
 }
 
+// Montgomery reduction tail shared by u_mul / u_sqr / u_mul2: the callers add their product terms to
+// `acc` for column k through the callback and this adds the m_i * p_j terms and extracts the limb.
+template <class PR, class ProductTerms>
+ZK_HD FpU<PR> u_montgomery_columns(ProductTerms&& terms) {
+  uint32_t m[9];
+  FpU<PR> r;
+  uint64_t acc = 0;
+  for_limbs<17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    terms(kc, acc);
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9 && (k >= 9 || i < k)) {
+        constexpr uint32_t pj = UParams<PR>::P(j);
+        acc += (uint64_t)m[i] * pj;
+      }
+    });
+    if constexpr (k < 9) {
+      constexpr uint32_t p0 = UParams<PR>::P(0);
+      m[k] = ((uint32_t)acc * UParams<PR>::INV) & U_MASK;
+      acc += (uint64_t)m[k] * p0;  // low 29 bits are now zero
+    } else {
+      r.l[k - 9] = (uint32_t)acc & U_MASK;
+    }
+    acc >>= U_BITS;
+  });
+  r.l[8] = (uint32_t)acc;
+  return r;
+}
+
+// a^2 * 2^-261 mod p with the 36 cross products taken once against the doubled operand: 45 + 81 mads
+// instead of 162.   precondition: a N-form (limbs < 2^29; doubled limbs < 2^30, 4 cross terms + 1 square +
+// the Montgomery terms per column stay far below 2^64).   result as u_mul.
 template <class PR>
 ZK_HD FpU<PR> u_sqr(const FpU<PR>& a) {
-  return u_mul(a, a);
+  uint32_t a2[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a2[i] = a.l[i] << 1;
+  return u_montgomery_columns<PR>([&](auto kc, uint64_t& acc) {
+    constexpr int k = decltype(kc)::value;
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) {
+        if constexpr (i < j) acc += (uint64_t)a2[i] * a.l[j];
+        else if constexpr (i == j) acc += (uint64_t)a.l[i] * a.l[i];
+      }
+    });
+  });
+}
+
+// (a*b + c*d) * 2^-261 mod p with ONE Montgomery reduction: 162 + 81 mads instead of 324.
+//   preconditions: all four operands N-form (18 products < 2^58 per column);
+//   result: N-form, value < (value(a) value(b) + value(c) value(d)) / 2^261 + p.
+template <class PR>
+ZK_HD FpU<PR> u_mul2(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const FpU<PR>& d) {
+  return u_montgomery_columns<PR>([&](auto kc, uint64_t& acc) {
+    constexpr int k = decltype(kc)::value;
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) {
+        acc += (uint64_t)a.l[i] * b.l[j];
+        acc += (uint64_t)c.l[i] * d.l[j];
+      }
+    });
+  });
 }
 
 // value == 0 mod p for an N-form value < 2p  (i.e. value in {0, p})
