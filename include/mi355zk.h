@@ -134,6 +134,12 @@ int mi355zk_selftest_g1_accumulate(int mode, const uint64_t *affine_pts, const u
  * SURVEY 8f row 1); used here to synthesise tau-table-like bases on the device. */
 int mi355zk_bn254_g1_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[8], const void *d_scalars, size_t n, void *stream);
 int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[16], const void *d_scalars, size_t n, void *stream);
+/* ---- per-point batch exponentiation out[i] = k[i] * P[i] (same_scalar == 0; powersoftau `batch_exp`,
+ * batched_accumulator.rs:1130-1181) or out[i] = k[0] * P[i] (same_scalar != 0; phase2 contribute,
+ * phase2/src/parameters.rs:423-470), normalised to affine like `batch_normalization` (ec.rs:251-299);
+ * the all-zero record is infinity on both sides.  Asynchronous on `stream`. */
+int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
+int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
 
 /* ---- host-side group helpers on Jacobian results: acc += other (CurveProjective::add_assign,
  * ec.rs:360-454) -- how per-GPU partial sums are joined after the all-gather -- and into_affine

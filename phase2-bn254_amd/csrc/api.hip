@@ -6,10 +6,11 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mi355zk.h"
-#include "curve.hpp"
+#include "curveu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -109,37 +110,69 @@ void prof_reset() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// batch fixed-base scalar multiplication (input synthesis + SURVEY 8f row 1 building block)
+// batch scalar multiplication out[i] = k[i or 0] * P[i or 0], affine out (infinity -> all-zero record):
+// the per-point `batch_exp` of the ceremony code (powersoftau/src/batched_accumulator.rs:1130-1181: point i
+// by its own tau-power; phase2/src/parameters.rs:423-470: every point by the same delta^-1) followed by the
+// normalisation to affine that `batch_normalization` performs there (ec.rs:251-299).  The reference uses
+// wNAF-4; the group element, hence the affine output, is the same for plain MSB-first double-and-add.
+// G1 runs on U-form arithmetic (curveu.hpp).
 template <class F>
-__global__ void __launch_bounds__(256) batch_mul_kernel(Affine<F>* __restrict__ out, Affine<F> base, const uint32_t* __restrict__ scalars,
-                                                       uint64_t n) {
+__global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
+                                                       const uint32_t* __restrict__ scalars, int same_scalar, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
+  const uint32_t* sp = scalars + (same_scalar ? 0 : i * 8);
 #pragma unroll
-  for (int l = 0; l < 8; ++l) s[l] = scalars[i * 8 + l];
-  XYZZ<F> acc = XYZZ<F>::zero();
+  for (int l = 0; l < 8; ++l) s[l] = sp[l];
+  const Affine<F> base = bases[same_base ? 0 : i];
+  XYZZ<F> res = XYZZ<F>::zero();
   if (!base.is_zero()) {
     bool found = false;
-    for (int bit = 255; bit >= 0; --bit) {
-      bool b = (s[bit >> 5] >> (bit & 31)) & 1;
-      if (found) acc = xyzz_double(acc);
-      else found = b;
-      if (b) xyzz_add_mixed(acc, base.x, base.y, false);
+    if constexpr (std::is_same<F, Fq>::value) {
+      XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
+      for (int bit = 255; bit >= 0; --bit) {
+        bool b = (s[bit >> 5] >> (bit & 31)) & 1;
+        if (found) acc = xyzzu_double(acc);
+        else found = b;
+        if (b) xyzzu_add_mixed(acc, base.x, base.y, false);
+      }
+      res = xyzzu_to_std(acc);
+    } else {
+      for (int bit = 255; bit >= 0; --bit) {
+        bool b = (s[bit >> 5] >> (bit & 31)) & 1;
+        if (found) res = xyzz_double(res);
+        else found = b;
+        if (b) xyzz_add_mixed(res, base.x, base.y, false);
+      }
     }
   }
-  out[i] = xyzz_to_affine(acc);
+  out[i] = xyzz_to_affine(res);
 }
 
+template <class F>
+int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_scalars, int same_scalar, size_t n, void* stream) {
+  if (!d_out || !d_bases || !d_scalars) return n ? ZK_ERR_BAD_ARGS : ZK_OK;
+  if (n == 0) return ZK_OK;
+  hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (Affine<F>*)d_out,
+                     (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n);
+  ZK_HIP(hipGetLastError());
+  return ZK_OK;
+}
+
+// fixed base given by value on the host (input synthesis: P_i = k_i * G)
 template <class F>
 int batch_mul(void* d_out, const uint64_t* base_raw, const void* d_scalars, size_t n, void* stream) {
   if (!d_out || !base_raw || (!d_scalars && n)) return ZK_ERR_BAD_ARGS;
   if (n == 0) return ZK_OK;
-  Affine<F> base;
-  std::memcpy(&base, base_raw, sizeof base);
-  hipLaunchKernelGGL(batch_mul_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (Affine<F>*)d_out, base,
-                     (const uint32_t*)d_scalars, (uint64_t)n);
-  ZK_HIP(hipGetLastError());
+  Affine<F>* d_base = nullptr;
+  ZK_HIP(hipMalloc(&d_base, sizeof(Affine<F>)));
+  hipError_t e = hipMemcpyAsync(d_base, base_raw, sizeof(Affine<F>), hipMemcpyHostToDevice, (hipStream_t)stream);
+  int rc = e == hipSuccess ? batch_exp<F>(d_out, d_base, 1, d_scalars, 0, n, stream) : ZK_ERR_DEVICE;
+  if (rc == ZK_OK) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(d_base);
+  if (rc != ZK_OK) return rc;
+  ZK_HIP(e);
   return ZK_OK;
 }
 
@@ -407,6 +440,12 @@ int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affin
 }
 int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[16], const void* d_scalars, size_t n, void* stream) {
   return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
+}
+int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
+  return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+}
+int mi355zk_bn254_g2_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
+  return batch_exp<Fq2>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
 }
 
 // host-side group helpers (joining per-GPU partial sums, normalising results)

@@ -69,6 +69,27 @@ ZK_HD XYZZU<PR> xyzzu_double_affine(const FpU<PR>& x2, const FpU<PR>& y2) {
   return r;
 }
 
+// acc = 2 * acc   [dbl-2008-s-1]; infinity stays infinity.  Same domains / invariants as the mixed add.
+template <class PR>
+ZK_HD XYZZU<PR> xyzzu_double(const XYZZU<PR>& a) {
+  if (a.is_zero()) return a;
+  FpU<PR> u = u_dbl(a.y);                       // < 4p, limbs < 2^30
+  FpU<PR> v = u_mul(u, u);                      // < 1.1p
+  FpU<PR> w = u_mul(u, v);                      // < 1.03p
+  FpU<PR> s = u_mul(a.x, v);                    // X < 6p: < 1.04p
+  FpU<PR> xx = u_sqr(a.x);                      // < 1.22p
+  FpU<PR> m = u_carry(u_add(u_dbl(xx), xx));    // 3*xx < 3.7p, N
+  FpU<PR> mm = u_sqr(m);                        // < 1.09p
+  XYZZU<PR> r;
+  r.x = u_sub<4, 2>(mm, u_dbl(s));              // < 5.1p
+  FpU<PR> d = u_sub<8, 1>(s, r.x);              // < 9.1p
+  FpU<PR> ny = u_sub<2, 1>(FpU<PR>::zero(), a.y);
+  r.y = u_mul2(m, d, w, ny);                    // M*D - W*Y1 < 1.22p
+  r.zz = u_mul(v, a.zz);                        // 261 + 266 - 261 = 266 domain
+  r.zzz = u_mul(w, a.zzz);
+  return r;
+}
+
 // acc += (+/-)(x2, y2);  (x2, y2) != infinity, canonical memory-format coordinates.
 template <class PR>
 ZK_HD void xyzzu_add_mixed(XYZZU<PR>& acc, const Fp<PR>& x2s, const Fp<PR>& y2s, bool negate) {

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mi355zk_selftest_g1_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_g1_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "mi355zk_bn254_g2_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mi355zk_bn254_g1_add": (_i, [_vp, _vp]),
     "mi355zk_bn254_g2_add": (_i, [_vp, _vp]),
     "mi355zk_bn254_g1_to_affine": (_i, [_vp, _vp]),
