@@ -149,4 +149,105 @@ ZK_HD XYZZ<Fp<PR>> xyzzu_to_std(const XYZZU<PR>& a) {
   return r;
 }
 
+// =================================================================================================
+// G2: the same accumulator over Fq2 = Fq[u]/(u^2+1) with U-form components (Fq2U, fieldu.hpp).
+// An Fq2 product is two sums of two Fq products, each with ONE Montgomery reduction (u_mul2):
+//     (a0 + a1 u)(b0 + b1 u) = (a0 b0 + a1 (-b1)) + (a0 b1 + a1 b0) u          486 mads, like Karatsuba's 3 x 162,
+// but with no subtraction afterwards, so every component stays < 2p.  Domains and invariants are those of
+// the G1 accumulator, componentwise:  X < 6p, Y < 2p, ZZ < 2p, ZZZ < 2p, N-form.
+struct XYZZU2 {
+  Fq2U x, y, zz, zzz;
+  ZK_HD static XYZZU2 zero() { return XYZZU2{Fq2U::zero(), Fq2U::zero(), Fq2U::zero(), Fq2U::zero()}; }
+  ZK_HD bool is_zero() const { return zz.limbs_all_zero(); }
+};
+
+// a * b; K bounds value(b.c1) <= K p.  Components: c0 < (va0 vb0 + va1 K) c + 1, c1 < (va0 vb1 + va1 vb0) c + 1.
+template <int K>
+ZK_HD Fq2U f2u_mul(const Fq2U& a, const Fq2U& b) {
+  FqU nb1 = u_sub<K, 1>(FqU::zero(), b.c1);
+  return Fq2U{u_mul2(a.c0, b.c0, a.c1, nb1), u_mul2(a.c0, b.c1, a.c1, b.c0)};
+}
+template <int K>
+ZK_HD Fq2U f2u_sub(const Fq2U& a, const Fq2U& b) { return Fq2U{u_sub<K, 1>(a.c0, b.c0), u_sub<K, 1>(a.c1, b.c1)}; }
+
+ZK_HD Fq2U f2u_from_std(const Fq2& a) { return Fq2U{u_from_std(a.c0), u_from_std(a.c1)}; }
+
+// std XYZZ over Fq2 (every coordinate in the 2^256 domain) -> accumulator domains (rare paths only)
+ZK_HD XYZZU2 xyzzu2_from_std(const XYZZ<Fq2>& s) {
+  if (s.is_zero()) return XYZZU2::zero();
+  const FqU c266 = UPow2<FqParams, 266>::get();  // v*2^256 * 2^266 / 2^261 = v * 2^261
+  const FqU c271 = UPow2<FqParams, 271>::get();  // v*2^256 * 2^271 / 2^261 = v * 2^266
+  auto cv = [&](const Fq2& v, const FqU& c) { return Fq2U{u_mul(u_from_std(v.c0), c), u_mul(u_from_std(v.c1), c)}; };
+  return XYZZU2{cv(s.x, c266), cv(s.y, c266), cv(s.zz, c271), cv(s.zzz, c271)};
+}
+
+ZK_HD XYZZ<Fq2> xyzzu2_to_std(const XYZZU2& a) {
+  if (a.is_zero()) return XYZZ<Fq2>::zero();
+  const FqU c256 = UPow2<FqParams, 256>::get();
+  const FqU c251 = UPow2<FqParams, 251>::get();
+  auto cv = [&](const Fq2U& v, const FqU& c) { return Fq2{u_to_std_lt2p(u_mul(v.c0, c)), u_to_std_lt2p(u_mul(v.c1, c))}; };
+  return XYZZ<Fq2>{cv(a.x, c256), cv(a.y, c256), cv(a.zz, c251), cv(a.zzz, c251)};
+}
+
+// acc += (+/-)(x2, y2);  (x2, y2) != infinity, canonical memory-format coordinates.
+ZK_HD void xyzzu2_add_mixed(XYZZU2& acc, const Fq2& x2s, const Fq2& y2s, bool negate) {
+  const Fq2U x2 = f2u_from_std(x2s);                        // < p
+  Fq2U y2 = f2u_from_std(y2s);
+  {
+    FqU n0 = u_sub<1, 1>(FqU::zero(), y2.c0), n1 = u_sub<1, 1>(FqU::zero(), y2.c1);  // p - y, N
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      y2.c0.l[i] = negate ? n0.l[i] : y2.c0.l[i];
+      y2.c1.l[i] = negate ? n1.l[i] : y2.c1.l[i];
+    }
+  }
+  if (acc.is_zero()) {
+    const FqU C = UPow2<FqParams, 266>::get();
+    acc.x = Fq2U{u_mul(x2.c0, C), u_mul(x2.c1, C)};         // * 2^261, < 2p
+    acc.y = Fq2U{u_mul(y2.c0, C), u_mul(y2.c1, C)};
+    acc.zz = Fq2U{C, FqU::zero()};                          // (1, 0) * 2^266
+    acc.zzz = acc.zz;
+    return;
+  }
+  Fq2U u2 = f2u_mul<2>(x2, acc.zz);                         // (1*2 + 1*2) c + 1 < 1.03p
+  Fq2U s2 = f2u_mul<2>(y2, acc.zzz);                        // < 1.03p
+  Fq2U p = f2u_sub<8>(u2, acc.x);                           // X < 6p;  P < 10p
+  Fq2U r = f2u_sub<2>(s2, acc.y);                           // Y < 2p;  R < 4p
+  Fq2U pp;                                                  // P^2 = (P0^2 - P1^2) + 2 P0 P1 u
+  pp.c0 = u_mul2(p.c0, p.c0, p.c1, u_sub<16, 1>(FqU::zero(), p.c1));  // (100 + 10*16) c + 1 < 2.56p
+  pp.c1 = u_mul(u_dbl(p.c0), p.c1);                         // 200 c + 1 < 2.2p
+  Fq2U ppp = f2u_mul<4>(p, pp);                             // c0 < (25.6 + 40) c + 1 < 1.4p, c1 < (22 + 25.6) c + 1 < 1.29p
+  Fq2U q = f2u_mul<4>(acc.x, pp);                           // < 1.24p, < 1.17p
+  Fq2U rr;                                                  // R^2 = (R0 + R1)(R0 - R1) + 2 R0 R1 u
+  rr.c0 = u_mul(u_carry(u_add(r.c0, r.c1)), u_sub<4, 1>(r.c0, r.c1));  // 8 * 8 c + 1 < 1.39p
+  rr.c1 = u_mul(u_dbl(r.c0), r.c1);                         // 32 c + 1 < 1.2p
+  Fq2U x3, d;
+  x3.c0 = u_sub<4, 3>(rr.c0, u_add(ppp.c0, u_dbl(q.c0)));   // PPP + 2Q < 3.9p <= 4p, limbs < 3 * 2^29;  X3 < 5.4p
+  x3.c1 = u_sub<4, 3>(rr.c1, u_add(ppp.c1, u_dbl(q.c1)));
+  d = f2u_sub<8>(q, x3);                                    // < 9.3p
+  FqU ny0 = u_sub<2, 1>(FqU::zero(), acc.y.c0);             // 2p - Y0
+  FqU ny1 = u_sub<2, 1>(FqU::zero(), acc.y.c1);
+  FqU nd1 = u_sub<16, 1>(FqU::zero(), d.c1);                // 16p - D1
+  Fq2U y3;                                                  // R*D - Y1*PPP
+  y3.c0 = u_mul4(r.c0, d.c0, r.c1, nd1, ny0, ppp.c0, acc.y.c1, ppp.c1);  // (37 + 64 + 2.8 + 2.6) c + 1 < 1.65p
+  y3.c1 = u_mul4(r.c0, d.c1, r.c1, d.c0, ny0, ppp.c1, ny1, ppp.c0);      // (37 + 37 + 2.6 + 2.8) c + 1 < 1.48p
+  Fq2U zz3 = f2u_mul<4>(acc.zz, pp);                        // < 1.08p
+  Fq2U zzz3 = f2u_mul<2>(acc.zzz, ppp);                     // PPP1 < 1.29p <= 2p;  < 1.03p
+  if (u_is_zero_lt2p(zz3.c0) && u_is_zero_lt2p(zz3.c1)) {
+    // P == 0: same x.  Same point -> double (ec.rs:483-485); opposite -> infinity (ec.rs:487).  Rare: done on
+    // the saturated-limb formulas of curve.hpp and converted back.
+    if (u_is_zero_lt8p(r.c0) && u_is_zero_lt8p(r.c1)) {
+      Fq2 yy = negate ? neg(y2s) : y2s;
+      acc = xyzzu2_from_std(xyzz_double_affine(x2s, yy));
+    } else {
+      acc = XYZZU2::zero();
+    }
+    return;
+  }
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = zz3;
+  acc.zzz = zzz3;
+}
+
 }  // namespace zk

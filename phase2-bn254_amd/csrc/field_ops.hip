@@ -171,6 +171,32 @@ int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const u
   return ZK_OK;
 }
 
+// same for G2 (16 u64 per affine point; out = X, Y, ZZ, ZZZ over Fq2: 32 u64)
+int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const uint8_t* negate, size_t n, uint64_t out_xyzz[32]) {
+  if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
+  if (!out_xyzz) return ZK_ERR_BAD_ARGS;
+  zk::G2XYZZ r;
+  if (mode == 0) {
+    zk::G2XYZZ acc = zk::G2XYZZ::zero();
+    for (size_t i = 0; i < n; ++i) {
+      zk::G2Affine p;
+      std::memcpy(&p, affine_pts + 16 * i, 128);
+      zk::xyzz_add_mixed(acc, p.x, p.y, negate[i] != 0);
+    }
+    r = acc;
+  } else {
+    zk::XYZZU2 acc = zk::XYZZU2::zero();
+    for (size_t i = 0; i < n; ++i) {
+      zk::G2Affine p;
+      std::memcpy(&p, affine_pts + 16 * i, 128);
+      zk::xyzzu2_add_mixed(acc, p.x, p.y, negate[i] != 0);
+    }
+    r = zk::xyzzu2_to_std(acc);
+  }
+  std::memcpy(out_xyzz, &r, sizeof r);
+  return ZK_OK;
+}
+
 int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 0); }
 int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 1); }
 

@@ -296,6 +296,27 @@ ZK_HD FpU<PR> u_mul2(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const
   });
 }
 
+// (a*b + c*d + e*f + g*h) * 2^-261 mod p with ONE Montgomery reduction (Fq2 products of sums).
+//   preconditions: all eight operands N-form: 36 products < 2^58 plus the Montgomery terms < 2^63.6 per column;
+//   result: N-form, value < (sum of the four value products) / 2^261 + p.
+template <class PR>
+ZK_HD FpU<PR> u_mul4(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const FpU<PR>& d, const FpU<PR>& e, const FpU<PR>& f,
+                     const FpU<PR>& g, const FpU<PR>& h) {
+  return u_montgomery_columns<PR>([&](auto kc, uint64_t& acc) {
+    constexpr int k = decltype(kc)::value;
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) {
+        acc += (uint64_t)a.l[i] * b.l[j];
+        acc += (uint64_t)c.l[i] * d.l[j];
+        acc += (uint64_t)e.l[i] * f.l[j];
+        acc += (uint64_t)g.l[i] * h.l[j];
+      }
+    });
+  });
+}
+
 // value == 0 mod p for an N-form value < 2p  (i.e. value in {0, p})
 template <class PR>
 ZK_HD bool u_is_zero_lt2p(const FpU<PR>& a) {

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) msm_sizes_kernel(const uint32_t* __restri
   ids[b] = b;
 }
 
-constexpr uint32_t MSM_HEAVY_BLOCKS = 4096;  // at most this many buckets get a whole workgroup
+constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets get a whole workgroup (e.g. the short top window: few, long buckets)
 
 template <class F>
 __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
@@ -163,13 +163,13 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
     }
     return xyzzu_to_std(acc);
   } else {
-    XYZZ<F> acc = XYZZ<F>::zero();
+    XYZZU2 acc = XYZZU2::zero();
     for (; j < e; j += stride) {
       uint32_t v = vals[j];
       Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
-      xyzz_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+      xyzzu2_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
-    return acc;
+    return xyzzu2_to_std(acc);
   }
 }
 
@@ -199,9 +199,8 @@ __global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<
   if (threadIdx.x == 0) store_vec(buckets + b, sh[0]);
 }
 
-// 4b. one lane per bucket, buckets taken in size order.  G1 runs on U-form arithmetic (curveu.hpp: 29-bit
-//     lazy limbs, one v_mad_u64_u32 per partial product, no carry flags); G2 still uses the saturated-limb
-//     XYZZ of curve.hpp.
+// 4b. one lane per bucket, buckets taken in size order.  Both groups run on U-form arithmetic (curveu.hpp:
+//     29-bit lazy limbs, one v_mad_u64_u32 per partial product, no carry flags).
 template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,

@@ -154,3 +154,44 @@ def test_u_accumulation_long_chain_keeps_invariants(lib):
             pt[4:] = M.to_limbs((M.Q - y) % M.Q)
         acc = O.G1.add_mixed(acc, pt)
     assert M.g1_jac_from_raw(acc) == outs[1]
+
+
+def _xyzz2_to_affine(x):
+    c = [M.from_mont(M.from_limbs(x[4 * i:4 * i + 4]), M.Q) for i in range(8)]
+    X, Y, ZZ, ZZZ = (c[0], c[1]), (c[2], c[3]), (c[4], c[5]), (c[6], c[7])
+    if ZZ == (0, 0):
+        return None
+    return (M.f2_mul(X, M.f2_inv(ZZ)), M.f2_mul(Y, M.f2_inv(ZZZ)))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_g2_bucket_accumulation_on_host(lib, mode):
+    n = 24
+    raw = inputs.bases_cpu(2, n, seed=223)
+    pts = [M.g2_affine_from_raw(r) for r in raw]
+    seq = [(0, 0), (0, 0), (1, 0), (1, 1), (2, 1), (2, 0), (3, 0)]
+    seq += [(i, rnd.randrange(2)) for i in range(4, n)]
+    seq += [(5, 1), (5, 1), (5, 0), (5, 0)]
+    for prefix in (1, 2, 4, 6, 7, len(seq)):
+        sub = seq[:prefix]
+        arr = np.ascontiguousarray(np.stack([raw[i] for i, _ in sub]))
+        neg = np.array([s for _, s in sub], dtype=np.uint8)
+        out = np.zeros(32, np.uint64)
+        assert lib.mi355zk_selftest_g2_accumulate(mode, arr.ctypes.data, neg.ctypes.data, len(sub), out.ctypes.data) == 0
+        want = None
+        for i, s in sub:
+            want = M.ec_add(M.FQ2_OPS, want, M.ec_neg(M.FQ2_OPS, pts[i]) if s else pts[i])
+        assert _xyzz2_to_affine(out) == want, (mode, prefix)
+        assert all(M.from_limbs(out[4 * i:4 * i + 4]) < M.Q for i in range(8))
+
+
+def test_g2_u_accumulation_long_chain(lib):
+    n = 600
+    raw = inputs.bases_progression_cpu(2, n, seed=421)
+    neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
+    outs = []
+    for mode in (0, 1):
+        out = np.zeros(32, np.uint64)
+        assert lib.mi355zk_selftest_g2_accumulate(mode, raw.ctypes.data, neg.ctypes.data, n, out.ctypes.data) == 0
+        outs.append(_xyzz2_to_affine(out))
+    assert outs[0] == outs[1] and outs[0] is not None
