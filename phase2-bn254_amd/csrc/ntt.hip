@@ -369,6 +369,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       // columns: G adjacent low positions share a tile
       uint64_t G = NTT_TILE_ELEMS / np;
       if (G > S[p]) G = S[p];
+      while (G > 1 && n / (np * G) < 256) G >>= 1;  // small transforms: prefer >= 256 tiles (one per CU) over wide tiles
       P.g = (uint32_t)G;
       P.in_xs = P.out_xs = S[p];
       P.in_gs = P.out_gs = 1;
@@ -384,6 +385,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       uint64_t N1 = 1ull << b[0];
       uint64_t G = NTT_TILE_ELEMS / np;
       if (G > N1) G = N1;
+      while (G > 1 && n / (np * G) < 256) G >>= 1;
       P.g = (uint32_t)G;
       P.in_xs = 1;
       P.in_gs = S[0];
