@@ -158,7 +158,7 @@ int mi355zk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
 int mi355zk_sync(void *stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg.
- * names: "msm_digits" "msm_sort" "msm_accumulate" "msm_reduce" "ntt_pass" "ntt_scale" */
+ * names: "msm_digits" "msm_sort" "msm_accumulate_heavy" "msm_accumulate" "msm_reduce" "ntt_pass" "ntt_scale" */
 void mi355zk_prof_enable(int on);
 void mi355zk_prof_reset(void);
 int mi355zk_prof_get(const char *kernel, double *total_ms, long *count);

@@ -424,7 +424,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     return 0;
   };
   static const int slot_digits = prof_slot("msm_digits"), slot_sort = prof_slot("msm_sort"),
-                   slot_acc = prof_slot("msm_accumulate"), slot_red = prof_slot("msm_reduce");
+                   slot_acc = prof_slot("msm_accumulate"), slot_heavy = prof_slot("msm_accumulate_heavy"),
+                   slot_red = prof_slot("msm_reduce");
 
   prof_begin(slot_digits, st);
   hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_bases, n, base_offset,
@@ -443,15 +444,17 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   prof_end(slot_sort, st);
   if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
 
-  prof_begin(slot_acc, st);
   {
     // a bucket is "heavy" when it is far longer than the mean: it then gets a workgroup instead of a lane
     uint64_t mean = n / G.nb + 1;
     uint32_t heavy = (uint32_t)(mean * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean * 8 + 1024);
     uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
+    prof_begin(slot_heavy, st);
     hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, d_bases, vals_b, first, last, order,
                        heavy, buckets);
     ZK_HIP(hipGetLastError());
+    prof_end(slot_heavy, st);
+    prof_begin(slot_acc, st);
     hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, d_bases, vals_b, first, last, order, heavy,
                        n_buckets, buckets);
     ZK_HIP(hipGetLastError());
