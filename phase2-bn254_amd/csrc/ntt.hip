@@ -27,6 +27,7 @@
 
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "fieldu.hpp"
@@ -261,8 +262,10 @@ struct ScratchBuf {
   void* p = nullptr;
   size_t bytes = 0;
 };
-std::map<int, ScratchBuf> g_scratch;  // per device; guarded by g_run_mu
-std::mutex g_run_mu;                  // serialises NTT calls that share the scratch buffer
+// one scratch array per (device, stream): calls on one stream are ordered by the stream itself, calls on
+// different streams must not share a buffer.  Guarded by g_run_mu (held only while launching).
+std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
+std::mutex g_run_mu;
 
 std::once_flag g_cfg_once;
 int g_cfg_rc = 0;
@@ -292,7 +295,7 @@ void ntt_release_all() {
   g_tables.clear();
   std::lock_guard<std::mutex> lk2(g_run_mu);
   for (auto& kv : g_scratch) {
-    (void)hipSetDevice(kv.first);
+    (void)hipSetDevice(kv.first.first);
     (void)hipFree(kv.second.p);
   }
   g_scratch.clear();
@@ -334,9 +337,12 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   if (R > 1) {
     int dev = 0;
     ZK_HIP(hipGetDevice(&dev));
-    ScratchBuf& sb = g_scratch[dev];
+    ScratchBuf& sb = g_scratch[std::make_pair(dev, st)];
     if (sb.bytes < n * sizeof(Fr)) {
-      if (sb.p) ZK_HIP(hipFree(sb.p));
+      if (sb.p) {
+        ZK_HIP(hipStreamSynchronize(st));  // earlier passes on this stream may still read the old buffer
+        ZK_HIP(hipFree(sb.p));
+      }
       sb.p = nullptr;
       sb.bytes = 0;
       ZK_HIP(hipMalloc(&sb.p, n * sizeof(Fr)));

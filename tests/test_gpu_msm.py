@@ -188,3 +188,40 @@ def test_batch_exp_matches_oracle(zk, worker, group, same_scalar):
     for i in range(n):
         want = G.to_affine(G.mul(G.from_affine(bases[i]), ks[i]))
         assert np.array_equal(got[i], want), i
+
+
+def test_concurrent_calls_from_several_host_threads(zk, worker):
+    """The prover queues 8 multiexps before the first wait() (prover.rs:250-298): the entry points must be
+    re-entrant.  4 host threads run G1 / G2 multiexps and domain ops at the same time; every result is checked."""
+    import threading
+
+    jobs = []
+    for t in range(4):
+        n = 700 + 100 * t
+        g = 1 + (t & 1)
+        bases = inputs.bases_progression_cpu(g, n, seed=500 + t)
+        scalars = inputs.random_scalars(n, seed=600 + t)
+        G = O.G1 if g == 1 else O.G2
+        rc, want = G.multiexp(bases, scalars, threads=2)
+        a = inputs.random_fr_mont(1 << (10 + t), seed=700 + t)
+        jobs.append((G, bases, scalars, G.to_affine(want), a, O.fr_domain_op(a, 10 + t, "icoset_fft").reshape(-1, 4)))
+    errors = []
+
+    def run(job):
+        G, bases, scalars, want, a, want_fft = job
+        try:
+            for _ in range(3):
+                got = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+                assert np.array_equal(G.to_affine(got), want)
+                dom = zk.EvaluationDomain.from_coeffs(a)
+                dom.icoset_fft(worker)
+                assert np.array_equal(dom.into_coeffs(), want_fft)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
