@@ -273,6 +273,35 @@ __global__ void __launch_bounds__(128) msm_sum_kernel(const XYZZ<F>* __restrict_
   if (threadIdx.x == 0) store_vec(out + (uint64_t)w * gridDim.x + blk, sh[0]);
 }
 
+// 5c. final stage: the serial depth of the running-sum levels (2L additions each) is what a small multiexp
+//     waits for, so once at most MSM_FINAL_MAX elements per window are left the weighted sum is finished by
+//     BIT DECOMPOSITION instead:  sum_x (x+off) F[x] = sum_j 2^j * (sum over x with bit j of (x+off) set of F[x]),
+//     one workgroup per (bit, window) doing a strided partial sum and an LDS tree (depth <= 8 + 8 additions for all
+//     bits at once); the host applies the powers of two.
+constexpr uint32_t MSM_FINAL_MAX = 4096;
+template <class F>
+__global__ void __launch_bounds__(256) msm_bitsum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t off,
+                                                        XYZZ<F>* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t j = blockIdx.x, w = blockIdx.y;
+  const XYZZ<F>* P = in + (uint64_t)w * count;
+  XYZZ<F> acc = XYZZ<F>::zero();
+  for (uint32_t x = threadIdx.x; x < count; x += blockDim.x)
+    if (((x + off) >> j) & 1) xyzz_add(acc, load_vec(P + x));
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      XYZZ<F> a = sh[threadIdx.x];
+      xyzz_add(a, sh[threadIdx.x + s]);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_vec(out + (uint64_t)w * gridDim.x + j, sh[0]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 
@@ -350,17 +379,22 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   const uint64_t m = n * G.W;
   if (m > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
   const uint32_t n_buckets = G.W * G.nb;
-  // reduction levels (see msm_reduce_level_kernel): cnt_0 = nb, cnt_{i+1} = ceil(cnt_i / L)
+  // reduction: running-sum levels (msm_reduce_level_kernel, chunk length L) while more than MSM_FINAL_MAX
+  // elements per window are left, then the bit-decomposition stage (msm_bitsum_kernel)
   const uint32_t L = 8, LOG_L = 3;
   uint32_t lvl_cnt[16], lvl_chunks[16], n_levels = 0;
-  uint64_t total_chunks = 0;
-  for (uint32_t cnt = G.nb;; cnt = lvl_chunks[n_levels - 1]) {
-    lvl_cnt[n_levels] = cnt;
-    lvl_chunks[n_levels] = (cnt + L - 1) / L;
+  uint64_t total_chunks = 1;
+  uint32_t final_cnt = G.nb;
+  while (final_cnt > MSM_FINAL_MAX) {
+    lvl_cnt[n_levels] = final_cnt;
+    lvl_chunks[n_levels] = (final_cnt + L - 1) / L;
     total_chunks += lvl_chunks[n_levels];
+    final_cnt = lvl_chunks[n_levels];
     ++n_levels;
-    if (lvl_chunks[n_levels - 1] == 1) break;
   }
+  const uint32_t final_off = n_levels == 0 ? 1u : 0u;  // bucket x of a window has weight x + 1; chunk sums have weight ch
+  uint32_t final_bits = 1;
+  while ((1u << final_bits) <= final_cnt - 1 + final_off) ++final_bits;
 
   int key_bits = 1;
   while ((1ull << key_bits) <= G.invalid) ++key_bits;
@@ -383,9 +417,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
   size_t o_partA = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
   size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
-  size_t o_wsums = take((size_t)G.W * n_levels * sizeof(XYZZ<F>));
+  const uint32_t n_out = n_levels + final_bits;  // per window: one A-sum per level, then one sum per bit
+  size_t o_wsums = take((size_t)G.W * n_out * sizeof(XYZZ<F>));
   const uint32_t SUM_PER_BLOCK = 1024;  // 128 lanes x 8 elements
-  size_t o_sumtmp = take((size_t)G.W * ((lvl_chunks[0] + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK + 1) * 2 * sizeof(XYZZ<F>));
+  const uint32_t sum_half = (n_levels ? (lvl_chunks[0] + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK : 0) + 1;
+  size_t o_sumtmp = take((size_t)G.W * sum_half * 2 * sizeof(XYZZ<F>));
   size_t o_err = take(8);
   size_t o_sort = take(sort_tmp_bytes);
 
@@ -476,7 +512,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       {  // wsums[lv][w] = sum_ch A[w][ch], by repeated blocked sums
         const XYZZ<F>* src = A;
         uint32_t cnt = lvl_chunks[lv];
-        uint32_t half = (lvl_chunks[0] + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK + 1;
+        const uint32_t half = sum_half;
         int flip = 0;
         for (;;) {
           uint32_t nblk = (cnt + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK;
@@ -492,24 +528,33 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       in = S;
       o += lvl_chunks[lv];
     }
+    // bit sums of the last array: wsums[n_levels * W + w * final_bits + j]
+    hipLaunchKernelGGL(msm_bitsum_kernel<F>, dim3(final_bits, G.W), dim3(256), 256 * sizeof(XYZZ<F>), st, in, final_cnt, final_off,
+                       wsums + (uint64_t)n_levels * G.W);
+    ZK_HIP(hipGetLastError());
   }
   prof_end(slot_red, st);
   if (checkpoint("reduce")) return ZK_ERR_DEVICE;
 
-  std::vector<XYZZ<F>> h_wsums((size_t)G.W * n_levels);
+  std::vector<XYZZ<F>> h_wsums((size_t)G.W * n_out);
   unsigned long long h_err = 0;
-  ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_levels * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
   ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
   ZK_HIP(hipStreamSynchronize(st));
   if (h_err != ~0ull) {
     *err_index_out = (long long)h_err;
     return ZK_ERR_UNEXPECTED_IDENTITY;
   }
-  // window sum T_w = A_0 + L*(A_1 + L*(A_2 + ...)), then the join of the windows, most significant
-  // first: c doublings + add per window (multiexp.rs:146-154)
+  // window sum T_w = A_0 + L*(A_1 + ... + L*(sum_j 2^j Bits_j)), then the join of the windows, most
+  // significant first: c doublings + add per window (multiexp.rs:146-154)
   auto window_sum = [&](uint32_t w) {
-    Jacobian<F> t = xyzz_to_jacobian(h_wsums[(size_t)(n_levels - 1) * G.W + w]);
-    for (int lv = (int)n_levels - 2; lv >= 0; --lv) {
+    const XYZZ<F>* bits = h_wsums.data() + (size_t)n_levels * G.W + (size_t)w * final_bits;
+    Jacobian<F> t = xyzz_to_jacobian(bits[final_bits - 1]);
+    for (int j = (int)final_bits - 2; j >= 0; --j) {
+      jac_double(t);
+      jac_add(t, xyzz_to_jacobian(bits[j]));
+    }
+    for (int lv = (int)n_levels - 1; lv >= 0; --lv) {
       for (uint32_t k = 0; k < LOG_L; ++k) jac_double(t);
       jac_add(t, xyzz_to_jacobian(h_wsums[(size_t)lv * G.W + w]));
     }
