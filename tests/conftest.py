@@ -9,6 +9,21 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _ensure_built():
+    """The HIP library and the oracle are git-ignored build products: build them when a fresh checkout runs the
+    tests before __graft_entry__.build() (hipcc cross-compiles gfx950 without a GPU; cold build ~4 min)."""
+    import subprocess
+
+    so = os.path.join(ROOT, "phase2-bn254_amd", "libmi355zk.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not (os.path.exists(so) and os.path.exists(orc)):
+        subprocess.check_call(["make", "-C", ROOT, "-j", str(min(8, os.cpu_count() or 1))], stdout=subprocess.DEVNULL)
+
+
+def pytest_sessionstart(session):
+    _ensure_built()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
