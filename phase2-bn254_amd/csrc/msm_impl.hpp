@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) msm_sizes_kernel(const uint32_t* __restri
   ids[b] = b;
 }
 
-constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets get a whole workgroup (e.g. the short top window: few, long buckets)
+constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take the segment-parallel path (the rest of a pathological input runs one lane per bucket)
 
 template <class F>
 __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
@@ -173,19 +173,63 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
   }
 }
 
-// 4a. heavy buckets (longer than `heavy`): one workgroup per bucket, 256 strided partial sums + LDS tree.
-//     Keeps a skewed scalar distribution (many equal scalars -> one huge bucket per window) from
-//     serialising on a single lane.
+// 4a. heavy buckets (longer than `heavy`: skewed scalars such as the many 0/1 witnesses of a Groth16 prover --
+//     every scalar equal to 1 lands in bucket 1 of window 0 -- and the short top window).  A heavy bucket is cut
+//     into segments of MSM_HEAVY_SEG entries; every segment is one workgroup (256 strided partial sums + an
+//     LDS tree) and a second kernel adds the segment sums of each bucket, so even a bucket holding a third
+//     of all points is spread over thousands of workgroups.  Because `order` is sorted by size, the heavy
+//     buckets are order[0..H): msm_heavy_plan_kernel scans ceil(size / SEG) over that prefix.
+constexpr uint32_t MSM_HEAVY_SEG = 8192;
+
+__global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __restrict__ sizes_sorted, uint32_t hb, uint32_t heavy,
+                                                             uint32_t* __restrict__ item_off /* hb + 1 */) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (hb + 1023) / 1024;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < hb ? lo + per : hb;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    uint32_t sz = sizes_sorted[i];
+    sum += sz > heavy ? (sz + MSM_HEAVY_SEG - 1) / MSM_HEAVY_SEG : 0;
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < 1024; ++t) {
+      uint32_t v = part[t];
+      part[t] = run;
+      run += v;
+    }
+    item_off[hb] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t i = lo; i < hi; ++i) {
+    item_off[i] = run;
+    uint32_t sz = sizes_sorted[i];
+    run += sz > heavy ? (sz + MSM_HEAVY_SEG - 1) / MSM_HEAVY_SEG : 0;
+  }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                                   const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                                  const uint32_t* __restrict__ order, uint32_t heavy,
-                                                                  XYZZ<F>* __restrict__ buckets) {
+                                                                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_off,
+                                                                  uint32_t hb, XYZZ<F>* __restrict__ seg_sums) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const uint32_t b = order[blockIdx.x];
-  const uint32_t j0 = first[b], e = last[b];
-  if (e - j0 <= heavy) return;  // uniform per workgroup
+  const uint32_t item = blockIdx.x;
+  if (item >= item_off[hb]) return;  // the grid is an upper bound on the number of segments
+  // bucket of this segment: last i with item_off[i] <= item
+  uint32_t lo = 0, hi = hb;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (item_off[mid] <= item) lo = mid;
+    else hi = mid;
+  }
+  const uint32_t b = order[lo];
+  const uint32_t j0 = first[b] + (item - item_off[lo]) * MSM_HEAVY_SEG;
+  const uint32_t e = j0 + MSM_HEAVY_SEG < last[b] ? j0 + MSM_HEAVY_SEG : last[b];
   sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x);
   __syncthreads();
   for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
@@ -196,7 +240,31 @@ __global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_vec(buckets + b, sh[0]);
+  if (threadIdx.x == 0) store_vec(seg_sums + item, sh[0]);
+}
+
+// bucket = sum of its segment sums (one workgroup per heavy bucket)
+template <class F>
+__global__ void __launch_bounds__(256) msm_heavy_combine_kernel(const XYZZ<F>* __restrict__ seg_sums, const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ item_off, XYZZ<F>* __restrict__ buckets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t i = blockIdx.x;
+  const uint32_t lo = item_off[i], hi = item_off[i + 1];
+  if (hi == lo) return;  // not heavy
+  XYZZ<F> acc = XYZZ<F>::zero();
+  for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) xyzz_add(acc, load_vec(seg_sums + k));
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      XYZZ<F> a = sh[threadIdx.x];
+      xyzz_add(a, sh[threadIdx.x + s]);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_vec(buckets + order[i], sh[0]);
 }
 
 // 4b. one lane per bucket, buckets taken in size order.  Both groups run on U-form arithmetic (curveu.hpp:
@@ -204,13 +272,13 @@ __global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<
 template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                            const uint32_t* __restrict__ order, uint32_t heavy, uint32_t n_buckets,
+                                                            const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
                                                             XYZZ<F>* __restrict__ buckets) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_buckets) return;
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
-  if (i < MSM_HEAVY_BLOCKS && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
+  if (i < hb && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
   store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1));
 }
 
@@ -414,6 +482,14 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4);
   size_t o_sizes_a = take((size_t)n_buckets * 4), o_sizes_b = take((size_t)n_buckets * 4);
   size_t o_ids_a = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
+  // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
+  const uint64_t mean_len = n / G.nb + 1;
+  const uint32_t heavy = (uint32_t)(mean_len * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean_len * 8 + 1024);
+  uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
+  if ((uint64_t)hb > m / heavy + 1) hb = (uint32_t)(m / heavy + 1);
+  const uint32_t max_items = (uint32_t)(m / MSM_HEAVY_SEG) + hb;  // every heavy bucket adds at most one partial segment
+  size_t o_item_off = take((size_t)(hb + 1) * 4);
+  size_t o_seg_sums = take((size_t)max_items * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
   size_t o_partA = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
   size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
@@ -440,6 +516,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t* sizes_b = (uint32_t*)(ws + o_sizes_b);
   uint32_t* ids_a = (uint32_t*)(ws + o_ids_a);
   uint32_t* order = (uint32_t*)(ws + o_ids_b);
+  uint32_t* item_off = (uint32_t*)(ws + o_item_off);
+  XYZZ<F>* seg_sums = (XYZZ<F>*)(ws + o_seg_sums);
   XYZZ<F>* buckets = (XYZZ<F>*)(ws + o_buckets);
   XYZZ<F>* partA = (XYZZ<F>*)(ws + o_partA);
   XYZZ<F>* partS = (XYZZ<F>*)(ws + o_partS);
@@ -481,18 +559,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
 
   {
-    // a bucket is "heavy" when it is far longer than the mean: it then gets a workgroup instead of a lane
-    uint64_t mean = n / G.nb + 1;
-    uint32_t heavy = (uint32_t)(mean * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean * 8 + 1024);
-    uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
     prof_begin(slot_heavy, st);
-    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, d_bases, vals_b, first, last, order,
-                       heavy, buckets);
+    hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(max_items), dim3(256), 256 * sizeof(XYZZ<F>), st, d_bases, vals_b, first, last,
+                       order, item_off, hb, seg_sums);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, buckets);
     ZK_HIP(hipGetLastError());
     prof_end(slot_heavy, st);
     prof_begin(slot_acc, st);
     hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, d_bases, vals_b, first, last, order, heavy,
-                       n_buckets, buckets);
+                       hb, n_buckets, buckets);
     ZK_HIP(hipGetLastError());
   }
   prof_end(slot_acc, st);

@@ -225,3 +225,26 @@ def test_concurrent_calls_from_several_host_threads(zk, worker):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_prover_like_scalars_many_zeros_and_ones(zk, worker):
+    """Groth16 witnesses are full of 0 and 1: every 1 lands in bucket 1 of window 0 (one huge bucket).  The
+    segment-parallel heavy-bucket path must give the oracle's answer (and not serialise on one lane)."""
+    import time
+
+    n = 1 << 17
+    bases = inputs.bases_progression_cpu(1, n, seed=801)
+    scalars = inputs.random_scalars(n, seed=802)
+    rng = np.random.default_rng(803)
+    kind = rng.integers(0, 10, size=n)
+    scalars[kind < 4] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    scalars[(kind >= 4) & (kind < 7)] = 0
+    scalars[kind == 7] = np.array([2, 0, 0, 0], dtype=np.uint64)
+    rc, want = O.G1.multiexp(bases, scalars, threads=8)
+    assert rc == 0
+    zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    t = time.perf_counter()
+    got = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    dt = time.perf_counter() - t
+    assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+    assert dt < 0.5, f"skewed multiexp took {dt * 1e3:.1f} ms (host-buffer entry point incl. H2D)"
