@@ -92,6 +92,16 @@ int mi355zk_bn254_g2_msm_dev(const void *d_bases, size_t n_bases, size_t base_of
                              const void *d_scalars, size_t n_scalars,
                              const uint32_t *density, size_t density_bits,
                              void *stream, uint64_t out_xyz[24]);
+/* ---- verification multiexps of the ceremony code, device-resident inputs:
+ * dense_multiexp (powersoftau/src/utils.rs:189-292): sum_i exp_i * base_i with bases.len() == exponents.len();
+ * infinity bases add nothing and there are no Source errors.
+ * merge_pairs (powersoftau/src/utils.rs:112-128; phase2/src/utils.rs:59-105; power_pairs = merge_pairs(v[0..n-1], v[1..])):
+ * s = sum rho_i * v1_i and sx = sum rho_i * v2_i for ONE scalar vector rho -- digit extraction and sorts are
+ * shared between the two sums.  rho are canonical FrRepr like every exponent of this ABI. */
+int mi355zk_bn254_g1_dense_multiexp_dev(const void *d_bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xyz[12]);
+int mi355zk_bn254_g2_dense_multiexp_dev(const void *d_bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xyz[24]);
+int mi355zk_bn254_g1_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[12], uint64_t out_sx[12]);
+int mi355zk_bn254_g2_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[24], uint64_t out_sx[24]);
 /* exponent index at which the last failing multiexp of this thread raised its error, or -1 */
 long long mi355zk_last_error_index(void);
 /* window size c and window count the library would use for n scalars (diagnostics / DESIGN.md) */

@@ -25,6 +25,8 @@ int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, c
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index);
 int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index);
+int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
+int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 void msm_release_g1();
 void msm_release_g2();
 void msm_geometry(uint64_t n, uint32_t* c, uint32_t* W);
@@ -393,6 +395,24 @@ int mi355zk_bn254_g1_msm_dev(const void* d_bases, size_t n_bases, size_t base_of
 int mi355zk_bn254_g2_msm_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                              const uint32_t* density, size_t density_bits, void* stream, uint64_t out_xyz[24]) {
   return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+}
+int mi355zk_bn254_g1_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
+  if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  return msm_g1_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
+}
+int mi355zk_bn254_g2_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[24]) {
+  if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  return msm_g2_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
+}
+int mi355zk_bn254_g1_merge_pairs_dev(const void* d_v1, const void* d_v2, const void* d_rho, size_t n, void* stream, uint64_t out_s[12],
+                                     uint64_t out_sx[12]) {
+  if (!out_s || !out_sx || (n && (!d_v1 || !d_v2 || !d_rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  return msm_g1_dense_device(d_v1, d_v2, d_rho, n, (hipStream_t)stream, out_s, out_sx);
+}
+int mi355zk_bn254_g2_merge_pairs_dev(const void* d_v1, const void* d_v2, const void* d_rho, size_t n, void* stream, uint64_t out_s[24],
+                                     uint64_t out_sx[24]) {
+  if (!out_s || !out_sx || (n && (!d_v1 || !d_v2 || !d_rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  return msm_g2_dense_device(d_v1, d_v2, d_rho, n, (hipStream_t)stream, out_s, out_sx);
 }
 long long mi355zk_last_error_index(void) { return t_last_err_index; }
 int mi355zk_msm_window_bits(size_t n_scalars, int* n_windows) {

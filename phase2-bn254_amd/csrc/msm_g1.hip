@@ -17,6 +17,22 @@ void msm_geometry(uint64_t n, uint32_t* c, uint32_t* W) {
   *W = G.W;
 }
 
+// powersoftau::utils::dense_multiexp (powersoftau/src/utils.rs:189-292): bases.len() == exponents.len(), infinity
+// bases add nothing; with d_bases2 the merge_pairs form (utils.rs:112-128, phase2/src/utils.rs:59-105): both
+// base vectors against ONE exponent vector, sharing digit extraction and sorts.
+int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz,
+                         uint64_t* out2_xyz) {
+  G1Jacobian r, r2;
+  long long err = -1;
+  int rc = msm_device<Fq>((const G1Affine*)d_bases, n, 0, (const uint32_t*)d_scalars, n, nullptr, nullptr, st, &r, &err, true,
+                          (const G1Affine*)d_bases2, d_bases2 ? &r2 : nullptr);
+  if (rc == ZK_OK) {
+    std::memcpy(out_xyz, &r, sizeof r);
+    if (d_bases2 && out2_xyz) std::memcpy(out2_xyz, &r2, sizeof r2);
+  }
+  return rc;
+}
+
 void msm_release_g1() { ws_release_all(); }
 
 }  // namespace zk

@@ -86,7 +86,8 @@ template <class F>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, const Affine<F>* __restrict__ bases,
                                                         uint64_t n, uint64_t base_offset, const uint32_t* __restrict__ density,
                                                         const uint32_t* __restrict__ dprefix, MsmGeom G, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, unsigned long long* __restrict__ err_index) {
+                                                        uint32_t* __restrict__ vals, unsigned long long* __restrict__ err_index,
+                                                        int check_identity) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool active = true;
@@ -106,7 +107,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
     return;
   }
   // a selected base with a non-zero exponent must not be the identity (source.rs:50-52)
-  if (load_affine(bases + bi).is_zero()) atomicMin(err_index, (unsigned long long)i);
+  // (dense_multiexp of powersoftau/src/utils.rs:189-292 has no such check: there infinity bases simply add nothing)
+  if (check_identity && load_affine(bases + bi).is_zero()) atomicMin(err_index, (unsigned long long)i);
   uint32_t carry = 0;
   const uint32_t mask = (1u << G.c) - 1u;
   for (uint32_t w = 0; w < G.W; ++w) {
@@ -153,12 +155,13 @@ constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take 
 
 template <class F>
 __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
-                                                  uint32_t stride) {
+                                                  uint32_t stride, bool skip_zero) {
   if constexpr (std::is_same<F, Fq>::value) {
     XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
     for (; j < e; j += stride) {
       uint32_t v = vals[j];
       Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
+      if (skip_zero && p.y.is_zero()) continue;  // dense mode: the all-zero record (no curve point has y == 0) adds nothing
       xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
     return xyzzu_to_std(acc);
@@ -167,6 +170,7 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
     for (; j < e; j += stride) {
       uint32_t v = vals[j];
       Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
+      if (skip_zero && p.y.is_zero()) continue;
       xyzzu2_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
     return xyzzu2_to_std(acc);
@@ -215,7 +219,7 @@ template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                                   const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_off,
-                                                                  uint32_t hb, XYZZ<F>* __restrict__ seg_sums) {
+                                                                  uint32_t hb, XYZZ<F>* __restrict__ seg_sums, int skip_zero) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t item = blockIdx.x;
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<
   const uint32_t b = order[lo];
   const uint32_t j0 = first[b] + (item - item_off[lo]) * MSM_HEAVY_SEG;
   const uint32_t e = j0 + MSM_HEAVY_SEG < last[b] ? j0 + MSM_HEAVY_SEG : last[b];
-  sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x);
+  sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0);
   __syncthreads();
   for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
@@ -273,13 +277,13 @@ template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                             const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
-                                                            XYZZ<F>* __restrict__ buckets) {
+                                                            XYZZ<F>* __restrict__ buckets, int skip_zero) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_buckets) return;
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
   if (i < hb && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
-  store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1));
+  store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1, skip_zero != 0));
 }
 
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
@@ -436,8 +440,13 @@ MsmGeom choose_geom(uint64_t n, int group) {
 
 template <class F>
 int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n,
-               const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out) {
+               const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out,
+               bool dense = false, const Affine<F>* d_bases2 = nullptr, Jacobian<F>* out2 = nullptr) {
+  // dense == true: powersoftau's dense_multiexp contract (infinity bases add nothing, no Source errors);
+  // d_bases2 != nullptr: a second base vector evaluated with the SAME exponents (merge_pairs), sharing the
+  // digit extraction and the sorts.
   *out = Jacobian<F>::zero();
+  if (out2) *out2 = Jacobian<F>::zero();
   *err_index_out = -1;
   if (n == 0) return ZK_OK;
   if (n_bases > 0x7fffffffull || n > 0x7fffffffull) return ZK_ERR_BAD_ARGS;
@@ -543,7 +552,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   prof_begin(slot_digits, st);
   hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_bases, n, base_offset,
-                     d_density, d_dprefix, G, keys_a, vals_a, d_err);
+                     d_density, d_dprefix, G, keys_a, vals_a, d_err, dense ? 0 : 1);
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
   if (checkpoint("digits")) return ZK_ERR_DEVICE;
@@ -558,92 +567,98 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   prof_end(slot_sort, st);
   if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
 
-  {
-    prof_begin(slot_heavy, st);
-    hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(max_items), dim3(256), 256 * sizeof(XYZZ<F>), st, d_bases, vals_b, first, last,
-                       order, item_off, hb, seg_sums);
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, buckets);
-    ZK_HIP(hipGetLastError());
-    prof_end(slot_heavy, st);
-    prof_begin(slot_acc, st);
-    hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, d_bases, vals_b, first, last, order, heavy,
-                       hb, n_buckets, buckets);
-    ZK_HIP(hipGetLastError());
-  }
-  prof_end(slot_acc, st);
-  if (checkpoint("accumulate")) return ZK_ERR_DEVICE;
-
-  prof_begin(slot_red, st);
-  {
-    const XYZZ<F>* in = buckets;
-    uint64_t o = 0;
-    for (uint32_t lv = 0; lv < n_levels; ++lv) {
-      uint32_t threads = lvl_chunks[lv] * G.W;
-      XYZZ<F>* A = partA + o * G.W;
-      XYZZ<F>* S = partS + o * G.W;
-      hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], L, lv == 0 ? 1u : 0u,
-                         G.W, A, S);
+  auto run_set = [&](const Affine<F>* bases_set, Jacobian<F>* result) -> int {
+    {
+      prof_begin(slot_heavy, st);
+      hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
       ZK_HIP(hipGetLastError());
-      {  // wsums[lv][w] = sum_ch A[w][ch], by repeated blocked sums
-        const XYZZ<F>* src = A;
-        uint32_t cnt = lvl_chunks[lv];
-        const uint32_t half = sum_half;
-        int flip = 0;
-        for (;;) {
-          uint32_t nblk = (cnt + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK;
-          XYZZ<F>* dst = nblk == 1 ? wsums + (uint64_t)lv * G.W : sumtmp + (uint64_t)flip * half * G.W;
-          hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(nblk, G.W), dim3(128), 128 * sizeof(XYZZ<F>), st, src, cnt, SUM_PER_BLOCK, dst);
-          ZK_HIP(hipGetLastError());
-          if (nblk == 1) break;
-          src = dst;
-          cnt = nblk;
-          flip ^= 1;
-        }
-      }
-      in = S;
-      o += lvl_chunks[lv];
+      hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(max_items), dim3(256), 256 * sizeof(XYZZ<F>), st, bases_set, vals_b, first, last,
+                         order, item_off, hb, seg_sums, dense ? 1 : 0);
+      ZK_HIP(hipGetLastError());
+      hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, buckets);
+      ZK_HIP(hipGetLastError());
+      prof_end(slot_heavy, st);
+      prof_begin(slot_acc, st);
+      hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order, heavy,
+                         hb, n_buckets, buckets, dense ? 1 : 0);
+      ZK_HIP(hipGetLastError());
     }
-    // bit sums of the last array: wsums[n_levels * W + w * final_bits + j]
-    hipLaunchKernelGGL(msm_bitsum_kernel<F>, dim3(final_bits, G.W), dim3(256), 256 * sizeof(XYZZ<F>), st, in, final_cnt, final_off,
-                       wsums + (uint64_t)n_levels * G.W);
-    ZK_HIP(hipGetLastError());
-  }
-  prof_end(slot_red, st);
-  if (checkpoint("reduce")) return ZK_ERR_DEVICE;
+    prof_end(slot_acc, st);
+    if (checkpoint("accumulate")) return (int)ZK_ERR_DEVICE;
 
-  std::vector<XYZZ<F>> h_wsums((size_t)G.W * n_out);
-  unsigned long long h_err = 0;
-  ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-  ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
-  ZK_HIP(hipStreamSynchronize(st));
-  if (h_err != ~0ull) {
-    *err_index_out = (long long)h_err;
-    return ZK_ERR_UNEXPECTED_IDENTITY;
-  }
-  // window sum T_w = A_0 + L*(A_1 + ... + L*(sum_j 2^j Bits_j)), then the join of the windows, most
-  // significant first: c doublings + add per window (multiexp.rs:146-154)
-  auto window_sum = [&](uint32_t w) {
-    const XYZZ<F>* bits = h_wsums.data() + (size_t)n_levels * G.W + (size_t)w * final_bits;
-    Jacobian<F> t = xyzz_to_jacobian(bits[final_bits - 1]);
-    for (int j = (int)final_bits - 2; j >= 0; --j) {
-      jac_double(t);
-      jac_add(t, xyzz_to_jacobian(bits[j]));
+    prof_begin(slot_red, st);
+    {
+      const XYZZ<F>* in = buckets;
+      uint64_t o = 0;
+      for (uint32_t lv = 0; lv < n_levels; ++lv) {
+        uint32_t threads = lvl_chunks[lv] * G.W;
+        XYZZ<F>* A = partA + o * G.W;
+        XYZZ<F>* S = partS + o * G.W;
+        hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], L, lv == 0 ? 1u : 0u,
+                           G.W, A, S);
+        ZK_HIP(hipGetLastError());
+        {  // wsums[lv][w] = sum_ch A[w][ch], by repeated blocked sums
+          const XYZZ<F>* src = A;
+          uint32_t cnt = lvl_chunks[lv];
+          const uint32_t half = sum_half;
+          int flip = 0;
+          for (;;) {
+            uint32_t nblk = (cnt + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK;
+            XYZZ<F>* dst = nblk == 1 ? wsums + (uint64_t)lv * G.W : sumtmp + (uint64_t)flip * half * G.W;
+            hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(nblk, G.W), dim3(128), 128 * sizeof(XYZZ<F>), st, src, cnt, SUM_PER_BLOCK, dst);
+            ZK_HIP(hipGetLastError());
+            if (nblk == 1) break;
+            src = dst;
+            cnt = nblk;
+            flip ^= 1;
+          }
+        }
+        in = S;
+        o += lvl_chunks[lv];
+      }
+      // bit sums of the last array: wsums[n_levels * W + w * final_bits + j]
+      hipLaunchKernelGGL(msm_bitsum_kernel<F>, dim3(final_bits, G.W), dim3(256), 256 * sizeof(XYZZ<F>), st, in, final_cnt, final_off,
+                         wsums + (uint64_t)n_levels * G.W);
+      ZK_HIP(hipGetLastError());
     }
-    for (int lv = (int)n_levels - 1; lv >= 0; --lv) {
-      for (uint32_t k = 0; k < LOG_L; ++k) jac_double(t);
-      jac_add(t, xyzz_to_jacobian(h_wsums[(size_t)lv * G.W + w]));
+    prof_end(slot_red, st);
+    if (checkpoint("reduce")) return (int)ZK_ERR_DEVICE;
+
+    std::vector<XYZZ<F>> h_wsums((size_t)G.W * n_out);
+    unsigned long long h_err = 0;
+    ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (h_err != ~0ull) {
+      *err_index_out = (long long)h_err;
+      return ZK_ERR_UNEXPECTED_IDENTITY;
     }
-    return t;
+    // window sum T_w = A_0 + L*(A_1 + ... + L*(sum_j 2^j Bits_j)), then the join of the windows, most
+    // significant first: c doublings + add per window (multiexp.rs:146-154)
+    auto window_sum = [&](uint32_t w) {
+      const XYZZ<F>* bits = h_wsums.data() + (size_t)n_levels * G.W + (size_t)w * final_bits;
+      Jacobian<F> t = xyzz_to_jacobian(bits[final_bits - 1]);
+      for (int j = (int)final_bits - 2; j >= 0; --j) {
+        jac_double(t);
+        jac_add(t, xyzz_to_jacobian(bits[j]));
+      }
+      for (int lv = (int)n_levels - 1; lv >= 0; --lv) {
+        for (uint32_t k = 0; k < LOG_L; ++k) jac_double(t);
+        jac_add(t, xyzz_to_jacobian(h_wsums[(size_t)lv * G.W + w]));
+      }
+      return t;
+    };
+    Jacobian<F> acc = window_sum(G.W - 1);
+    for (int w = (int)G.W - 2; w >= 0; --w) {
+      for (uint32_t k = 0; k < G.c; ++k) jac_double(acc);
+      jac_add(acc, window_sum((uint32_t)w));
+    }
+    *result = acc;
+    return (int)ZK_OK;
   };
-  Jacobian<F> acc = window_sum(G.W - 1);
-  for (int w = (int)G.W - 2; w >= 0; --w) {
-    for (uint32_t k = 0; k < G.c; ++k) jac_double(acc);
-    jac_add(acc, window_sum((uint32_t)w));
-  }
-  *out = acc;
+  int rc_set = run_set(d_bases, out);
+  if (rc_set != ZK_OK) return rc_set;
+  if (d_bases2 != nullptr && out2 != nullptr) return run_set(d_bases2, out2);
   return ZK_OK;
 }
 

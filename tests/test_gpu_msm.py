@@ -248,3 +248,39 @@ def test_prover_like_scalars_many_zeros_and_ones(zk, worker):
     dt = time.perf_counter() - t
     assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
     assert dt < 0.5, f"skewed multiexp took {dt * 1e3:.1f} ms (host-buffer entry point incl. H2D)"
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_merge_pairs_and_dense_multiexp(zk, worker, group):
+    """powersoftau / phase2 verification.  power_pairs(v) = merge_pairs(v[0..n-1], v[1..]) with one
+    random scalar vector; infinity entries add nothing (dense_multiexp has no identity check).  Both sums must equal the
+    oracle's per-vector multiexp, bit exact after normalisation."""
+    import torch
+
+    G = O.G1 if group == 1 else O.G2
+    n = 3000 if group == 1 else 400
+    v = inputs.bases_progression_cpu(group, n + 1, seed=950 + group)
+    v[17] = 0  # an infinity entry: allowed here
+    rho = inputs.random_scalars(n, seed=951)
+    rho[5] = 0
+    d_v = torch.from_numpy(v.view(np.int64)).cuda()
+    d_rho = torch.from_numpy(rho.view(np.int64)).cuda()
+    L = zk.lib.load()
+    s, sx = np.zeros(12 * group, np.uint64), np.zeros(12 * group, np.uint64)
+    fn = L.mi355zk_bn254_g1_merge_pairs_dev if group == 1 else L.mi355zk_bn254_g2_merge_pairs_dev
+    rec = 64 * group
+    assert fn(C.c_void_p(d_v.data_ptr()), C.c_void_p(d_v.data_ptr() + rec), C.c_void_p(d_rho.data_ptr()), n, None,
+              s.ctypes.data_as(C.c_void_p), sx.ctypes.data_as(C.c_void_p)) == 0
+    # oracle: zero scalar where the base is infinity (dense semantics), then the bellman multiexp restatement
+    def ref(bases):
+        sc = rho.copy()
+        sc[~bases.any(axis=1)] = 0
+        rc, out = G.multiexp(bases, sc, threads=4)
+        assert rc == 0
+        return G.to_affine(out)
+    assert np.array_equal(G.to_affine(s), ref(v[:n]))
+    assert np.array_equal(G.to_affine(sx), ref(v[1:n + 1]))
+    one = np.zeros(12 * group, np.uint64)
+    fn1 = L.mi355zk_bn254_g1_dense_multiexp_dev if group == 1 else L.mi355zk_bn254_g2_dense_multiexp_dev
+    assert fn1(C.c_void_p(d_v.data_ptr()), C.c_void_p(d_rho.data_ptr()), n, None, one.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(G.to_affine(one), ref(v[:n]))
