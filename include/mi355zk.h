@@ -140,6 +140,13 @@ int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9
 int mi355zk_selftest_g1_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[16]);
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[32]);
 
+/* ---- FFT over curve points: EvaluationDomain<Point<G1>>::fft / ifft (bellman/src/group.rs:22-51
+ * under domain.rs:154-173), the Lagrange-basis conversion of powersoftau/src/bin/prepare_phase2.rs:68-131.  In
+ * place on 2^log_n AFFINE raw records (64 B, all-zero = infinity); the output is normalised to affine, i.e. what
+ * `batch_normalization` + `into_affine` leave (ec.rs:251-299, 596-629).  inverse != 0: omega^-1 and the 1/m scaling.
+ * Synchronises `stream` before returning. */
+int mi355zk_bn254_g1_point_fft_dev(void *d_points_affine, uint32_t log_n, int inverse, void *stream);
+
 /* ---- batch fixed-base scalar multiplication out[i] = k[i] * P, affine (all-zero = infinity).
  * Building block of the per-point `batch_exp` path (powersoftau/src/batched_accumulator.rs:1130-1181,
  * SURVEY 8f row 1); used here to synthesise tau-table-like bases on the device. */

@@ -167,33 +167,24 @@ static inline void dfe_inv(dfe_t *r, const dfe_t *a) { dfe_pow(r, a, DUMMY_P - 2
 #undef M_SCALAR_LIMBS
 #undef M_NUM_BITS
 
+#define FFT_UNDEF_ALL
 #define TNAME(x) dfft_##x
 #define T_FE dfe_t
-#define T_ONE(p) (*(p) = 1)
+#define S_FE dfe_t
+#define S_ONE(p) (*(p) = 1)
 #define T_ZERO(p) (*(p) = 0)
 #define T_ADD(r, a, b) (*(r) = (*(a) + *(b)) % DUMMY_P)
 #define T_SUB(r, a, b) (*(r) = ((DUMMY_P + *(a)) - *(b)) % DUMMY_P)
-#define T_MUL(r, a, b) (*(r) = (dfe_t)((uint64_t)*(a) * *(b) % DUMMY_P))
-#define T_INV(r, a) dfe_inv(r, a)
-#define T_POW64(r, a, e) dfe_pow(r, a, e)
-#define T_ROOT_OF_UNITY(p) (*(p) = 57751)   /* dummy_engine.rs:292-294 */
-#define T_GENERATOR(p) (*(p) = 5)           /* dummy_engine.rs:288-290 */
-#define T_FROM_U64(p, v) (*(p) = (dfe_t)((v) % DUMMY_P))
-#define T_S 10                              /* dummy_engine.rs:258 */
+#define S_MUL(r, a, b) (*(r) = (dfe_t)((uint64_t)*(a) * *(b) % DUMMY_P))
+#define T_MULS(r, a, b) S_MUL(r, a, b)
+#define S_INV(r, a) dfe_inv(r, a)
+#define S_POW64(r, a, e) dfe_pow(r, a, e)
+#define S_ROOT_OF_UNITY(p) (*(p) = 57751)   /* dummy_engine.rs:292-294 */
+#define S_GENERATOR(p) (*(p) = 5)           /* dummy_engine.rs:288-290 */
+#define S_FROM_U64(p, v) (*(p) = (dfe_t)((v) % DUMMY_P))
+#define S_S 10                              /* dummy_engine.rs:258 */
 #include "tmpl_fft.h"
-#undef TNAME
-#undef T_FE
-#undef T_ONE
-#undef T_ZERO
-#undef T_ADD
-#undef T_SUB
-#undef T_MUL
-#undef T_INV
-#undef T_POW64
-#undef T_ROOT_OF_UNITY
-#undef T_GENERATOR
-#undef T_FROM_U64
-#undef T_S
+#include "tmpl_fft_undef.h"
 
 /* ------------------------------------------------------------------ BN254 Fr FFT */
 static inline void fr_pow64(fe_t *r, const fe_t *a, uint64_t e) { fe_pow(&FR, r, a, &e, 1); }
@@ -211,19 +202,59 @@ static inline void fr_root_of_unity(fe_t *r) {
 static inline void fr_generator(fe_t *r) { uint64_t seven[4] = {7, 0, 0, 0}; fe_from_canonical(&FR, r, seven); }
 static inline void fr_from_u64(fe_t *r, uint64_t v) { uint64_t c[4] = {v, 0, 0, 0}; fe_from_canonical(&FR, r, c); }
 
+/* scalar field of every BN254 instantiation */
+#define S_FE fe_t
+#define S_ONE(p) fe_one(&FR, p)
+#define S_MUL(r, a, b) fe_mul(&FR, r, a, b)
+#define S_INV(r, a) fe_inv(&FR, r, a)
+#define S_POW64(r, a, e) fr_pow64(r, a, e)
+#define S_ROOT_OF_UNITY(p) fr_root_of_unity(p)
+#define S_GENERATOR(p) fr_generator(p)
+#define S_FROM_U64(p, v) fr_from_u64(p, v)
+#define S_S 28
+
+/* Scalar<Bn256> elements (group.rs:53-82) */
 #define TNAME(x) frfft_##x
 #define T_FE fe_t
-#define T_ONE(p) fe_one(&FR, p)
 #define T_ZERO(p) fe_zero(p)
 #define T_ADD(r, a, b) fe_add(&FR, r, a, b)
 #define T_SUB(r, a, b) fe_sub(&FR, r, a, b)
-#define T_MUL(r, a, b) fe_mul(&FR, r, a, b)
-#define T_INV(r, a) fe_inv(&FR, r, a)
-#define T_POW64(r, a, e) fr_pow64(r, a, e)
-#define T_ROOT_OF_UNITY(p) fr_root_of_unity(p)
-#define T_GENERATOR(p) fr_generator(p)
-#define T_FROM_U64(p, v) fr_from_u64(p, v)
-#define T_S 28
+#define T_MULS(r, a, b) fe_mul(&FR, r, a, b)
+#include "tmpl_fft.h"
+#undef TNAME
+#undef T_FE
+#undef T_ZERO
+#undef T_ADD
+#undef T_SUB
+#undef T_MULS
+
+/* Point<G1> / Point<G2> elements (group.rs:22-51): group_mul_assign(by) = self.0.mul_assign(by.into_repr()) */
+static inline void g1pt_muls(g1_jac_t *r, const g1_jac_t *a, const fe_t *s) { uint64_t k[4]; fe_to_canonical(&FR, k, s); g1_jac_t t = *a; g1_mul(&t, k); *r = t; }
+static inline void g1pt_add(g1_jac_t *r, const g1_jac_t *a, const g1_jac_t *b) { g1_jac_t t = *a; g1_add(&t, b); *r = t; }
+static inline void g1pt_sub(g1_jac_t *r, const g1_jac_t *a, const g1_jac_t *b) { g1_jac_t t = *a, nb = *b; g1_negate(&nb); g1_add(&t, &nb); *r = t; }
+#define TNAME(x) g1fft_##x
+#define T_FE g1_jac_t
+#define T_ZERO(p) g1_set_zero(p)
+#define T_ADD(r, a, b) g1pt_add(r, a, b)
+#define T_SUB(r, a, b) g1pt_sub(r, a, b)
+#define T_MULS(r, a, b) g1pt_muls(r, a, b)
+#include "tmpl_fft.h"
+#undef TNAME
+#undef T_FE
+#undef T_ZERO
+#undef T_ADD
+#undef T_SUB
+#undef T_MULS
+
+static inline void g2pt_muls(g2_jac_t *r, const g2_jac_t *a, const fe_t *s) { uint64_t k[4]; fe_to_canonical(&FR, k, s); g2_jac_t t = *a; g2_mul(&t, k); *r = t; }
+static inline void g2pt_add(g2_jac_t *r, const g2_jac_t *a, const g2_jac_t *b) { g2_jac_t t = *a; g2_add(&t, b); *r = t; }
+static inline void g2pt_sub(g2_jac_t *r, const g2_jac_t *a, const g2_jac_t *b) { g2_jac_t t = *a, nb = *b; g2_negate(&nb); g2_add(&t, &nb); *r = t; }
+#define TNAME(x) g2fft_##x
+#define T_FE g2_jac_t
+#define T_ZERO(p) g2_set_zero(p)
+#define T_ADD(r, a, b) g2pt_add(r, a, b)
+#define T_SUB(r, a, b) g2pt_sub(r, a, b)
+#define T_MULS(r, a, b) g2pt_muls(r, a, b)
 #include "tmpl_fft.h"
 
 /* ================================================================== exported C API (ctypes) */
@@ -364,6 +395,26 @@ EXPORT int oracle_dummy_domain_op(uint32_t *a, uint32_t log_n, int op, uint32_t 
     case 3: dfft_icoset_fft(a, &d, log_cpus); break;
     default: return -2;
   }
+  return 0;
+}
+/* EvaluationDomain<Point<G>> ops on Jacobian points, then batch_normalization (what prepare_phase2.rs:102-131 does
+ * before it writes the Lagrange-basis points): pts = 2^log_n x (12 | 24) u64, result normalised (z = one or infinity). */
+EXPORT int oracle_g1_point_domain_op(uint64_t *pts, uint32_t log_n, int op, uint32_t log_cpus) {
+  g1fft_domain_t d;
+  if (g1fft_domain_init(&d, log_n)) return -1;
+  if (op == 0) g1fft_fft((g1_jac_t *)pts, &d, log_cpus);
+  else if (op == 1) g1fft_ifft((g1_jac_t *)pts, &d, log_cpus);
+  else return -2;
+  g1_batch_normalization((g1_jac_t *)pts, (size_t)1 << log_n);
+  return 0;
+}
+EXPORT int oracle_g2_point_domain_op(uint64_t *pts, uint32_t log_n, int op, uint32_t log_cpus) {
+  g2fft_domain_t d;
+  if (g2fft_domain_init(&d, log_n)) return -1;
+  if (op == 0) g2fft_fft((g2_jac_t *)pts, &d, log_cpus);
+  else if (op == 1) g2fft_ifft((g2_jac_t *)pts, &d, log_cpus);
+  else return -2;
+  g2_batch_normalization((g2_jac_t *)pts, (size_t)1 << log_n);
   return 0;
 }
 EXPORT uint32_t oracle_dummy_domain_omega(uint32_t log_n) { dfft_domain_t d; if (dfft_domain_init(&d, log_n)) return 0; return d.omega; }

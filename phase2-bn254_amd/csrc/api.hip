@@ -27,6 +27,8 @@ int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, c
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index);
 int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
+// point_fft.hip
+int point_fft_g1(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
 void msm_release_g1();
 void msm_release_g2();
 void msm_geometry(uint64_t n, uint32_t* c, uint32_t* W);
@@ -453,6 +455,15 @@ int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_
   if (geninv) std::memcpy(geninv, &D.geninv, 32);
   if (minv) std::memcpy(minv, &D.minv, 32);
   return ZK_OK;
+}
+
+// EvaluationDomain<Point<G1>>::{fft, ifft} on affine records (group.rs:22-51, domain.rs:154-173; prepare_phase2.rs:68-131)
+int mi355zk_bn254_g1_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {
+  if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
+  DomainConsts D;
+  int rc = domain_consts(log_n, &D);
+  if (rc) return rc;
+  return point_fft_g1(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
 }
 
 int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[8], const void* d_scalars, size_t n, void* stream) {

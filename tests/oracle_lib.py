@@ -16,7 +16,7 @@ _SO = os.path.join(_ROOT, "oracle", "_build", "liboracle.so")
 
 
 def build_oracle(force: bool = False) -> str:
-    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("bn254_oracle.c", "field.h", "tmpl_curve.h", "tmpl_multiexp.h", "tmpl_fft.h")]
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("bn254_oracle.c", "field.h", "tmpl_curve.h", "tmpl_multiexp.h", "tmpl_fft.h", "tmpl_fft_undef.h")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
@@ -228,6 +228,19 @@ class Group:
 
 G1 = Group(1)
 G2 = Group(2)
+
+
+def point_domain_op(group: int, affine_pts, log_n: int, op: str, log_cpus: int = 31):
+    """EvaluationDomain<Point<G>>::{fft, ifft} then batch_normalization (prepare_phase2.rs:68-131):
+    (2^log_n, 8g) affine raw records in -> affine raw records out."""
+    G = G1 if group == 1 else G2
+    affine_pts = _arr(affine_pts).reshape(-1, G.aff)
+    jac = np.ascontiguousarray(np.stack([G.from_affine(p) for p in affine_pts]))
+    fn = lib().oracle_g1_point_domain_op if group == 1 else lib().oracle_g2_point_domain_op
+    rc = fn(_p64(jac), C.c_uint32(log_n), C.c_int(OPS[op]), C.c_uint32(log_cpus))
+    if rc:
+        raise ValueError(f"oracle point_domain_op rc={rc}")
+    return np.stack([G.to_affine(p) for p in jac.reshape(-1, G.jac)])
 
 
 def multiexp_window_bits(n):

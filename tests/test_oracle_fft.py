@@ -56,3 +56,28 @@ def test_polynomial_arith():
             back = O.fr_domain_op(prod, log_n, "ifft").reshape(-1, 4)
             got = [M.from_mont(M.from_limbs(r), M.R_ORDER) for r in back]
             assert got[: la + lb] == naive and not any(got[la + lb:])
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_point_fft_oracle_against_model(group):
+    """EvaluationDomain<Point<G>> (group.rs:22-51): the oracle's point FFT is the scalar FFT 'in the exponent'.
+    For v_i = a_i * G:  fft(v)_k = (sum_i a_i w^(ik)) * G, checked with the independent model's DFT; and
+    ifft(fft(v)) == v; parallel_fft shape == serial (domain.rs:465-496)."""
+    import random
+    rnd = random.Random(11 + group)
+    G = O.G1 if group == 1 else O.G2
+    F, gen = (M.FQ_OPS, M.G1_GEN) if group == 1 else (M.FQ2_OPS, M.G2_GEN)
+    gen_raw = inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW
+    to_raw = M.g1_affine_to_raw if group == 1 else M.g2_affine_to_raw
+    log_n = 3
+    n = 1 << log_n
+    a = [rnd.randrange(M.R_ORDER) for _ in range(n)]
+    a[2] = 0
+    pts = G.mul_many_affine(gen_raw, np.array([M.to_limbs(v) for v in a], dtype=np.uint64))
+    got = O.point_domain_op(group, pts, log_n, "fft")
+    want = M.dft(a, M.domain_omega(log_n))
+    for k in range(n):
+        assert list(got[k]) == to_raw(M.ec_mul(F, gen, want[k])), k
+    back = O.point_domain_op(group, got, log_n, "ifft")
+    assert np.array_equal(back, pts)
+    assert np.array_equal(O.point_domain_op(group, pts, log_n, "fft", log_cpus=1), got)

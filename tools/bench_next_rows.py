@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Measurements for the SURVEY 8(f) "next" rows that are built: batch_exp (row 1) and merge_pairs (row 2)."""
+import argparse, ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import phase2_bn254_amd as zk, inputs, bench
+
+ap = argparse.ArgumentParser(); ap.add_argument("--log-n", type=int, default=20); ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+L = zk.lib.load(); w = zk.Worker(0); dev = torch.device("cuda", 0)
+n = 1 << a.log_n
+out = {"log_n": a.log_n}
+for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
+    k = bench.gen_scalars(n + 1, 31 + g, dev)
+    bases = torch.empty((n + 1, limbs), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(gen)
+    mul = L.mi355zk_bn254_g1_batch_mul_dev if g == 1 else L.mi355zk_bn254_g2_batch_mul_dev
+    assert mul(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n + 1, None) == 0
+    torch.cuda.synchronize()
+    sc = bench.gen_scalars(n, 41 + g, dev)
+    res = torch.empty((n, limbs), dtype=torch.int64, device=dev)
+    bexp = L.mi355zk_bn254_g1_batch_exp_dev if g == 1 else L.mi355zk_bn254_g2_batch_exp_dev
+    for same in (0, 1):
+        bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same, None); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(a.iters): bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same, None)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / a.iters
+        out[f"g{g}_batch_exp_{'same_scalar' if same else 'per_point'}"] = {"ms": round(dt * 1e3, 3), "Mpoint_per_s": round(n / dt / 1e6, 2)}
+    mp = L.mi355zk_bn254_g1_merge_pairs_dev if g == 1 else L.mi355zk_bn254_g2_merge_pairs_dev
+    s, sx = np.zeros(12 * g, np.uint64), np.zeros(12 * g, np.uint64)
+    args = (C.c_void_p(bases.data_ptr()), C.c_void_p(bases.data_ptr() + 64 * g), C.c_void_p(sc.data_ptr()), n, None, s.ctypes.data_as(C.c_void_p), sx.ctypes.data_as(C.c_void_p))
+    assert mp(*args) == 0
+    t = time.perf_counter()
+    for _ in range(a.iters): mp(*args)
+    dt = (time.perf_counter() - t) / a.iters
+    out[f"g{g}_power_pairs"] = {"ms": round(dt * 1e3, 3), "Mscalar_mul_per_s_both_sums": round(2 * n / dt / 1e6, 2)}
+print(json.dumps(out))
