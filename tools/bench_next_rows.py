@@ -35,4 +35,18 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     for _ in range(a.iters): mp(*args)
     dt = (time.perf_counter() - t) / a.iters
     out[f"g{g}_power_pairs"] = {"ms": round(dt * 1e3, 3), "Mscalar_mul_per_s_both_sums": round(2 * n / dt / 1e6, 2)}
+# row 4: point FFT (prepare_phase2's Lagrange-basis conversion)
+for ln in (12, 16, a.log_n):
+    m = 1 << ln
+    k = bench.gen_scalars(m, 51, dev)
+    pts = torch.empty((m, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    assert L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(pts.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), m, None) == 0
+    torch.cuda.synchronize()
+    ref = pts.clone()
+    t = time.perf_counter()
+    assert L.mi355zk_bn254_g1_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 1, None) == 0
+    dt = time.perf_counter() - t
+    assert L.mi355zk_bn254_g1_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 0, None) == 0
+    out[f"g1_point_ifft_2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mbutterfly_per_s": round(m / 2 * ln / dt / 1e6, 2), "fft_of_ifft_is_identity": bool(torch.equal(pts, ref))}
 print(json.dumps(out))
