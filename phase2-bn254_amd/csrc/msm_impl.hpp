@@ -43,11 +43,18 @@ namespace {  // one copy per translation unit (msm_g1.hip / msm_g2.hip): compile
 
 constexpr uint32_t SIGN_BIT = 0x80000000u;
 
+// Window layout.  The 254 scalar bits are split into W windows of (nearly) EQUAL width instead of W-1 full
+// c-bit windows and a short remainder: a short top window would put its n digits into very few buckets
+// (2^26 points, c = 20: 16383 buckets of 4096 entries against 128 everywhere else).  Windows 0..W-2 use signed
+// digits (d in [-2^(width-1), 2^(width-1)], width <= c); the TOP window is at most c-1 bits wide and keeps its
+// digits unsigned (value + carry <= 2^(c-1) = nb), which is also what absorbs the final carry.
 struct MsmGeom {
-  uint32_t c;        // window bits
+  uint32_t c;        // widest window, bits
   uint32_t W;        // windows
-  uint32_t nb;       // buckets per window = 2^(c-1)
+  uint32_t nb;       // bucket slots per window = 2^(c-1) (narrower windows leave their upper slots empty)
   uint32_t invalid;  // key of "no contribution" = W * nb
+  uint8_t width[64]; // bits of window w (c >= 4: at most 64 windows)
+  uint8_t shift[64]; // first bit of window w
 };
 
 template <class F>
@@ -110,16 +117,15 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   // (dense_multiexp of powersoftau/src/utils.rs:189-292 has no such check: there infinity bases simply add nothing)
   if (check_identity && load_affine(bases + bi).is_zero()) atomicMin(err_index, (unsigned long long)i);
   uint32_t carry = 0;
-  const uint32_t mask = (1u << G.c) - 1u;
   for (uint32_t w = 0; w < G.W; ++w) {
-    uint32_t bit = w * G.c;
+    const uint32_t width = G.width[w], bit = G.shift[w];
     uint32_t limb = bit >> 5, off = bit & 31;
     uint64_t two = limb < 8 ? ((uint64_t)s[limb] | ((uint64_t)s[limb + 1] << 32)) : 0ull;
-    uint32_t d = ((uint32_t)(two >> off) & mask) + carry;
+    uint32_t d = ((uint32_t)(two >> off) & ((1u << width) - 1u)) + carry;
     uint32_t neg = 0;
     carry = 0;
-    if (d > G.nb) {  // d in (2^(c-1), 2^c]  ->  d - 2^c in (-2^(c-1), 0]
-      d = (1u << G.c) - d;
+    if (w + 1 < G.W && d > (1u << (width - 1))) {  // d in (2^(width-1), 2^width]  ->  d - 2^width in (-2^(width-1), 0]
+      d = (1u << width) - d;
       neg = (d != 0) ? SIGN_BIT : 0;
       carry = 1;
     }
@@ -179,11 +185,12 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
 
 // 4a. heavy buckets (longer than `heavy`: skewed scalars such as the many 0/1 witnesses of a Groth16 prover --
 //     every scalar equal to 1 lands in bucket 1 of window 0 -- and the short top window).  A heavy bucket is cut
-//     into segments of MSM_HEAVY_SEG entries; every segment is one workgroup (256 strided partial sums + an
+//     into segments of MSM_HEAVY_SEG entries; every segment is one wave (64 strided partial sums + an
 //     LDS tree) and a second kernel adds the segment sums of each bucket, so even a bucket holding a third
 //     of all points is spread over thousands of workgroups.  Because `order` is sorted by size, the heavy
 //     buckets are order[0..H): msm_heavy_plan_kernel scans ceil(size / SEG) over that prefix.
-constexpr uint32_t MSM_HEAVY_SEG = 8192;
+constexpr uint32_t MSM_HEAVY_SEG = 4096;    // entries per segment
+constexpr uint32_t MSM_HEAVY_LANES = 64;   // one wave per segment: 64 strided partial sums of <= 64 points, then a 6-level tree
 
 __global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __restrict__ sizes_sorted, uint32_t hb, uint32_t heavy,
                                                              uint32_t* __restrict__ item_off /* hb + 1 */) {
@@ -216,59 +223,65 @@ __global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
+__global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                                   const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_off,
                                                                   uint32_t hb, XYZZ<F>* __restrict__ seg_sums, int skip_zero) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const uint32_t item = blockIdx.x;
-  if (item >= item_off[hb]) return;  // the grid is an upper bound on the number of segments
-  // bucket of this segment: last i with item_off[i] <= item
-  uint32_t lo = 0, hi = hb;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (item_off[mid] <= item) lo = mid;
-    else hi = mid;
-  }
-  const uint32_t b = order[lo];
-  const uint32_t j0 = first[b] + (item - item_off[lo]) * MSM_HEAVY_SEG;
-  const uint32_t e = j0 + MSM_HEAVY_SEG < last[b] ? j0 + MSM_HEAVY_SEG : last[b];
-  sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0);
-  __syncthreads();
-  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      XYZZ<F> a = sh[threadIdx.x];
-      xyzz_add(a, sh[threadIdx.x + s]);
-      sh[threadIdx.x] = a;
+  const uint32_t total = item_off[hb];
+  // a fixed-size grid strides over the segments: dispatching one (mostly empty) workgroup per POSSIBLE segment
+  // costs milliseconds at 2^26 points
+  for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+    // bucket of this segment: last i with item_off[i] <= item
+    uint32_t lo = 0, hi = hb;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (item_off[mid] <= item) lo = mid;
+      else hi = mid;
     }
+    const uint32_t b = order[lo];
+    const uint32_t j0 = first[b] + (item - item_off[lo]) * MSM_HEAVY_SEG;
+    const uint32_t e = j0 + MSM_HEAVY_SEG < last[b] ? j0 + MSM_HEAVY_SEG : last[b];
+    sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0);
+    __syncthreads();
+    for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        XYZZ<F> a = sh[threadIdx.x];
+        xyzz_add(a, sh[threadIdx.x + s]);
+        sh[threadIdx.x] = a;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) store_vec(seg_sums + item, sh[0]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_vec(seg_sums + item, sh[0]);
 }
 
 // bucket = sum of its segment sums (one workgroup per heavy bucket)
 template <class F>
-__global__ void __launch_bounds__(256) msm_heavy_combine_kernel(const XYZZ<F>* __restrict__ seg_sums, const uint32_t* __restrict__ order,
-                                                               const uint32_t* __restrict__ item_off, XYZZ<F>* __restrict__ buckets) {
+__global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __restrict__ seg_sums, const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ item_off, uint32_t hb, XYZZ<F>* __restrict__ buckets) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const uint32_t i = blockIdx.x;
-  const uint32_t lo = item_off[i], hi = item_off[i + 1];
-  if (hi == lo) return;  // not heavy
-  XYZZ<F> acc = XYZZ<F>::zero();
-  for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) xyzz_add(acc, load_vec(seg_sums + k));
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      XYZZ<F> a = sh[threadIdx.x];
-      xyzz_add(a, sh[threadIdx.x + s]);
-      sh[threadIdx.x] = a;
+  for (uint32_t i = blockIdx.x; i < hb; i += gridDim.x) {
+    const uint32_t lo = item_off[i], hi = item_off[i + 1];
+    if (hi == lo) continue;  // not heavy (uniform per workgroup)
+    XYZZ<F> acc = XYZZ<F>::zero();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) xyzz_add(acc, load_vec(seg_sums + k));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        XYZZ<F> a = sh[threadIdx.x];
+        xyzz_add(a, sh[threadIdx.x + s]);
+        sh[threadIdx.x] = a;
+      }
+      __syncthreads();
     }
+    if (threadIdx.x == 0) store_vec(buckets + order[i], sh[0]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_vec(buckets + order[i], sh[0]);
 }
 
 // 4b. one lane per bucket, buckets taken in size order.  Both groups run on U-form arithmetic (curveu.hpp:
@@ -412,12 +425,36 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // one-thread-per-window scan.  Here every bucket of every window is a lane, so c trades
 // W*n mixed adds (10 mul each) against W*2^(c-1) buckets to reduce (~35 mul each) while keeping
 // enough buckets to fill 256 CUs.  Override: env MI355ZK_MSM_C.
+// widths for a maximum window size c: top window c-1 bits (unsigned), the rest as even as possible, all <= c
+MsmGeom make_geom(uint32_t c) {
+  MsmGeom G{};
+  G.c = c;
+  uint32_t W = 1;
+  while ((W - 1) * c + (c - 1) < 254) ++W;      // smallest W with (W-1) windows of <= c bits + a top window of <= c-1 bits
+  G.W = W;
+  G.nb = 1u << (c - 1);
+  G.invalid = W * G.nb;
+  uint32_t top = c - 1;
+  if (W == 1) top = 254 < top ? 254 : top;
+  uint32_t rest = 254 > top ? 254 - top : 0;    // bits for windows 0..W-2
+  uint32_t base = W > 1 ? rest / (W - 1) : 0, rem = W > 1 ? rest % (W - 1) : 0;
+  uint32_t bit = 0;
+  for (uint32_t w = 0; w + 1 < W; ++w) {
+    G.width[w] = (uint8_t)(base + (w < rem ? 1 : 0));
+    G.shift[w] = (uint8_t)bit;
+    bit += G.width[w];
+  }
+  G.width[W - 1] = (uint8_t)(254 - bit);        // == top when rest was spread exactly (always: base*(W-1)+rem == rest)
+  G.shift[W - 1] = (uint8_t)bit;
+  return G;
+}
+
 MsmGeom choose_geom(uint64_t n, int group) {
   static const char* env = std::getenv("MI355ZK_MSM_C");
   uint32_t best_c = 0;
   double best = 1e300;
   for (uint32_t c = 4; c <= 24; ++c) {
-    double W = std::ceil(254.0 / c) + ((254 % c) == 0 ? 1 : 0);
+    double W = std::ceil((254.0 + 1.0) / c);  // (W-1)*c + (c-1) >= 254
     double nbk = std::ldexp(1.0, (int)c - 1);
     double cost = W * (10.0 * (double)n + 40.0 * nbk);
     // occupancy term: fewer than ~2^17 bucket lanes leaves CUs idle during accumulation
@@ -430,12 +467,7 @@ MsmGeom choose_geom(uint64_t n, int group) {
     int v = std::atoi(env);
     if (v >= 2 && v <= 24) best_c = (uint32_t)v;
   }
-  MsmGeom G;
-  G.c = best_c;
-  G.W = (254 + best_c - 1) / best_c + ((254 % best_c) == 0 ? 1 : 0);
-  G.nb = 1u << (best_c - 1);
-  G.invalid = G.W * G.nb;
-  return G;
+  return make_geom(best_c);
 }
 
 template <class F>
@@ -572,10 +604,12 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       prof_begin(slot_heavy, st);
       hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
       ZK_HIP(hipGetLastError());
-      hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(max_items), dim3(256), 256 * sizeof(XYZZ<F>), st, bases_set, vals_b, first, last,
-                         order, item_off, hb, seg_sums, dense ? 1 : 0);
+      const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
+      hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st,
+                         bases_set, vals_b, first, last, order, item_off, hb, seg_sums, dense ? 1 : 0);
       ZK_HIP(hipGetLastError());
-      hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb), dim3(256), 256 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, buckets);
+      hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off,
+                         hb, buckets);
       ZK_HIP(hipGetLastError());
       prof_end(slot_heavy, st);
       prof_begin(slot_acc, st);
@@ -650,7 +684,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     };
     Jacobian<F> acc = window_sum(G.W - 1);
     for (int w = (int)G.W - 2; w >= 0; --w) {
-      for (uint32_t k = 0; k < G.c; ++k) jac_double(acc);
+      for (uint32_t k = 0; k < G.width[w]; ++k) jac_double(acc);  // the window below spans width[w] bits
       jac_add(acc, window_sum((uint32_t)w));
     }
     *result = acc;
