@@ -145,6 +145,19 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # size-independent check at the FULL size (outside the timed region): additivity over point ranges,
+    # MSM(local shard) == MSM(first half) + MSM(second half, reached through the Source offset)
+    h = n_local // 2
+    whole = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    lo_half = zk.multiexp(worker, (bases[:h], 0), zk.FullDensity(), scalars[:h]).wait()
+    hi_half = zk.multiexp(worker, (bases, h), zk.FullDensity(), scalars[h:]).wait()
+    aff_a, aff_b = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    L.mi355zk_bn254_g1_to_affine(aff_a.ctypes.data_as(C.c_void_p), np.ascontiguousarray(whole).ctypes.data_as(C.c_void_p))
+    joined = zk.shard.join_partials(np.stack([lo_half, hi_half]))
+    L.mi355zk_bn254_g1_to_affine(aff_b.ctypes.data_as(C.c_void_p), joined.ctypes.data_as(C.c_void_p))
+    additive_ok = bool(np.array_equal(aff_a, aff_b))
+    assert additive_ok, "full-size additivity check failed"
+
     # per-kernel durations measured with HIP events on the launch stream (library hooks)
     kern = {}
     for name in ("msm_digits", "msm_sort", "msm_accumulate_heavy", "msm_accumulate", "msm_reduce"):
@@ -197,6 +210,7 @@ def main() -> int:
                          "kernel_ms": {k: (round(v, 4) if v is not None else None) for k, v in kern.items()},
                          "alu_model": {"fq_mul_per_s": fq_mul_per_s, "note": "W*10 Fq mul per scalar-mul in msm_accumulate; MSM is integer-ALU bound (SURVEY 8d)"}},
             "result_affine_x_limb0": hex(int(aff[0])),
+            "full_size_additivity_check": additive_ok,
             "input_gen_s": round(t_gen, 2),
         }
 
