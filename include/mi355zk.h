@@ -140,6 +140,18 @@ int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9
 int mi355zk_selftest_g1_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[16]);
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[32]);
 
+/* ---- QAP evaluation: the per-variable sparse sums of MPCParameters::new
+ * (phase2/src/parameters.rs:225-294: `a_g1[v] += coeffs_g1[lag].mul(coeff)` over the terms of variable v, then
+ * batch_normalization) as one CSR-matrix x point-vector product:
+ *   out[r] = sum_{t = row_ptr[r]}^{row_ptr[r+1]-1} coeff[t] * bases[col[t]],  r < n_rows,  affine out (all-zero = infinity).
+ * row_ptr: u32[n_rows + 1] (row_ptr[n_rows] == nnz), col: u32[nnz], coeff: nnz canonical FrRepr; all device pointers.
+ * `ext` of the reference (three products added) is one call on the concatenated term lists / bases.
+ * Synchronises `stream` before returning. */
+int mi355zk_bn254_g1_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, const uint32_t *d_row_ptr, const uint32_t *d_col,
+                                       const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
+int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, const uint32_t *d_row_ptr, const uint32_t *d_col,
+                                       const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
+
 /* ---- FFT over curve points: EvaluationDomain<Point<G1>>::fft / ifft (bellman/src/group.rs:22-51
  * under domain.rs:154-173), the Lagrange-basis conversion of powersoftau/src/bin/prepare_phase2.rs:68-131.  In
  * place on 2^log_n AFFINE raw records (64 B, all-zero = infinity); the output is normalised to affine, i.e. what

@@ -29,6 +29,8 @@ int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
 int point_fft_g1(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
+int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
+int segsum_g2_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
 void msm_release_g1();
 void msm_release_g2();
 void msm_geometry(uint64_t n, uint32_t* c, uint32_t* W);
@@ -122,14 +124,15 @@ void prof_reset() {
 // G1 runs on U-form arithmetic (curveu.hpp).
 template <class F>
 __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
-                                                       const uint32_t* __restrict__ scalars, int same_scalar, uint64_t n) {
+                                                       const uint32_t* __restrict__ scalars, int same_scalar, uint64_t n,
+                                                       const uint32_t* __restrict__ base_index) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
   const uint32_t* sp = scalars + (same_scalar ? 0 : i * 8);
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = sp[l];
-  const Affine<F> base = bases[same_base ? 0 : i];
+  const Affine<F> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
   XYZZ<F> res = XYZZ<F>::zero();
   if (!base.is_zero()) {
     bool found = false;
@@ -155,11 +158,12 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
 }
 
 template <class F>
-int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_scalars, int same_scalar, size_t n, void* stream) {
+int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_scalars, int same_scalar, size_t n, void* stream,
+              const uint32_t* d_base_index = nullptr) {
   if (!d_out || !d_bases || !d_scalars) return n ? ZK_ERR_BAD_ARGS : ZK_OK;
   if (n == 0) return ZK_OK;
   hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (Affine<F>*)d_out,
-                     (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n);
+                     (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n, d_base_index);
   ZK_HIP(hipGetLastError());
   return ZK_OK;
 }
@@ -359,6 +363,22 @@ int ntt_host(uint64_t* a, uint32_t log_n, int op, const uint64_t* omega) {
 
 using namespace zk;
 
+// out[r] = sum_{t in [row_ptr[r], row_ptr[r+1])} coeff[t] * bases[col[t]], affine (QAP evaluation, parameters.rs:225-294)
+template <class F>
+static int sparse_matvec(void* d_out, const void* d_bases, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeffs, size_t n_rows,
+                         size_t nnz, void* stream, int group) {
+  if (!d_out || !d_row_ptr || (nnz && (!d_bases || !d_col || !d_coeffs)) || n_rows >= (1ull << 31) || nnz >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  if (n_rows == 0) return ZK_OK;
+  Affine<F>* d_terms = nullptr;
+  ZK_HIP(hipMalloc(&d_terms, (nnz ? nnz : 1) * sizeof(Affine<F>)));
+  int rc = batch_exp<F>(d_terms, d_bases, 0, d_coeffs, 0, nnz, stream, d_col);
+  if (rc == ZK_OK)
+    rc = group == 1 ? segsum_g1_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out)
+                    : segsum_g2_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out);
+  (void)hipFree(d_terms);
+  return rc;
+}
+
 extern "C" {
 
 int mi355zk_init(const int* device_ids, int n_devices) {
@@ -472,6 +492,15 @@ int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affin
 int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[16], const void* d_scalars, size_t n, void* stream) {
   return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
 }
+int mi355zk_bn254_g1_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, const uint32_t* d_row_ptr, const uint32_t* d_col,
+                                       const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
+  return sparse_matvec<Fq>(d_out_affine, d_bases_affine, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1);
+}
+int mi355zk_bn254_g2_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, const uint32_t* d_row_ptr, const uint32_t* d_col,
+                                       const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
+  return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
+}
+
 int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
   return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
 }

@@ -33,6 +33,10 @@ int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d
   return rc;
 }
 
+int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out) {
+  return segsum_device<Fq>((const G1Affine*)d_points, nnz, d_row_ptr, n_rows, st, (G1Affine*)d_out);
+}
+
 void msm_release_g1() { ws_release_all(); }
 
 }  // namespace zk

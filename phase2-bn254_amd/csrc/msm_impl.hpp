@@ -696,6 +696,79 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   return ZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Segmented sum of affine points: out[r] = sum of points[row_ptr[r] .. row_ptr[r+1]), normalised to affine.
+// This is the bucket accumulation above with the rows of a CSR matrix as the "buckets" (size-ordered lanes,
+// segment-parallel path for long rows), used by the QAP evaluation of phase2/src/parameters.rs:225-294
+// (per variable: sum of coeff * Lagrange-basis point, then batch_normalization).
+__global__ void __launch_bounds__(256) msm_iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+template <class F>
+__global__ void __launch_bounds__(256) msm_to_affine_kernel(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = xyzz_to_affine(load_vec(in + i));
+}
+
+template <class F>
+int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, Affine<F>* d_out) {
+  if (n_rows == 0) return ZK_OK;
+  if (nnz >= 0x7fffffffull) return ZK_ERR_BAD_ARGS;
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  const uint32_t* first = d_row_ptr;
+  const uint32_t* last = d_row_ptr + 1;
+  const uint64_t mean_len = nnz / n_rows + 1;
+  const uint32_t heavy = (uint32_t)(mean_len * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean_len * 8 + 1024);
+  uint32_t hb = n_rows < MSM_HEAVY_BLOCKS ? n_rows : MSM_HEAVY_BLOCKS;
+  if ((uint64_t)hb > nnz / heavy + 1) hb = (uint32_t)(nnz / heavy + 1);
+  const uint32_t max_items = (uint32_t)(nnz / MSM_HEAVY_SEG) + hb;
+  int size_bits = 1;
+  while (size_bits < 32 && (1ull << size_bits) <= nnz) ++size_bits;
+  size_t sort_tmp_bytes = 0;
+  ZK_HIP(rocprim::radix_sort_pairs_desc(nullptr, sort_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (uint32_t*)nullptr, (size_t)n_rows, 0, size_bits, st));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  size_t o_vals = take((size_t)(nnz ? nnz : 1) * 4);
+  size_t o_sizes_a = take((size_t)n_rows * 4), o_sizes_b = take((size_t)n_rows * 4);
+  size_t o_ids_a = take((size_t)n_rows * 4), o_order = take((size_t)n_rows * 4);
+  size_t o_item_off = take((size_t)(hb + 1) * 4);
+  size_t o_seg = take((size_t)max_items * sizeof(XYZZ<F>));
+  size_t o_buckets = take((size_t)n_rows * sizeof(XYZZ<F>));
+  size_t o_sort = take(sort_tmp_bytes);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  void* base = nullptr;
+  int rc = ws_reserve(dev, off, &base);
+  if (rc) return rc;
+  char* ws = (char*)base;
+  uint32_t* vals = (uint32_t*)(ws + o_vals);
+  uint32_t* sizes_a = (uint32_t*)(ws + o_sizes_a);
+  uint32_t* sizes_b = (uint32_t*)(ws + o_sizes_b);
+  uint32_t* ids_a = (uint32_t*)(ws + o_ids_a);
+  uint32_t* order = (uint32_t*)(ws + o_order);
+  uint32_t* item_off = (uint32_t*)(ws + o_item_off);
+  XYZZ<F>* seg_sums = (XYZZ<F>*)(ws + o_seg);
+  XYZZ<F>* buckets = (XYZZ<F>*)(ws + o_buckets);
+  if (nnz) hipLaunchKernelGGL(msm_iota_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, vals, (uint32_t)nnz);
+  hipLaunchKernelGGL(msm_sizes_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, first, last, n_rows, sizes_a, ids_a);
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(rocprim::radix_sort_pairs_desc((void*)(ws + o_sort), sort_tmp_bytes, sizes_a, sizes_b, ids_a, order, (size_t)n_rows, 0, size_bits, st));
+  hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
+  const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
+  hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st, d_points,
+                     vals, first, last, order, item_off, hb, seg_sums, 1);
+  hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, hb,
+                     buckets);
+  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
+                     n_rows, buckets, 1);
+  hipLaunchKernelGGL(msm_to_affine_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, buckets, d_out, n_rows);
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(hipStreamSynchronize(st));  // the workspace is shared: finish before releasing the lock
+  return ZK_OK;
+}
+
 }  // namespace
 
 }  // namespace zk

@@ -284,3 +284,40 @@ def test_merge_pairs_and_dense_multiexp(zk, worker, group):
     fn1 = L.mi355zk_bn254_g1_dense_multiexp_dev if group == 1 else L.mi355zk_bn254_g2_dense_multiexp_dev
     assert fn1(C.c_void_p(d_v.data_ptr()), C.c_void_p(d_rho.data_ptr()), n, None, one.ctypes.data_as(C.c_void_p)) == 0
     assert np.array_equal(G.to_affine(one), ref(v[:n]))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_sparse_matvec_qap_evaluation(zk, worker, group):
+    """out[v] = sum over the terms of variable v of coeff * Lagrange point (parameters.rs:281-294),
+    then batch_normalization.  CSR rows of very different lengths (empty rows, one long row such as the constant-one
+    variable, +-1 and zero coefficients, an infinity base), bit exact against the oracle's mul_assign / add_assign."""
+    import torch
+
+    import bn254_model as M
+
+    G = O.G1 if group == 1 else O.G2
+    nb = 64 if group == 1 else 24
+    bases = inputs.bases_progression_cpu(group, nb, seed=1300 + group)
+    bases[5] = 0
+    rng = np.random.default_rng(1301)
+    row_len = [0, 1, 3, 0, (900 if group == 1 else 150), 2, 7, 1]
+    row_ptr = np.concatenate([[0], np.cumsum(row_len)]).astype(np.uint32)
+    nnz = int(row_ptr[-1])
+    col = rng.integers(0, nb, size=nnz).astype(np.uint32)
+    coeff = inputs.random_scalars(nnz, seed=1302)
+    small = rng.integers(0, 4, size=nnz)
+    coeff[small == 0] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    coeff[small == 1] = np.array(M.to_limbs(M.R_ORDER - 1), dtype=np.uint64)
+    coeff[3] = 0
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else np.int32)).cuda()  # noqa: E731
+    d_bases, d_rp, d_col, d_cf = d(bases), d(row_ptr), d(col), d(coeff)
+    d_out = torch.zeros((len(row_len), 8 * group), dtype=torch.int64, device="cuda")
+    fn = zk.lib.load().mi355zk_bn254_g1_sparse_matvec_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_sparse_matvec_dev
+    assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_col.data_ptr()),
+              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 0
+    got = d_out.cpu().numpy().view(np.uint64)
+    for r in range(len(row_len)):
+        acc = G.from_affine(np.zeros(G.aff, np.uint64))
+        for t in range(row_ptr[r], row_ptr[r + 1]):
+            acc = G.add(acc, G.mul(G.from_affine(bases[col[t]]), coeff[t]))
+        assert np.array_equal(got[r], G.to_affine(acc)), r

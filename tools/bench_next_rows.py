@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measurements for the SURVEY 8(f) "next" rows that are built: batch_exp (row 1) and merge_pairs (row 2)."""
+"""Measurements for the SURVEY 8(f) "next" rows that are built: batch_exp (row 1), merge_pairs (row 2), the QAP sparse matvec (row 3) and the G1 point FFT (row 4)."""
 import argparse, ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -35,6 +35,20 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     for _ in range(a.iters): mp(*args)
     dt = (time.perf_counter() - t) / a.iters
     out[f"g{g}_power_pairs"] = {"ms": round(dt * 1e3, 3), "Mscalar_mul_per_s_both_sums": round(2 * n / dt / 1e6, 2)}
+    # row 3: QAP evaluation as a CSR sparse matvec over points: n variables, ~3 terms each, variable 0 ("one") in n/4 terms
+    g_ = torch.Generator(device=dev); g_.manual_seed(77 + g)
+    lens = torch.randint(0, 6, (n,), device=dev, generator=g_, dtype=torch.int64); lens[0] = n // 4
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=dev); rp[1:] = torch.cumsum(lens, 0)
+    nnz = int(rp[-1].item())
+    rp32 = rp.to(torch.int32); col = torch.randint(0, n, (nnz,), device=dev, generator=g_, dtype=torch.int32)
+    cf = bench.gen_scalars(nnz, 61 + g, dev)
+    smv = L.mi355zk_bn254_g1_sparse_matvec_dev if g == 1 else L.mi355zk_bn254_g2_sparse_matvec_dev
+    sargs = (C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(rp32.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(cf.data_ptr()), n, nnz, None)
+    assert smv(*sargs) == 0
+    t = time.perf_counter()
+    for _ in range(a.iters): assert smv(*sargs) == 0
+    dt = (time.perf_counter() - t) / a.iters
+    out[f"g{g}_qap_sparse_matvec"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
 # row 4: point FFT (prepare_phase2's Lagrange-basis conversion)
 for ln in (12, 16, a.log_n):
     m = 1 << ln
