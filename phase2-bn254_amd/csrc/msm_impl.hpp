@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
   uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
   if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
-    for (uint32_t w = 0; w < G.W; ++w) keys[(uint64_t)w * n + i] = G.invalid;
+    for (uint32_t w = 0; w < G.W; ++w) keys[(uint64_t)w * n + i] = (w << G.c) | G.nb;
     return;
   }
   // a selected base with a non-zero exponent must not be the identity (source.rs:50-52)
@@ -130,31 +130,104 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       carry = 1;
     }
     uint64_t o = (uint64_t)w * n + i;
-    keys[o] = d ? (w * G.nb + d - 1) : G.invalid;
+    keys[o] = (w << G.c) | (d ? d - 1 : G.nb);  // sort field = low c bits: bucket, or 2^(c-1) = "no bucket" (sorts last)
     vals[o] = (uint32_t)bi | neg;
   }
 }
 
-// 3. bucket boundaries in the sorted pair list
-__global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t invalid,
+// 2. the pairs are sorted (stable LSD radix sort) on the LOW c BITS of the key only: the digits kernel writes
+//    window-major, so equal sort fields keep their window order and every (window, bucket) run is contiguous --
+//    the window number never has to take part in the sort (2 passes instead of 3 for c <= 16).
+// 3. bucket boundaries in the sorted pair list; bucket id = window * nb + bucket
+__global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t c, uint32_t nb,
                                                         uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
   uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   uint32_t k = keys[j];
-  if (k >= invalid) return;
-  if (j == 0 || keys[j - 1] != k) first[k] = (uint32_t)j;
-  if (j + 1 == m || keys[j + 1] != k) last[k] = (uint32_t)j + 1;
+  uint32_t field = k & ((1u << c) - 1u);
+  if (field >= nb) return;
+  uint32_t id = (k >> c) * nb + field;
+  if (j == 0 || keys[j - 1] != k) first[id] = (uint32_t)j;
+  if (j + 1 == m || keys[j + 1] != k) last[id] = (uint32_t)j + 1;
 }
 
-// 3b. size[b] = last[b] - first[b], id[b] = b : sorted by size (descending) so that the 64 lanes of a wave
-//     own buckets of (nearly) equal length -- bucket sizes are Poisson distributed and a wave runs as long
-//     as its longest lane -- and so that the few very long buckets of a skewed input come first.
-__global__ void __launch_bounds__(256) msm_sizes_kernel(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                       uint32_t n_buckets, uint32_t* __restrict__ sizes, uint32_t* __restrict__ ids) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_buckets) return;
-  sizes[b] = last[b] - first[b];
-  ids[b] = b;
+// 3b. buckets ordered by size (descending) so that the 64 lanes of a wave own buckets of (nearly) equal length --
+//     bucket sizes are Poisson distributed and a wave runs as long as its longest lane -- and so that the few very
+//     long buckets of a skewed input come first.  A counting sort on the size (exact below 2048, then in steps of
+//     2048): histogram, suffix scan, scatter; the order inside a bin is irrelevant.
+constexpr uint32_t MSM_SIZE_BINS = 4096;
+__device__ __forceinline__ uint32_t msm_size_bin(uint32_t sz) {
+  uint32_t hi = sz >> 11;
+  return sz < 2048 ? sz : 2048 + (hi < 2047 ? hi : 2047);
+}
+__global__ void __launch_bounds__(1024) msm_size_hist_kernel(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                            uint32_t n_buckets, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[MSM_SIZE_BINS];
+  for (uint32_t t = threadIdx.x; t < MSM_SIZE_BINS; t += blockDim.x) lh[t] = 0;
+  __syncthreads();
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += gridDim.x * blockDim.x)
+    atomicAdd(&lh[msm_size_bin(last[b] - first[b])], 1u);
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < MSM_SIZE_BINS; t += blockDim.x)
+    if (lh[t]) atomicAdd(&hist[t], lh[t]);
+}
+// offs[bin] = number of buckets in larger bins (in place over hist); one workgroup
+__global__ void __launch_bounds__(1024) msm_size_scan_kernel(uint32_t* __restrict__ hist) {
+  __shared__ uint32_t part[1024];
+  constexpr uint32_t PER = MSM_SIZE_BINS / 1024;
+  uint32_t v[PER], sum = 0;
+  for (uint32_t k = 0; k < PER; ++k) { v[k] = hist[threadIdx.x * PER + k]; sum += v[k]; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive suffix sums
+    uint32_t add = threadIdx.x + d < 1024 ? part[threadIdx.x + d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;  // buckets in the bins of higher threads
+  for (int k = (int)PER - 1; k >= 0; --k) { hist[threadIdx.x * PER + k] = run; run += v[k]; }
+}
+constexpr uint32_t MSM_SCATTER_PER = 4;  // buckets per lane
+__global__ void __launch_bounds__(1024) msm_size_scatter_kernel(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                               uint32_t n_buckets, uint32_t* __restrict__ offs, uint32_t* __restrict__ order,
+                                                               uint32_t* __restrict__ sizes_sorted) {
+  __shared__ uint32_t cnt[MSM_SIZE_BINS];
+  __shared__ uint32_t base[MSM_SIZE_BINS];
+  for (uint32_t t = threadIdx.x; t < MSM_SIZE_BINS; t += blockDim.x) cnt[t] = 0;
+  __syncthreads();
+  uint32_t sz[MSM_SCATTER_PER], rank[MSM_SCATTER_PER];
+  const uint32_t b0 = blockIdx.x * (blockDim.x * MSM_SCATTER_PER) + threadIdx.x;
+#pragma unroll
+  for (uint32_t k = 0; k < MSM_SCATTER_PER; ++k) {
+    uint32_t b = b0 + k * blockDim.x;
+    if (b < n_buckets) {
+      sz[k] = last[b] - first[b];
+      rank[k] = atomicAdd(&cnt[msm_size_bin(sz[k])], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < MSM_SIZE_BINS; t += blockDim.x)
+    if (cnt[t]) base[t] = atomicAdd(&offs[t], cnt[t]);
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < MSM_SCATTER_PER; ++k) {
+    uint32_t b = b0 + k * blockDim.x;
+    if (b < n_buckets) {
+      uint32_t pos = base[msm_size_bin(sz[k])] + rank[k];
+      order[pos] = b;
+      sizes_sorted[pos] = sz[k];
+    }
+  }
+}
+// hist: MSM_SIZE_BINS words, zeroed by the caller
+inline void msm_order_by_size(const uint32_t* first, const uint32_t* last, uint32_t n_buckets, uint32_t* hist, uint32_t* order,
+                              uint32_t* sizes_sorted, hipStream_t st) {
+  uint32_t hb = (n_buckets + 4095) / 4096;
+  hipLaunchKernelGGL(msm_size_hist_kernel, dim3(hb < 1024 ? hb : 1024), dim3(1024), 0, st, first, last, n_buckets, hist);
+  hipLaunchKernelGGL(msm_size_scan_kernel, dim3(1), dim3(1024), 0, st, hist);
+  hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((n_buckets + 1024 * MSM_SCATTER_PER - 1) / (1024 * MSM_SCATTER_PER)), dim3(1024), 0, st, first,
+                     last, n_buckets, hist, order, sizes_sorted);
 }
 
 constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take the segment-parallel path (the rest of a pathological input runs one lane per bucket)
@@ -332,59 +405,56 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __
   store_vec(outS + t, run);
 }
 
-// out[w*nblk + blk] = sum of slice `blk` (of `per_block` elements) of in[w*count .. (w+1)*count).
-// Launched as grid (nblk, W): strided serial sums of <= per_block/128 elements per lane, then an LDS tree.
-// Applied repeatedly until one element per window is left.
+// 5b/5c. the tail of the reduction, by trees.  A running-sum level costs 2L dependent additions however few
+//     elements are left, so once at most MSM_FINAL_MAX elements per window remain the weighted sum of the last S[]
+//     is finished by BIT DECOMPOSITION:  sum_x (x+off) S[x] = sum_j 2^j * (sum over x with bit j of (x+off) set of S[x]),
+//     and the plain sums of every level's A[] ride in the same launch.  One workgroup sums a slice of MSM_TREE_SLICE
+//     elements of one job (A of a level, or one bit) of one window: one pair per lane, then an LDS tree (depth 9);
+//     further launches of the same kernel sum the slice sums.  The host applies the powers of two and of L.
+//     The grid is 1-D over the NON-EMPTY (window, job, slice) triples: jobs of one launch differ in length, and a
+//     (slices, jobs, windows) grid put every short job's only workgroup on the same XCD (block id = multiple of 8).
+constexpr uint32_t MSM_FINAL_MAX = 1024;
+constexpr uint32_t MSM_TREE_SLICE = 512;
+constexpr uint32_t MSM_MAX_LEVELS = 8;
+constexpr uint32_t MSM_MAX_JOBS = MSM_MAX_LEVELS + 24;
 template <class F>
-__global__ void __launch_bounds__(128) msm_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t per_block,
-                                                     XYZZ<F>* __restrict__ out) {
+struct TreeJobs {
+  const XYZZ<F>* in[MSM_MAX_JOBS];   // job j sums in[j][w * stride[j] + x], x < cnt[j] (bit[j] < 0), or only the x with
+  uint32_t cnt[MSM_MAX_JOBS];        // bit bit[j] of (x + off) set
+  uint32_t stride[MSM_MAX_JOBS];
+  int32_t bit[MSM_MAX_JOBS];
+  uint32_t first_block[MSM_MAX_JOBS + 1];  // prefix sums of the slice counts: blocks per window = first_block[n_jobs]
+  uint32_t n_jobs, off;
+};
+// out[(w * n_jobs + job) * out_stride + slice]
+template <class F>
+__global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J, XYZZ<F>* __restrict__ out, uint32_t out_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const uint32_t w = blockIdx.y, blk = blockIdx.x;
-  const XYZZ<F>* P = in + (uint64_t)w * count;
-  uint32_t lo = blk * per_block, hi = lo + per_block < count ? lo + per_block : count;
-  XYZZ<F> acc = XYZZ<F>::zero();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) xyzz_add(acc, load_vec(P + i));
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      XYZZ<F> a = sh[threadIdx.x];
-      xyzz_add(a, sh[threadIdx.x + s]);
-      sh[threadIdx.x] = a;
-    }
+  const uint32_t per_w = J.first_block[J.n_jobs];
+  const uint32_t w = blockIdx.x / per_w, r = blockIdx.x % per_w;
+  uint32_t job = 0;
+  while (job + 1 < J.n_jobs && J.first_block[job + 1] <= r) ++job;
+  const uint32_t slice = r - J.first_block[job];
+  const uint32_t count = J.cnt[job];
+  const int32_t bit = J.bit[job];
+  const XYZZ<F>* P = J.in[job] + (uint64_t)w * J.stride[job];
+  const uint32_t x0 = slice * MSM_TREE_SLICE + threadIdx.x, x1 = x0 + 256;
+  XYZZ<F> acc = XYZZ<F>::zero(), other = XYZZ<F>::zero();
+  if (x0 < count && (bit < 0 || (((x0 + J.off) >> bit) & 1))) acc = load_vec(P + x0);
+  if (x1 < count && (bit < 0 || (((x1 + J.off) >> bit) & 1))) other = load_vec(P + x1);
+  // ONE inlined xyzz_add for the pair and for every tree level (code size).  Lanes [s, 2s) publish, lanes [0, s)
+  // consume; the regions written in consecutive rounds are disjoint from the ones still being read, so one
+  // barrier per round.
+  for (uint32_t s = 256;;) {
+    xyzz_add(acc, other);
+    s >>= 1;
+    if (s == 0) break;
+    if (threadIdx.x >= s && threadIdx.x < 2 * s) sh[threadIdx.x] = acc;
     __syncthreads();
+    other = threadIdx.x < s ? sh[threadIdx.x + s] : XYZZ<F>::zero();
   }
-  if (threadIdx.x == 0) store_vec(out + (uint64_t)w * gridDim.x + blk, sh[0]);
-}
-
-// 5c. final stage: the serial depth of the running-sum levels (2L additions each) is what a small multiexp
-//     waits for, so once at most MSM_FINAL_MAX elements per window are left the weighted sum is finished by
-//     BIT DECOMPOSITION instead:  sum_x (x+off) F[x] = sum_j 2^j * (sum over x with bit j of (x+off) set of F[x]),
-//     one workgroup per (bit, window) doing a strided partial sum and an LDS tree (depth <= 8 + 8 additions for all
-//     bits at once); the host applies the powers of two.
-constexpr uint32_t MSM_FINAL_MAX = 4096;
-template <class F>
-__global__ void __launch_bounds__(256) msm_bitsum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t off,
-                                                        XYZZ<F>* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const uint32_t j = blockIdx.x, w = blockIdx.y;
-  const XYZZ<F>* P = in + (uint64_t)w * count;
-  XYZZ<F> acc = XYZZ<F>::zero();
-  for (uint32_t x = threadIdx.x; x < count; x += blockDim.x)
-    if (((x + off) >> j) & 1) xyzz_add(acc, load_vec(P + x));
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      XYZZ<F> a = sh[threadIdx.x];
-      xyzz_add(a, sh[threadIdx.x + s]);
-      sh[threadIdx.x] = a;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) store_vec(out + (uint64_t)w * gridDim.x + j, sh[0]);
+  if (threadIdx.x == 0) store_vec(out + ((uint64_t)w * J.n_jobs + job) * out_stride + slice, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,14 +559,16 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   if (m > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
   const uint32_t n_buckets = G.W * G.nb;
   // reduction: running-sum levels (msm_reduce_level_kernel, chunk length L) while more than MSM_FINAL_MAX
-  // elements per window are left, then the bit-decomposition stage (msm_bitsum_kernel)
-  const uint32_t L = 8, LOG_L = 3;
-  uint32_t lvl_cnt[16], lvl_chunks[16], n_levels = 0;
+  // elements per window are left, then the bit-decomposition stage (msm_tree_kernel)
+  // chunk length per level: 2L serial additions per lane, so shorter chunks once lanes are scarce
+  uint32_t lvl_cnt[MSM_MAX_LEVELS + 1], lvl_chunks[MSM_MAX_LEVELS + 1], lvl_logl[MSM_MAX_LEVELS + 1], n_levels = 0;
   uint64_t total_chunks = 1;
   uint32_t final_cnt = G.nb;
-  while (final_cnt > MSM_FINAL_MAX) {
+  while (final_cnt > MSM_FINAL_MAX && n_levels < MSM_MAX_LEVELS) {
+    const uint32_t logl = (uint64_t)final_cnt * G.W >= (1ull << 20) ? 3 : 2;
     lvl_cnt[n_levels] = final_cnt;
-    lvl_chunks[n_levels] = (final_cnt + L - 1) / L;
+    lvl_logl[n_levels] = logl;
+    lvl_chunks[n_levels] = (final_cnt + (1u << logl) - 1) >> logl;
     total_chunks += lvl_chunks[n_levels];
     final_cnt = lvl_chunks[n_levels];
     ++n_levels;
@@ -505,24 +577,17 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t final_bits = 1;
   while ((1u << final_bits) <= final_cnt - 1 + final_off) ++final_bits;
 
-  int key_bits = 1;
-  while ((1ull << key_bits) <= G.invalid) ++key_bits;
-
-  size_t sort_tmp_bytes = 0, sort2_tmp_bytes = 0;
+  size_t sort_tmp_bytes = 0;
   ZK_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint32_t*)nullptr, (size_t)m, 0, key_bits, st));
-  int size_bits = 1;
-  while (size_bits < 32 && (1ull << size_bits) <= n) ++size_bits;  // a bucket holds at most n entries
-  ZK_HIP(rocprim::radix_sort_pairs_desc(nullptr, sort2_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                        (uint32_t*)nullptr, (size_t)n_buckets, 0, size_bits, st));
-  if (sort2_tmp_bytes > sort_tmp_bytes) sort_tmp_bytes = sort2_tmp_bytes;
+                                   (uint32_t*)nullptr, (size_t)m, 0, G.c, st));
 
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   size_t o_keys_a = take(m * 4), o_keys_b = take(m * 4), o_vals_a = take(m * 4), o_vals_b = take(m * 4);
-  size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4);
-  size_t o_sizes_a = take((size_t)n_buckets * 4), o_sizes_b = take((size_t)n_buckets * 4);
-  size_t o_ids_a = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
+  // first, last and the size histogram are contiguous: one memset clears them
+  size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
+  size_t o_zero_end = off;
+  size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
   // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
   const uint64_t mean_len = n / G.nb + 1;
   const uint32_t heavy = (uint32_t)(mean_len * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean_len * 8 + 1024);
@@ -536,9 +601,10 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
   const uint32_t n_out = n_levels + final_bits;  // per window: one A-sum per level, then one sum per bit
   size_t o_wsums = take((size_t)G.W * n_out * sizeof(XYZZ<F>));
-  const uint32_t SUM_PER_BLOCK = 1024;  // 128 lanes x 8 elements
-  const uint32_t sum_half = (n_levels ? (lvl_chunks[0] + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK : 0) + 1;
-  size_t o_sumtmp = take((size_t)G.W * sum_half * 2 * sizeof(XYZZ<F>));
+  // slice sums of msm_tree_kernel (two ping-pong halves): n_out jobs per window, slices of the longest job
+  const uint32_t tree_cnt = n_levels ? lvl_chunks[0] : final_cnt;
+  const uint64_t tree_tmp = (uint64_t)n_out * ((tree_cnt + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE);
+  size_t o_sumtmp = take((size_t)G.W * tree_tmp * 2 * sizeof(XYZZ<F>));
   size_t o_err = take(8);
   size_t o_sort = take(sort_tmp_bytes);
 
@@ -553,9 +619,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t* vals_b = (uint32_t*)(ws + o_vals_b);
   uint32_t* first = (uint32_t*)(ws + o_first);
   uint32_t* last = (uint32_t*)(ws + o_last);
-  uint32_t* sizes_a = (uint32_t*)(ws + o_sizes_a);
+  uint32_t* size_hist = (uint32_t*)(ws + o_hist);
   uint32_t* sizes_b = (uint32_t*)(ws + o_sizes_b);
-  uint32_t* ids_a = (uint32_t*)(ws + o_ids_a);
   uint32_t* order = (uint32_t*)(ws + o_ids_b);
   uint32_t* item_off = (uint32_t*)(ws + o_item_off);
   XYZZ<F>* seg_sums = (XYZZ<F>*)(ws + o_seg_sums);
@@ -567,15 +632,14 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   unsigned long long* d_err = (unsigned long long*)(ws + o_err);
 
   ZK_HIP(hipMemsetAsync(d_err, 0xff, 8, st));
-  ZK_HIP(hipMemsetAsync(first, 0, (size_t)(n_buckets + 1) * 4, st));
-  ZK_HIP(hipMemsetAsync(last, 0, (size_t)(n_buckets + 1) * 4, st));
+  ZK_HIP(hipMemsetAsync(first, 0, o_zero_end - o_first, st));
 
   static const bool debug = std::getenv("MI355ZK_DEBUG") != nullptr;
   auto checkpoint = [&](const char* what) -> int {
     if (!debug) return 0;
     ZK_HIP(hipStreamSynchronize(st));
-    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u L=%u: %s done\n", (int)(sizeof(F) / sizeof(Fq)),
-                 (unsigned long long)n, G.c, G.W, n_buckets, L, what);
+    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u levels=%u: %s done\n", (int)(sizeof(F) / sizeof(Fq)),
+                 (unsigned long long)n, G.c, G.W, n_buckets, n_levels, what);
     return 0;
   };
   static const int slot_digits = prof_slot("msm_digits"), slot_sort = prof_slot("msm_sort"),
@@ -590,12 +654,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   if (checkpoint("digits")) return ZK_ERR_DEVICE;
 
   prof_begin(slot_sort, st);
-  ZK_HIP(rocprim::radix_sort_pairs((void*)(ws + o_sort), sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, key_bits, st));
-  hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys_b, m, G.invalid, first, last);
+  ZK_HIP(rocprim::radix_sort_pairs((void*)(ws + o_sort), sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, G.c, st));
+  hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys_b, m, G.c, G.nb, first, last);
   ZK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(msm_sizes_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, st, first, last, n_buckets, sizes_a, ids_a);
+  msm_order_by_size(first, last, n_buckets, size_hist, order, sizes_b, st);
   ZK_HIP(hipGetLastError());
-  ZK_HIP(rocprim::radix_sort_pairs_desc((void*)(ws + o_sort), sort_tmp_bytes, sizes_a, sizes_b, ids_a, order, (size_t)n_buckets, 0, size_bits, st));
   prof_end(slot_sort, st);
   if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
 
@@ -622,38 +685,51 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
     prof_begin(slot_red, st);
     {
+      // wsums[w * n_out + k]:  k < n_levels: sum of A of level k;  k >= n_levels: bit sum j = k - n_levels of the last array
+      TreeJobs<F> J{};
       const XYZZ<F>* in = buckets;
       uint64_t o = 0;
       for (uint32_t lv = 0; lv < n_levels; ++lv) {
         uint32_t threads = lvl_chunks[lv] * G.W;
         XYZZ<F>* A = partA + o * G.W;
         XYZZ<F>* S = partS + o * G.W;
-        hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], L, lv == 0 ? 1u : 0u,
-                           G.W, A, S);
+        hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], 1u << lvl_logl[lv],
+                           lv == 0 ? 1u : 0u, G.W, A, S);
         ZK_HIP(hipGetLastError());
-        {  // wsums[lv][w] = sum_ch A[w][ch], by repeated blocked sums
-          const XYZZ<F>* src = A;
-          uint32_t cnt = lvl_chunks[lv];
-          const uint32_t half = sum_half;
-          int flip = 0;
-          for (;;) {
-            uint32_t nblk = (cnt + SUM_PER_BLOCK - 1) / SUM_PER_BLOCK;
-            XYZZ<F>* dst = nblk == 1 ? wsums + (uint64_t)lv * G.W : sumtmp + (uint64_t)flip * half * G.W;
-            hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(nblk, G.W), dim3(128), 128 * sizeof(XYZZ<F>), st, src, cnt, SUM_PER_BLOCK, dst);
-            ZK_HIP(hipGetLastError());
-            if (nblk == 1) break;
-            src = dst;
-            cnt = nblk;
-            flip ^= 1;
-          }
-        }
+        J.in[lv] = A;
+        J.cnt[lv] = J.stride[lv] = lvl_chunks[lv];
+        J.bit[lv] = -1;
         in = S;
         o += lvl_chunks[lv];
       }
-      // bit sums of the last array: wsums[n_levels * W + w * final_bits + j]
-      hipLaunchKernelGGL(msm_bitsum_kernel<F>, dim3(final_bits, G.W), dim3(256), 256 * sizeof(XYZZ<F>), st, in, final_cnt, final_off,
-                         wsums + (uint64_t)n_levels * G.W);
-      ZK_HIP(hipGetLastError());
+      for (uint32_t j = 0; j < final_bits; ++j) {
+        J.in[n_levels + j] = in;
+        J.cnt[n_levels + j] = J.stride[n_levels + j] = final_cnt;
+        J.bit[n_levels + j] = (int32_t)j;
+      }
+      J.n_jobs = n_out;
+      J.off = final_off;
+      const size_t lds = 256 * sizeof(XYZZ<F>);
+      XYZZ<F>* dst = sumtmp;
+      for (;;) {
+        uint32_t left = 1;  // longest row of slice sums this launch leaves
+        for (uint32_t j = 0; j < n_out; ++j) {
+          const uint32_t sl = (J.cnt[j] + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
+          J.first_block[j + 1] = J.first_block[j] + sl;
+          if (sl > left) left = sl;
+        }
+        const bool last = left == 1;
+        hipLaunchKernelGGL(msm_tree_kernel<F>, dim3(J.first_block[n_out] * G.W), dim3(256), lds, st, J, last ? wsums : dst, left);
+        ZK_HIP(hipGetLastError());
+        if (last) break;
+        for (uint32_t j = 0; j < n_out; ++j) {  // next launch: plain sums of the rows of slice sums
+          J.in[j] = dst + (uint64_t)j * left;
+          J.cnt[j] = (J.cnt[j] + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
+          J.stride[j] = n_out * left;
+          J.bit[j] = -1;
+        }
+        dst = dst == sumtmp ? sumtmp + (uint64_t)G.W * tree_tmp : sumtmp;
+      }
     }
     prof_end(slot_red, st);
     if (checkpoint("reduce")) return (int)ZK_ERR_DEVICE;
@@ -667,25 +743,27 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       *err_index_out = (long long)h_err;
       return ZK_ERR_UNEXPECTED_IDENTITY;
     }
-    // window sum T_w = A_0 + L*(A_1 + ... + L*(sum_j 2^j Bits_j)), then the join of the windows, most
-    // significant first: c doublings + add per window (multiexp.rs:146-154)
-    auto window_sum = [&](uint32_t w) {
-      const XYZZ<F>* bits = h_wsums.data() + (size_t)n_levels * G.W + (size_t)w * final_bits;
-      Jacobian<F> t = xyzz_to_jacobian(bits[final_bits - 1]);
-      for (int j = (int)final_bits - 2; j >= 0; --j) {
-        jac_double(t);
-        jac_add(t, xyzz_to_jacobian(bits[j]));
+    // result = sum_w 2^shift_w * T_w,  T_w = A_0 + L_0*(A_1 + L_1*(... + sum_j 2^j Bits_j)):  every partial sum
+    // P[w][k] carries a power of two 2^(shift_w + e_k).  Terms are collected per exponent and ONE Horner pass
+    // (a doubling per bit, multiexp.rs:146-154) joins everything -- ~270 doublings instead of W * (c + e_max).
+    std::vector<uint32_t> e_k(n_out);
+    uint32_t e_lv = 0;
+    for (uint32_t lv = 0; lv < n_levels; ++lv) {
+      e_k[lv] = e_lv;
+      e_lv += lvl_logl[lv];
+    }
+    for (uint32_t j = 0; j < final_bits; ++j) e_k[n_levels + j] = e_lv + j;
+    const uint32_t t_max = G.shift[G.W - 1] + e_k[n_out - 1];
+    std::vector<Jacobian<F>> by_exp((size_t)t_max + 1, Jacobian<F>::zero());
+    for (uint32_t w = 0; w < G.W; ++w)
+      for (uint32_t k = 0; k < n_out; ++k) {
+        const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
+        if (!pt.is_zero()) jac_add(by_exp[G.shift[w] + e_k[k]], xyzz_to_jacobian(pt));
       }
-      for (int lv = (int)n_levels - 1; lv >= 0; --lv) {
-        for (uint32_t k = 0; k < LOG_L; ++k) jac_double(t);
-        jac_add(t, xyzz_to_jacobian(h_wsums[(size_t)lv * G.W + w]));
-      }
-      return t;
-    };
-    Jacobian<F> acc = window_sum(G.W - 1);
-    for (int w = (int)G.W - 2; w >= 0; --w) {
-      for (uint32_t k = 0; k < G.width[w]; ++k) jac_double(acc);  // the window below spans width[w] bits
-      jac_add(acc, window_sum((uint32_t)w));
+    Jacobian<F> acc = by_exp[t_max];
+    for (int t = (int)t_max - 1; t >= 0; --t) {
+      jac_double(acc);
+      if (!by_exp[t].is_zero()) jac_add(acc, by_exp[t]);
     }
     *result = acc;
     return (int)ZK_OK;
@@ -724,37 +802,29 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   uint32_t hb = n_rows < MSM_HEAVY_BLOCKS ? n_rows : MSM_HEAVY_BLOCKS;
   if ((uint64_t)hb > nnz / heavy + 1) hb = (uint32_t)(nnz / heavy + 1);
   const uint32_t max_items = (uint32_t)(nnz / MSM_HEAVY_SEG) + hb;
-  int size_bits = 1;
-  while (size_bits < 32 && (1ull << size_bits) <= nnz) ++size_bits;
-  size_t sort_tmp_bytes = 0;
-  ZK_HIP(rocprim::radix_sort_pairs_desc(nullptr, sort_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                        (uint32_t*)nullptr, (size_t)n_rows, 0, size_bits, st));
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   size_t o_vals = take((size_t)(nnz ? nnz : 1) * 4);
-  size_t o_sizes_a = take((size_t)n_rows * 4), o_sizes_b = take((size_t)n_rows * 4);
-  size_t o_ids_a = take((size_t)n_rows * 4), o_order = take((size_t)n_rows * 4);
+  size_t o_hist = take(MSM_SIZE_BINS * 4), o_sizes_b = take((size_t)n_rows * 4), o_order = take((size_t)n_rows * 4);
   size_t o_item_off = take((size_t)(hb + 1) * 4);
   size_t o_seg = take((size_t)max_items * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_rows * sizeof(XYZZ<F>));
-  size_t o_sort = take(sort_tmp_bytes);
   std::lock_guard<std::mutex> lk(g_ws_mu);
   void* base = nullptr;
   int rc = ws_reserve(dev, off, &base);
   if (rc) return rc;
   char* ws = (char*)base;
   uint32_t* vals = (uint32_t*)(ws + o_vals);
-  uint32_t* sizes_a = (uint32_t*)(ws + o_sizes_a);
+  uint32_t* size_hist = (uint32_t*)(ws + o_hist);
   uint32_t* sizes_b = (uint32_t*)(ws + o_sizes_b);
-  uint32_t* ids_a = (uint32_t*)(ws + o_ids_a);
   uint32_t* order = (uint32_t*)(ws + o_order);
   uint32_t* item_off = (uint32_t*)(ws + o_item_off);
   XYZZ<F>* seg_sums = (XYZZ<F>*)(ws + o_seg);
   XYZZ<F>* buckets = (XYZZ<F>*)(ws + o_buckets);
   if (nnz) hipLaunchKernelGGL(msm_iota_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, vals, (uint32_t)nnz);
-  hipLaunchKernelGGL(msm_sizes_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, first, last, n_rows, sizes_a, ids_a);
+  ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
+  msm_order_by_size(first, last, n_rows, size_hist, order, sizes_b, st);
   ZK_HIP(hipGetLastError());
-  ZK_HIP(rocprim::radix_sort_pairs_desc((void*)(ws + o_sort), sort_tmp_bytes, sizes_a, sizes_b, ids_a, order, (size_t)n_rows, 0, size_bits, st));
   hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
   const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
   hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st, d_points,

@@ -17,7 +17,15 @@ def short(name: str) -> str:
     return ("at::native::" + m.group(1)) if m else name[:60]
 
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
-if "--pmc" in sys.argv:
+if "--timeline" in sys.argv:  # last N dispatches in launch order: start offset, duration, gap to the previous kernel
+    n = int(sys.argv[sys.argv.index("--timeline") + 1])
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    rows = cur.execute("select name, start, end from kernels order by start desc limit ?", (n,)).fetchall()[::-1]
+    t0, prev = rows[0][1], rows[0][1]
+    for name, st, en in rows:
+        print(f"{(st - t0) / 1e3:10.1f} us  dur {(en - st) / 1e3:9.1f}  gap {(st - prev) / 1e3:8.1f}  {short(name)}")
+        prev = en
+elif "--pmc" in sys.argv:
     rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), sum(value), avg(duration) from counters_collection group by kernel_name, counter_name").fetchall()
     agg = {}
     for n, c, cnt, av, sm, dur in rows:
