@@ -158,6 +158,8 @@ int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_a
  * `batch_normalization` + `into_affine` leave (ec.rs:251-299, 596-629).  inverse != 0: omega^-1 and the 1/m scaling.
  * Synchronises `stream` before returning. */
 int mi355zk_bn254_g1_point_fft_dev(void *d_points_affine, uint32_t log_n, int inverse, void *stream);
+/* the same over G2 (128-byte affine records; `coeffs_g2` of prepare_phase2.rs:102-105) */
+int mi355zk_bn254_g2_point_fft_dev(void *d_points_affine, uint32_t log_n, int inverse, void *stream);
 
 /* ---- batch fixed-base scalar multiplication out[i] = k[i] * P, affine (all-zero = infinity).
  * Building block of the per-point `batch_exp` path (powersoftau/src/batched_accumulator.rs:1130-1181,

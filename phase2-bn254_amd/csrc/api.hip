@@ -29,6 +29,8 @@ int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
 int point_fft_g1(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
+// point_fft_g2.hip
+int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
 int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
 int segsum_g2_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
 void msm_release_g1();
@@ -484,6 +486,14 @@ int mi355zk_bn254_g1_point_fft_dev(void* d_points_affine, uint32_t log_n, int in
   int rc = domain_consts(log_n, &D);
   if (rc) return rc;
   return point_fft_g1(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+}
+
+int mi355zk_bn254_g2_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {
+  if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
+  DomainConsts D;
+  int rc = domain_consts(log_n, &D);
+  if (rc) return rc;
+  return point_fft_g2(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
 }
 
 int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[8], const void* d_scalars, size_t n, void* stream) {

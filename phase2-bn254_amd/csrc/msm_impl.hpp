@@ -526,7 +526,9 @@ MsmGeom choose_geom(uint64_t n, int group) {
   for (uint32_t c = 4; c <= 24; ++c) {
     double W = std::ceil((254.0 + 1.0) / c);  // (W-1)*c + (c-1) >= 254
     double nbk = std::ldexp(1.0, (int)c - 1);
-    double cost = W * (10.0 * (double)n + 40.0 * nbk);
+    // per (point, window): one mixed add (10 units) + one radix-sort pass per 8 key bits (0.7 units each,
+    // measured); per bucket: ~45 units of reduction
+    double cost = W * ((10.0 + 0.7 * std::ceil(c / 8.0)) * (double)n + 45.0 * nbk);
     // occupancy term: fewer than ~2^17 bucket lanes leaves CUs idle during accumulation
     double lanes = W * nbk;
     if (lanes < 131072.0) cost *= (1.0 + 0.5 * (131072.0 / lanes - 1.0));

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mi355zk_bn254_g1_sparse_matvec_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_bn254_g2_sparse_matvec_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_bn254_g1_point_fft_dev": (_i, [_vp, _u32, _i, _vp]),
+    "mi355zk_bn254_g2_point_fft_dev": (_i, [_vp, _u32, _i, _vp]),
     "mi355zk_bn254_g1_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

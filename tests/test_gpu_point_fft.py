@@ -13,11 +13,12 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def _run(zk, pts, log_n, inverse):
+def _run(zk, pts, log_n, inverse, group=1):
     import torch
 
     d = torch.from_numpy(np.ascontiguousarray(pts).view(np.int64)).cuda()
-    assert zk.lib.load().mi355zk_bn254_g1_point_fft_dev(C.c_void_p(d.data_ptr()), log_n, inverse, None) == 0
+    fn = zk.lib.load().mi355zk_bn254_g1_point_fft_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_point_fft_dev
+    assert fn(C.c_void_p(d.data_ptr()), log_n, inverse, None) == 0
     return d.cpu().numpy().view(np.uint64)
 
 
@@ -55,3 +56,24 @@ def test_point_fft_roundtrip_and_lagrange_property(zk, worker):
         assert np.array_equal(lag[j], want), j
     back = _run(zk, lag, log_n, 0)
     assert np.array_equal(back, pts)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 3, 6])
+@pytest.mark.parametrize("op", ["fft", "ifft"])
+def test_g2_point_fft_matches_oracle(zk, worker, log_n, op):
+    """The G2 leg of prepare_phase2 (coeffs_g2): bit exact against the oracle's Point<G2> FFT + batch_normalization."""
+    n = 1 << log_n
+    pts = inputs.bases_progression_cpu(2, n, seed=60 + log_n)
+    if n >= 4:
+        pts[2] = 0  # an infinity coefficient
+    want = O.point_domain_op(2, pts, log_n, op)
+    got = _run(zk, pts, log_n, 1 if op == "ifft" else 0, group=2)
+    assert np.array_equal(got, want)
+
+
+def test_g2_point_fft_roundtrip(zk, worker):
+    log_n = 9
+    pts = inputs.bases_progression_cpu(2, 1 << log_n, seed=71)
+    lag = _run(zk, pts, log_n, 1, group=2)
+    assert not np.array_equal(lag, pts)
+    assert np.array_equal(_run(zk, lag, log_n, 0, group=2), pts)

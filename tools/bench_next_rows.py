@@ -63,4 +63,17 @@ for ln in (12, 16, a.log_n):
     dt = time.perf_counter() - t
     assert L.mi355zk_bn254_g1_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 0, None) == 0
     out[f"g1_point_ifft_2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mbutterfly_per_s": round(m / 2 * ln / dt / 1e6, 2), "fft_of_ifft_is_identity": bool(torch.equal(pts, ref))}
+for ln in (12, min(a.log_n, 18)):  # G2 leg (coeffs_g2)
+    m = 1 << ln
+    k = bench.gen_scalars(m, 52, dev)
+    pts = torch.empty((m, 16), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G2_GEN_RAW)
+    assert L.mi355zk_bn254_g2_batch_mul_dev(C.c_void_p(pts.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), m, None) == 0
+    torch.cuda.synchronize()
+    ref = pts.clone()
+    t = time.perf_counter()
+    assert L.mi355zk_bn254_g2_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 1, None) == 0
+    dt = time.perf_counter() - t
+    assert L.mi355zk_bn254_g2_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 0, None) == 0
+    out[f"g2_point_ifft_2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mbutterfly_per_s": round(m / 2 * ln / dt / 1e6, 2), "fft_of_ifft_is_identity": bool(torch.equal(pts, ref))}
 print(json.dumps(out))
