@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): collects everything profiles/ is built from into gpurun_out/refresh/.
+#   tools/refresh_profiles.sh            then locally: python tools/refresh_profiles_post.py
+set -u
+R=/root/repo
+O=$R/gpurun_out/refresh
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py"
+timeout 400 $B > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 200 $B --log-n 20 --steps 20 --warmup 3 > $O/bench_2e20.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace -d /tmp/p_kt -- $B --steps 3 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_kt -name "*.db" | head -1) > $O/msm26_kernel_stats.txt
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -- $B --steps 1 --warmup 0 --no-cpu-baseline > $O/pf.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -- $B --steps 1 --warmup 0 --no-cpu-baseline > $O/pw.log 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_f -name "*.db" | head -1) --pmc > $O/msm26_pmc_fetch.txt
+python $R/tools/rocpd_summary.py $(find /tmp/p_w -name "*.db" | head -1) --pmc > $O/msm26_pmc_write.txt
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY -d /tmp/p_s -- $B --steps 1 --warmup 0 --no-cpu-baseline > $O/ps.log 2>&1
+python $R/tools/pmc_kernel.py $(find /tmp/p_s -name "*.db" | head -1) msm_accumulate_kernel > $O/msm26_accumulate_sq_pmc.txt
+timeout 300 rocprofv3 --kernel-trace -d /tmp/p_ntt -- python $R/tools/bench_ntt.py --check > $O/ntt20.json 2> $O/ntt.err
+python $R/tools/rocpd_summary.py $(find /tmp/p_ntt -name "*.db" | head -1) > $O/ntt20_kernel_stats.txt
+timeout 300 python $R/tools/bench_g2.py > $O/g2_2e20.json 2>/dev/null
+timeout 400 python $R/tools/bench_next_rows.py --log-n 20 > $O/next_rows_2e20.json 2>/dev/null
+ls -la $O

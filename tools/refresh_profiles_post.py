@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Local step after `gpurun -- bash tools/refresh_profiles.sh`: copies the summaries from gpurun_out/refresh/ into
+profiles/ (round-tagged names) and rebuilds profiles/latest_pmc.json, which bench.py reports as roofline.traffic."""
+import json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "refresh"); DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+def put(src, dst, header=None):
+    body = open(os.path.join(SRC, src)).read()
+    with open(os.path.join(DST, f"{tag}_{dst}"), "w") as f:
+        if header: f.write(header)
+        f.write(body)
+put("bench_n1.json", "bench_n1.json"); put("bench_2e20.json", "bench_2e20.json"); put("g2_2e20.json", "g2_2e20.json")
+put("next_rows_2e20.json", "next_rows_2e20.json"); put("ntt20.json", "ntt20.json")
+put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
+    "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, 2^26-point G1 MSM)\n"
+    "# summarised from the rocpd database with tools/rocpd_summary.py (ROCm 7.2 rocprofv3 writes rocpd; same numbers as --stats)\n"
+    "# batch_exp_kernel = synthetic-input generation (outside the timed region); every msm_* launch is a full-size step\n"
+    "# (1 warm-up + 3 timed + 2 of the linearity check); msm_accumulate_kernel is the dominant kernel of a step\n")
+put("ntt20_kernel_stats.txt", "ntt20_kernel_stats.txt", "# rocprofv3 --kernel-trace -- python tools/bench_ntt.py --check   (MI355X, 2^20 Fr NTT, 20 iterations x 4 ops)\n")
+put("msm26_accumulate_sq_pmc.txt", "msm26_accumulate_sq_pmc.txt", "# rocprofv3 --pmc SQ_* (one pass, 8 counters) on msm_accumulate_kernel<Fq>, 2^26 points, MI355X\n")
+with open(os.path.join(DST, f"{tag}_msm26_pmc_hbm.txt"), "w") as f:
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline  (MI355X)\n"
+            "# unit: KB per dispatch; gfx950 FETCH_SIZE under-reports 16 B/lane reads by 2x (MI355X_MICROARCH.md HBM section) --\n"
+            "# cross-check: msm_digits_kernel reads 2 GiB of scalars + 4 GiB of bases = 6.44e9 B and reports 3.146e6 KB\n")
+    f.write(open(os.path.join(SRC, "msm26_pmc_fetch.txt")).read())
+    f.write("".join(l for l in open(os.path.join(SRC, "msm26_pmc_write.txt")) if not l.startswith("kernel ")))
+def counter(path, kernel):
+    for l in open(os.path.join(SRC, path)):
+        if l.startswith(kernel + " "): return float(l.split()[3])
+    raise SystemExit(f"{kernel} not in {path}")
+fetch = counter("msm26_pmc_fetch.txt", "zk::msm_accumulate_kernel<Fq>"); write = counter("msm26_pmc_write.txt", "zk::msm_accumulate_kernel<Fq>")
+json.dump({"round": 1, "workload_log_n": 26, "n_gpus": 1, "kernel": "msm_accumulate_kernel<Fq>", "FETCH_SIZE_KB_per_launch": fetch,
+           "WRITE_SIZE_KB_per_launch": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+           "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{tag}_msm26_pmc_hbm.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                  "with the gfx950 2x FETCH_SIZE correction for 16 B/lane loads (MI355X_MICROARCH.md, HBM section)"},
+          open(os.path.join(DST, "latest_pmc.json"), "w"), indent=1)
+print(open(os.path.join(DST, "latest_pmc.json")).read())
