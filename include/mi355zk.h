@@ -152,6 +152,24 @@ int mi355zk_bn254_g1_sparse_matvec_dev(void *d_out_affine, const void *d_bases_a
 int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, const uint32_t *d_row_ptr, const uint32_t *d_col,
                                        const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
 
+/* ---- point codecs: the reference's wire encodings <-> raw affine records.
+ * Replaces EncodedPoint::{into_affine, into_affine_unchecked, from_affine} for G1Uncompressed (64 B), G1Compressed
+ * (32 B), G2Uncompressed (128 B), G2Compressed (64 B)  (pairing/src/bn256/ec.rs:763-946, 1136-1344), which
+ * powersoftau applies to every element of an accumulator file (batched_accumulator.rs read_points_chunk /
+ * write_point): big-endian canonical coordinates, Fq2 as c1 || c0, byte 0 bit 7 = "y is the larger root"
+ * (compressed), bit 6 = infinity.  n records, device pointers (byte buffers 4-byte aligned), one record per point;
+ * the all-zero raw record is the point at infinity.  checked != 0: into_affine (on-curve test for uncompressed
+ * input; decompression is on the curve by construction -- for G2 up to the reference's Fq2::sqrt quirk, which is
+ * reproduced).  decode returns 0, or the GroupDecodingError of the FIRST failing record with its index in
+ * *err_index (may be NULL): 4 NotOnCurve, 6 CoordinateDecodingError, 7 UnexpectedCompressionMode,
+ * 8 UnexpectedInformation; failing records decode to infinity.  decode synchronises `stream`; encode is asynchronous. */
+int mi355zk_bn254_g1_decode_dev(void *d_out_affine, const void *d_in_bytes, size_t n, int compressed, int checked, void *stream,
+                                long long *err_index);
+int mi355zk_bn254_g2_decode_dev(void *d_out_affine, const void *d_in_bytes, size_t n, int compressed, int checked, void *stream,
+                                long long *err_index);
+int mi355zk_bn254_g1_encode_dev(void *d_out_bytes, const void *d_in_affine, size_t n, int compressed, void *stream);
+int mi355zk_bn254_g2_encode_dev(void *d_out_bytes, const void *d_in_affine, size_t n, int compressed, void *stream);
+
 /* ---- FFT over curve points: EvaluationDomain<Point<G1>>::fft / ifft (bellman/src/group.rs:22-51
  * under domain.rs:154-173), the Lagrange-basis conversion of powersoftau/src/bin/prepare_phase2.rs:68-131.  In
  * place on 2^log_n AFFINE raw records (64 B, all-zero = infinity); the output is normalised to affine, i.e. what

@@ -257,6 +257,8 @@ static inline void g2pt_sub(g2_jac_t *r, const g2_jac_t *a, const g2_jac_t *b) {
 #define T_MULS(r, a, b) g2pt_muls(r, a, b)
 #include "tmpl_fft.h"
 
+#include "codec.h"
+
 /* ================================================================== exported C API (ctypes) */
 #define EXPORT __attribute__((visibility("default")))
 
@@ -418,3 +420,32 @@ EXPORT int oracle_g2_point_domain_op(uint64_t *pts, uint32_t log_n, int op, uint
   return 0;
 }
 EXPORT uint32_t oracle_dummy_domain_omega(uint32_t log_n) { dfft_domain_t d; if (dfft_domain_init(&d, log_n)) return 0; return d.omega; }
+
+/* ---- point codecs (codec.h): n records; returns the first failing record's code and index, or 0 */
+EXPORT int oracle_g1_decode(uint64_t *out_affine, const uint8_t *in, size_t n, int compressed, int checked, long long *err_index) {
+  size_t sz = compressed ? 32 : 64;
+  for (size_t i = 0; i < n; ++i) {
+    int rc = g1_decode((g1_affine_t *)(out_affine + 8 * i), in + sz * i, compressed, checked);
+    if (rc) { if (err_index) *err_index = (long long)i; return rc; }
+  }
+  return 0;
+}
+EXPORT void oracle_g1_encode(uint8_t *out, const uint64_t *affine, size_t n, int compressed) {
+  size_t sz = compressed ? 32 : 64;
+  for (size_t i = 0; i < n; ++i) g1_encode(out + sz * i, (const g1_affine_t *)(affine + 8 * i), compressed);
+}
+EXPORT int oracle_g2_decode(uint64_t *out_affine, const uint8_t *in, size_t n, int compressed, int checked, long long *err_index) {
+  size_t sz = compressed ? 64 : 128;
+  for (size_t i = 0; i < n; ++i) {
+    int rc = g2_decode((g2_affine_t *)(out_affine + 16 * i), in + sz * i, compressed, checked);
+    if (rc) { if (err_index) *err_index = (long long)i; return rc; }
+  }
+  return 0;
+}
+EXPORT void oracle_g2_encode(uint8_t *out, const uint64_t *affine, size_t n, int compressed) {
+  size_t sz = compressed ? 64 : 128;
+  for (size_t i = 0; i < n; ++i) g2_encode(out + sz * i, (const g2_affine_t *)(affine + 16 * i), compressed);
+}
+EXPORT int oracle_fq_sqrt(uint64_t r[4], const uint64_t a[4]) { return fq_sqrt((fe_t *)r, (const fe_t *)a); }
+EXPORT int oracle_fq2_sqrt(uint64_t r[8], const uint64_t a[8]) { return fq2_sqrt_ref((fe2_t *)r, (const fe2_t *)a); }
+EXPORT void oracle_g2_coeff_b(uint64_t r[8]) { g2_coeff_b((fe2_t *)r); }

@@ -29,6 +29,9 @@ int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
 int point_fft_g1(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
+// codec.hip
+int codec_decode(int group, void* d_out, const void* d_in, size_t n, int compressed, int checked, hipStream_t st, long long* err_index);
+int codec_encode(int group, void* d_out, const void* d_in, size_t n, int compressed, hipStream_t st);
 // point_fft_g2.hip
 int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
 int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
@@ -486,6 +489,24 @@ int mi355zk_bn254_g1_point_fft_dev(void* d_points_affine, uint32_t log_n, int in
   int rc = domain_consts(log_n, &D);
   if (rc) return rc;
   return point_fft_g1(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+}
+
+// point codecs (ec.rs:763-946, 1136-1344): wire encodings <-> raw affine records
+int mi355zk_bn254_g1_decode_dev(void* d_out_affine, const void* d_in_bytes, size_t n, int compressed, int checked, void* stream, long long* err_index) {
+  if ((n && (!d_out_affine || !d_in_bytes)) || ((uintptr_t)d_in_bytes & 3)) return ZK_ERR_BAD_ARGS;
+  return codec_decode(1, d_out_affine, d_in_bytes, n, compressed, checked, (hipStream_t)stream, err_index);
+}
+int mi355zk_bn254_g2_decode_dev(void* d_out_affine, const void* d_in_bytes, size_t n, int compressed, int checked, void* stream, long long* err_index) {
+  if ((n && (!d_out_affine || !d_in_bytes)) || ((uintptr_t)d_in_bytes & 3)) return ZK_ERR_BAD_ARGS;
+  return codec_decode(2, d_out_affine, d_in_bytes, n, compressed, checked, (hipStream_t)stream, err_index);
+}
+int mi355zk_bn254_g1_encode_dev(void* d_out_bytes, const void* d_in_affine, size_t n, int compressed, void* stream) {
+  if ((n && (!d_out_bytes || !d_in_affine)) || ((uintptr_t)d_out_bytes & 3)) return ZK_ERR_BAD_ARGS;
+  return codec_encode(1, d_out_bytes, d_in_affine, n, compressed, (hipStream_t)stream);
+}
+int mi355zk_bn254_g2_encode_dev(void* d_out_bytes, const void* d_in_affine, size_t n, int compressed, void* stream) {
+  if ((n && (!d_out_bytes || !d_in_affine)) || ((uintptr_t)d_out_bytes & 3)) return ZK_ERR_BAD_ARGS;
+  return codec_encode(2, d_out_bytes, d_in_affine, n, compressed, (hipStream_t)stream);
 }
 
 int mi355zk_bn254_g2_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {

@@ -73,9 +73,55 @@ struct Fp {
   ZK_HD bool operator!=(const Fp& b) const { return !(*this == b); }
 };
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+#define ZK_HOST64 1
+// Host side (the window join of every multiexp, the g*_add / to_affine helpers): the same 8 x u32 limbs viewed as
+// 4 x u64 with carries through unsigned __int128 -- about 2x the 32-bit loops below, which the device keeps.
+namespace host64 {
+typedef unsigned __int128 u128;
+template <class PR>
+inline void load(const Fp<PR>& a, uint64_t o[4]) {
+  for (int i = 0; i < 4; ++i) o[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+}
+template <class PR>
+inline Fp<PR> store(const uint64_t t[4]) {
+  Fp<PR> r;
+  for (int i = 0; i < 4; ++i) {
+    r.l[2 * i] = (uint32_t)t[i];
+    r.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+  }
+  return r;
+}
+template <class PR>
+inline void modulus(uint64_t P[4]) {
+  for (int i = 0; i < 4; ++i) P[i] = (uint64_t)PR::P[2 * i] | ((uint64_t)PR::P[2 * i + 1] << 32);
+}
+// t = t - p if t >= p  (t < 2p)
+template <class PR>
+inline void reduce_once(uint64_t t[4]) {
+  uint64_t P[4], d[4];
+  modulus<PR>(P);
+  u128 b = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 x = (u128)t[i] - P[i] - (uint64_t)b;
+    d[i] = (uint64_t)x;
+    b = (x >> 64) & 1;
+  }
+  if (!b)
+    for (int i = 0; i < 4; ++i) t[i] = d[i];
+}
+}  // namespace host64
+#endif
+
 // r = a - p if a >= p else a   (a < 2p)
 template <class PR>
 ZK_HD Fp<PR> reduce_once(const Fp<PR>& a) {
+#ifdef ZK_HOST64
+  uint64_t t64[4];
+  host64::load(a, t64);
+  host64::reduce_once<PR>(t64);
+  return host64::store<PR>(t64);
+#endif
   Fp<PR> t;
   uint64_t borrow = 0;
 #pragma unroll
@@ -92,6 +138,19 @@ ZK_HD Fp<PR> reduce_once(const Fp<PR>& a) {
 
 template <class PR>
 ZK_HD Fp<PR> add(const Fp<PR>& a, const Fp<PR>& b) {
+#ifdef ZK_HOST64
+  uint64_t A[4], B[4];
+  host64::load(a, A);
+  host64::load(b, B);
+  host64::u128 cy = 0;
+  for (int i = 0; i < 4; ++i) {
+    cy += (host64::u128)A[i] + B[i];
+    A[i] = (uint64_t)cy;
+    cy >>= 64;
+  }
+  host64::reduce_once<PR>(A);
+  return host64::store<PR>(A);
+#endif
   Fp<PR> t;
   uint64_t c = 0;
 #pragma unroll
@@ -114,6 +173,27 @@ ZK_HD Fp<PR> dbl(const Fp<PR>& a) {
 
 template <class PR>
 ZK_HD Fp<PR> sub(const Fp<PR>& a, const Fp<PR>& b) {
+#ifdef ZK_HOST64
+  uint64_t A[4], B[4], P[4];
+  host64::load(a, A);
+  host64::load(b, B);
+  host64::modulus<PR>(P);
+  host64::u128 bw = 0;
+  for (int i = 0; i < 4; ++i) {
+    host64::u128 x = (host64::u128)A[i] - B[i] - (uint64_t)bw;
+    A[i] = (uint64_t)x;
+    bw = (x >> 64) & 1;
+  }
+  if (bw) {
+    host64::u128 cy = 0;
+    for (int i = 0; i < 4; ++i) {
+      cy += (host64::u128)A[i] + P[i];
+      A[i] = (uint64_t)cy;
+      cy >>= 64;
+    }
+  }
+  return host64::store<PR>(A);
+#endif
   Fp<PR> t;
   uint64_t borrow = 0;
 #pragma unroll
@@ -160,17 +240,16 @@ ZK_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
   return reduce_once(r);
 #elif !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
   // host: CIOS on 4 x 64-bit limbs (the same bytes viewed as u64) -- the window join of a multiexp runs a few
-  // hundred doublings on the host, so this path is worth its 4x over the 32-bit portable form below
-  uint64_t A[4], B[4], P[4], t[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; ++i) {
-    A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
-    B[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
-    P[i] = (uint64_t)PR::P[2 * i] | ((uint64_t)PR::P[2 * i + 1] << 32);
-  }
+  // hundred doublings on the host.  p < 2^254 leaves two spare bits, so the running value stays below 2^257 and the
+  // fifth word is a single carry word.
+  typedef unsigned __int128 u128;
+  uint64_t A[4], B[4], P[4], t[5] = {0, 0, 0, 0, 0};
+  host64::load(a, A);
+  host64::load(b, B);
+  host64::modulus<PR>(P);
   // -p^-1 mod 2^64 from -p^-1 mod 2^32 by one Newton step: x' = x * (2 + p0 * x)  (for x = -p0^-1)
   const uint64_t x32 = PR::INV;
   const uint64_t inv64 = x32 * (2 + P[0] * x32);
-  typedef unsigned __int128 u128;
   for (int i = 0; i < 4; ++i) {
     u128 c = 0;
     for (int j = 0; j < 4; ++j) {
@@ -178,9 +257,7 @@ ZK_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
       t[j] = (uint64_t)c;
       c >>= 64;
     }
-    c += t[4];
-    t[4] = (uint64_t)c;
-    t[5] = (uint64_t)(c >> 64);
+    uint64_t t4 = t[4] + (uint64_t)c;  // < 2^64: the value is < 2p * 2^64 ... see above
     uint64_t k = t[0] * inv64;
     c = (u128)k * P[0] + t[0];
     c >>= 64;
@@ -189,16 +266,13 @@ ZK_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
       t[j - 1] = (uint64_t)c;
       c >>= 64;
     }
-    c += t[4];
+    c += t4;
     t[3] = (uint64_t)c;
-    t[4] = t[5] + (uint64_t)(c >> 64);
+    t[4] = (uint64_t)(c >> 64);
   }
-  Fp<PR> r;
-  for (int i = 0; i < 4; ++i) {
-    r.l[2 * i] = (uint32_t)t[i];
-    r.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
-  }
-  return reduce_once(r);
+  // a, b < p  =>  t < 2p < 2^255: t[4] == 0
+  host64::reduce_once<PR>(t);
+  return host64::store<PR>(t);
 #else
   uint32_t t[10];
 #pragma unroll

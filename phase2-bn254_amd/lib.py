@@ -51,6 +51,10 @@ SIGNATURES = {
     "mi355zk_selftest_g2_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_sparse_matvec_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_bn254_g2_sparse_matvec_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "mi355zk_bn254_g1_decode_dev": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
+    "mi355zk_bn254_g2_decode_dev": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
+    "mi355zk_bn254_g1_encode_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "mi355zk_bn254_g2_encode_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
     "mi355zk_bn254_g1_point_fft_dev": (_i, [_vp, _u32, _i, _vp]),
     "mi355zk_bn254_g2_point_fft_dev": (_i, [_vp, _u32, _i, _vp]),
     "mi355zk_bn254_g1_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -16,7 +16,7 @@ _SO = os.path.join(_ROOT, "oracle", "_build", "liboracle.so")
 
 
 def build_oracle(force: bool = False) -> str:
-    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("bn254_oracle.c", "field.h", "tmpl_curve.h", "tmpl_multiexp.h", "tmpl_fft.h", "tmpl_fft_undef.h")]
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("bn254_oracle.c", "field.h", "tmpl_curve.h", "tmpl_multiexp.h", "tmpl_fft.h", "tmpl_fft_undef.h", "codec.h")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
@@ -302,3 +302,48 @@ def dummy_domain_op(a, log_n, op, log_cpus=31):
 
 def dummy_domain_omega(log_n):
     return int(lib().oracle_dummy_domain_omega(C.c_uint32(log_n)))
+
+
+# ---- point codecs (oracle/codec.h)
+ENC_SIZE = {(1, False): 64, (1, True): 32, (2, False): 128, (2, True): 64}
+
+
+def encode_points(group: int, affine, compressed: bool) -> np.ndarray:
+    """(n, 8g) raw affine records -> (n, size) uint8 wire records (EncodedPoint::from_affine)."""
+    G = G1 if group == 1 else G2
+    affine = _arr(affine).reshape(-1, G.aff)
+    out = np.zeros((affine.shape[0], ENC_SIZE[(group, bool(compressed))]), np.uint8)
+    fn = lib().oracle_g1_encode if group == 1 else lib().oracle_g2_encode
+    fn(out.ctypes.data_as(C.c_void_p), _p64(affine), C.c_size_t(affine.shape[0]), C.c_int(1 if compressed else 0))
+    return out
+
+
+def decode_points(group: int, data, compressed: bool, checked: bool = True):
+    """wire records -> (rc, err_index, (n, 8g) raw affine records); rc = 0 or the GroupDecodingError code of the first failure."""
+    G = G1 if group == 1 else G2
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, ENC_SIZE[(group, bool(compressed))])
+    out = np.zeros((data.shape[0], G.aff), np.uint64)
+    err = C.c_longlong(-1)
+    fn = lib().oracle_g1_decode if group == 1 else lib().oracle_g2_decode
+    fn.restype = C.c_int
+    rc = fn(_p64(out), data.ctypes.data_as(C.c_void_p), C.c_size_t(data.shape[0]), C.c_int(1 if compressed else 0), C.c_int(1 if checked else 0),
+            C.byref(err))
+    return rc, err.value, out
+
+
+def fq_sqrt(a):
+    a = _arr(a)
+    r = np.zeros(4, np.uint64)
+    return r if lib().oracle_fq_sqrt(_p64(r), _p64(a)) else None
+
+
+def fq2_sqrt(a):
+    a = _arr(a)
+    r = np.zeros(8, np.uint64)
+    return r if lib().oracle_fq2_sqrt(_p64(r), _p64(a)) else None
+
+
+def g2_coeff_b():
+    r = np.zeros(8, np.uint64)
+    lib().oracle_g2_coeff_b(_p64(r))
+    return r

@@ -63,6 +63,27 @@ for ln in (12, 16, a.log_n):
     dt = time.perf_counter() - t
     assert L.mi355zk_bn254_g1_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 0, None) == 0
     out[f"g1_point_ifft_2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mbutterfly_per_s": round(m / 2 * ln / dt / 1e6, 2), "fft_of_ifft_is_identity": bool(torch.equal(pts, ref))}
+# row 4: point codecs (accumulator files): encode, then decode (compressed = one sqrt per point)
+for g, limbs in ((1, 8), (2, 16)):
+    m = n if g == 1 else n // 4
+    k = bench.gen_scalars(m, 71 + g, dev)
+    pts = torch.empty((m, limbs), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW if g == 1 else inputs.G2_GEN_RAW)
+    mul = L.mi355zk_bn254_g1_batch_mul_dev if g == 1 else L.mi355zk_bn254_g2_batch_mul_dev
+    assert mul(C.c_void_p(pts.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), m, None) == 0
+    enc_f = L.mi355zk_bn254_g1_encode_dev if g == 1 else L.mi355zk_bn254_g2_encode_dev
+    dec_f = L.mi355zk_bn254_g1_decode_dev if g == 1 else L.mi355zk_bn254_g2_decode_dev
+    for comp in (0, 1):
+        enc = torch.zeros((m, (32 if comp else 64) * g), dtype=torch.uint8, device=dev)
+        back = torch.zeros_like(pts)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(a.iters): assert enc_f(C.c_void_p(enc.data_ptr()), C.c_void_p(pts.data_ptr()), m, comp, None) == 0
+        torch.cuda.synchronize(); te = (time.perf_counter() - t) / a.iters
+        t = time.perf_counter()
+        for _ in range(a.iters): assert dec_f(C.c_void_p(back.data_ptr()), C.c_void_p(enc.data_ptr()), m, comp, 1, None, None) == 0
+        td = (time.perf_counter() - t) / a.iters
+        out[f"g{g}_codec_{'compressed' if comp else 'uncompressed'}"] = {"points": m, "encode_ms": round(te * 1e3, 3), "decode_checked_ms": round(td * 1e3, 3),
+                                                                          "decode_Mpoint_per_s": round(m / td / 1e6, 1), "roundtrip_ok": bool(torch.equal(back, pts))}
 for ln in (12, min(a.log_n, 18)):  # G2 leg (coeffs_g2)
     m = 1 << ln
     k = bench.gen_scalars(m, 52, dev)
