@@ -321,3 +321,60 @@ def test_sparse_matvec_qap_evaluation(zk, worker, group):
         for t in range(row_ptr[r], row_ptr[r + 1]):
             acc = G.add(acc, G.mul(G.from_affine(bases[col[t]]), coeff[t]))
         assert np.array_equal(got[r], G.to_affine(acc)), r
+
+
+def test_baseline_size_2e26_closed_form_and_linearity(zk, worker):
+    """BASELINE.json's headline size: 2^26 points resident in HBM (4 GiB of bases + 2 GiB of scalars).
+    Size-independent checks at the FULL size:
+      - closed form: the bases are k_i*G, so MSM == (sum_i s_i*k_i mod r) * G.  The 2^26-term dot product is taken
+        on the device as a checksum of checksums: t_i = s_i*k_i/R (the pointwise Montgomery product on the canonical
+        limbs), and sum_i t_i is output 0 of a 2^26-point fft of t (X[0] = sum a_i) -- two kernels that are
+        parity-tested on their own;
+      - linearity in the exponents: MSM(s) == MSM(a) + MSM(s - a);
+      - additivity over point ranges through the Source offset: MSM(all) == MSM(first half) + MSM(second half)."""
+    import torch
+
+    import bench
+    import bn254_model as M
+
+    log_n = 26
+    n = 1 << log_n
+    L = zk.lib.load()
+    dev = torch.device("cuda", 0)
+    shard = 1 << 20
+    scalars = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    k = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    bases = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    for s in range(n // shard):
+        scalars[s * shard:(s + 1) * shard] = bench.gen_scalars(shard, 7_000_003 * s + 5, dev)
+        k[s * shard:(s + 1) * shard] = bench.gen_scalars(shard, 9_000_011 * s + 3, dev)
+    assert L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+    torch.cuda.synchronize()
+    total = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    # closed form
+    t = scalars.clone()
+    assert L.mi355zk_bn254_fr_mul_assign_dev(C.c_void_p(t.data_ptr()), C.c_void_p(k.data_ptr()), n, None) == 0
+    assert L.mi355zk_bn254_fr_domain_op_dev(C.c_void_p(t.data_ptr()), log_n, 0, None) == 0
+    torch.cuda.synchronize()
+    x0 = M.from_limbs([int(v) for v in t[0].cpu().numpy().view(np.uint64)])
+    del t, k
+    dot = x0 * M.MONT_R % M.R_ORDER
+    want = O.G1.mul(O.G1.from_affine(inputs.G1_GEN_RAW), M.to_limbs(dot))
+    assert np.array_equal(O.G1.to_affine(total), O.G1.to_affine(want))
+    # linearity
+    a = torch.empty_like(scalars)
+    for s in range(n // shard):
+        a[s * shard:(s + 1) * shard] = bench.gen_scalars(shard, 11_000_027 * s + 1, dev)
+    b = scalars.clone()
+    assert L.mi355zk_bn254_fr_sub_assign_dev(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, None) == 0
+    torch.cuda.synchronize()
+    pa = zk.multiexp(worker, (bases, 0), zk.FullDensity(), a).wait()
+    pb = zk.multiexp(worker, (bases, 0), zk.FullDensity(), b).wait()
+    del a, b
+    assert np.array_equal(O.G1.to_affine(zk.shard.join_partials(np.stack([pa, pb]))), O.G1.to_affine(total))
+    # additivity over point ranges
+    h = n // 2
+    lo = zk.multiexp(worker, (bases[:h], 0), zk.FullDensity(), scalars[:h]).wait()
+    hi = zk.multiexp(worker, (bases, h), zk.FullDensity(), scalars[h:]).wait()
+    assert np.array_equal(O.G1.to_affine(zk.shard.join_partials(np.stack([lo, hi]))), O.G1.to_affine(total))
