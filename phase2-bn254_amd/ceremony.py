@@ -1,0 +1,149 @@
+"""Host-side mirror of the ceremony-side callers next to the hot path; thin wrappers over the
+C ABI for device-resident data (torch CUDA tensors of dtype int64/uint8), same names and argument meaning as the
+reference functions they replace:
+
+  batch_exp(bases, exps)                   powersoftau/src/batched_accumulator.rs:1130-1181 (exp_i * coeff folded by the caller)
+  batch_exp(bases, coeff, same_scalar)     phase2/src/parameters.rs:423-470 (every point by delta^-1)
+  dense_multiexp(bases, exponents)         powersoftau/src/utils.rs:189-292
+  merge_pairs(v1, v2, rho)                 powersoftau/src/utils.rs:112-131, phase2/src/utils.rs:59-105 (rho drawn by the caller)
+  power_pairs(v, rho)                      powersoftau/src/utils.rs:133-135
+  eval_qap(bases, row_ptr, col, coeff)     the per-variable sums of MPCParameters::new, phase2/src/parameters.rs:225-294
+  point_fft / point_ifft(points)           EvaluationDomain<Point<G>>::{fft, ifft}, powersoftau/src/bin/prepare_phase2.rs:68-131
+  decode_points / encode_points            EncodedPoint::{into_affine[_unchecked], from_affine}, pairing/src/bn256/ec.rs:763-946, 1136-1344
+
+Points are raw affine records (n x 8 int64 for G1, n x 16 for G2; all-zero = infinity), scalars canonical FrRepr
+(n x 4 int64).  The group (1 or 2) is taken from the record width.  Work is issued on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .bellman import DeviceError, _stream_ptr
+
+
+class GroupDecodingError(Exception):
+    """pairing/src/lib.rs GroupDecodingError, as raised by EncodedPoint::into_affine."""
+
+    KINDS = {4: "NotOnCurve", 5: "NotInSubgroup", 6: "CoordinateDecodingError", 7: "UnexpectedCompressionMode", 8: "UnexpectedInformation"}
+
+    def __init__(self, code: int, index: int):
+        super().__init__(f"{self.KINDS.get(code, code)} at point {index}")
+        self.kind = self.KINDS.get(code, str(code))
+        self.index = index
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _group(points) -> int:
+    w = points.shape[-1]
+    if w not in (8, 16):
+        raise ValueError("points must be (n, 8) G1 or (n, 16) G2 raw affine records")
+    return w // 8
+
+
+def _fn(name: str, group: int):
+    return getattr(_lib.load(), f"mi355zk_bn254_g{group}_{name}")
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise DeviceError(f"{what} failed (rc={rc})")
+
+
+def batch_exp(bases, exps, same_scalar: bool = False):
+    """out[i] = exps[i] * bases[i]  (same_scalar: exps is one scalar applied to every point); affine, normalised."""
+    import torch
+
+    g = _group(bases)
+    out = torch.empty_like(bases)
+    _check(_fn("batch_exp_dev", g)(_p(out), _p(bases), _p(exps), bases.shape[0], 1 if same_scalar else 0, _stream_ptr()), "batch_exp")
+    return out
+
+
+def _to_host_point(g: int):
+    return np.zeros(12 * g, dtype=np.uint64)
+
+
+def dense_multiexp(bases, exponents) -> np.ndarray:
+    """sum_i exponents[i] * bases[i] with powersoftau's contract (infinity bases add nothing); Jacobian limbs on the host."""
+    g = _group(bases)
+    out = _to_host_point(g)
+    _check(_fn("dense_multiexp_dev", g)(_p(bases), _p(exponents), bases.shape[0], _stream_ptr(), out.ctypes.data_as(C.c_void_p)), "dense_multiexp")
+    return out
+
+
+def merge_pairs(v1, v2, rho):
+    """(sum rho_i * v1[i], sum rho_i * v2[i]) from one digit extraction and one sort; Jacobian limbs on the host."""
+    g = _group(v1)
+    s, sx = _to_host_point(g), _to_host_point(g)
+    _check(_fn("merge_pairs_dev", g)(_p(v1), _p(v2), _p(rho), v1.shape[0], _stream_ptr(), s.ctypes.data_as(C.c_void_p),
+                                     sx.ctypes.data_as(C.c_void_p)), "merge_pairs")
+    return s, sx
+
+
+def power_pairs(v, rho):
+    """merge_pairs(v[:-1], v[1:]) (utils.rs:133-135); rho has len(v) - 1 scalars."""
+    return merge_pairs(v[:-1], v[1:], rho)
+
+
+def eval_qap(bases, row_ptr, col, coeff):
+    """out[v] = sum over the terms t of variable v of coeff[t] * bases[col[t]] (CSR: row_ptr int32 (n_rows + 1), col int32), affine."""
+    import torch
+
+    g = _group(bases)
+    n_rows = row_ptr.shape[0] - 1
+    out = torch.zeros((n_rows, 8 * g), dtype=bases.dtype, device=bases.device)
+    _check(_fn("sparse_matvec_dev", g)(_p(out), _p(bases), _p(row_ptr), _p(col), _p(coeff), n_rows, col.shape[0], _stream_ptr()), "eval_qap")
+    return out
+
+
+def _point_fft(points, inverse: int):
+    g = _group(points)
+    n = points.shape[0]
+    if n == 0 or n & (n - 1):
+        raise ValueError("the number of points must be a power of two")
+    _check(_fn("point_fft_dev", g)(_p(points), n.bit_length() - 1, inverse, _stream_ptr()), "point fft")
+    return points
+
+
+def point_fft(points):
+    """in place; returns its argument"""
+    return _point_fft(points, 0)
+
+
+def point_ifft(points):
+    """in place, including the 1/m scaling and the normalisation to affine (prepare_phase2.rs:102-131)"""
+    return _point_fft(points, 1)
+
+
+_ENC_SIZE = {(1, False): 64, (1, True): 32, (2, False): 128, (2, True): 64}
+
+
+def encode_points(points, compressed: bool):
+    import torch
+
+    g = _group(points)
+    out = torch.zeros((points.shape[0], _ENC_SIZE[(g, bool(compressed))]), dtype=torch.uint8, device=points.device)
+    _check(_fn("encode_dev", g)(_p(out), _p(points), points.shape[0], 1 if compressed else 0, _stream_ptr()), "encode_points")
+    return out
+
+
+def decode_points(data, group: int, compressed: bool, checked: bool = True):
+    """(n, size) uint8 wire records -> (n, 8 * group) raw affine records; raises GroupDecodingError for the first bad record."""
+    import torch
+
+    size = _ENC_SIZE[(group, bool(compressed))]
+    if data.shape[-1] != size:
+        raise ValueError(f"expected records of {size} bytes")
+    out = torch.empty((data.shape[0], 8 * group), dtype=torch.int64, device=data.device)
+    idx = C.c_longlong(-1)
+    rc = _fn("decode_dev", group)(_p(out), _p(data), data.shape[0], 1 if compressed else 0, 1 if checked else 0, _stream_ptr(), C.byref(idx))
+    if rc in GroupDecodingError.KINDS:
+        raise GroupDecodingError(rc, idx.value)
+    _check(rc, "decode_points")
+    return out

@@ -1,0 +1,81 @@
+"""The ceremony-side mirror (phase2-bn254_amd/ceremony.py) driven the way the reference's own tests drive the functions
+it replaces: powersoftau/src/utils.rs:90-109 `test_power_pairs` (the pairing check `same_ratio(.., (g2, g2^x))` is
+replaced by the equivalent statement with the known x: sx == x * s), the tau-power `batch_exp` of
+batched_accumulator.rs:1130-1181, the QAP sums of parameters.rs:281-294 and a codec round trip with its error."""
+import numpy as np
+import pytest
+
+import bn254_model as M
+import inputs
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _limbs(v):
+    return np.array(M.to_limbs(v % M.R_ORDER), dtype=np.uint64)
+
+
+def test_power_pairs_like_the_reference(zk, worker):
+    x = 0x1F3C5A7E9B2D4F60718293A4B5C6D7E8F9 % M.R_ORDER
+    powers = np.stack([_limbs(pow(x, i, M.R_ORDER)) for i in range(100)])
+    one = _dev(np.tile(inputs.G1_GEN_RAW, (100, 1)))
+    v = zk.ceremony.batch_exp(one, _dev(powers))                      # v[i] = x^i * G, affine (utils.rs:94-100)
+    assert np.array_equal(_host(v)[:3], O.G1.mul_many_affine(inputs.G1_GEN_RAW, powers[:3]))
+    rho = _dev(inputs.random_scalars(99, seed=801))
+    s, sx = zk.ceremony.power_pairs(v, rho)
+    assert np.array_equal(O.G1.to_affine(sx), O.G1.to_affine(O.G1.mul(s, _limbs(x))))          # same_ratio(power_pairs(v), (g2, g2^x))
+    hv = _host(v).copy()
+    hv[1] = O.G1.to_affine(O.G1.mul(O.G1.from_affine(hv[1]), _limbs(12345)))                    # utils.rs:106
+    s2, sx2 = zk.ceremony.power_pairs(_dev(hv), rho)
+    assert not np.array_equal(O.G1.to_affine(sx2), O.G1.to_affine(O.G1.mul(s2, _limbs(x))))
+
+
+def test_contribute_like_batch_exp_same_scalar_g2(zk, worker):
+    pts = inputs.bases_progression_cpu(2, 20, seed=810)
+    delta_inv = _limbs(pow(0xDEADBEEFCAFE, -1, M.R_ORDER))
+    out = zk.ceremony.batch_exp(_dev(pts), _dev(delta_inv.reshape(1, 4)), same_scalar=True)     # parameters.rs:423-470
+    for i in (0, 7, 19):
+        assert np.array_equal(_host(out)[i], O.G2.to_affine(O.G2.mul(O.G2.from_affine(pts[i]), delta_inv)))
+
+
+def test_eval_qap_and_dense_multiexp(zk, worker):
+    bases = inputs.bases_progression_cpu(1, 16, seed=820)
+    row_ptr = np.array([0, 2, 2, 5], dtype=np.int32)
+    col = np.array([3, 9, 0, 15, 3], dtype=np.int32)
+    coeff = inputs.random_scalars(5, seed=821)
+    out = _host(zk.ceremony.eval_qap(_dev(bases), _dev(row_ptr), _dev(col), _dev(coeff)))
+    for r in range(3):
+        acc = O.G1.from_affine(np.zeros(8, np.uint64))
+        for t in range(row_ptr[r], row_ptr[r + 1]):
+            acc = O.G1.add(acc, O.G1.mul(O.G1.from_affine(bases[col[t]]), coeff[t]))
+        assert np.array_equal(out[r], O.G1.to_affine(acc))
+    ks = inputs.random_scalars(16, seed=822)
+    got = zk.ceremony.dense_multiexp(_dev(bases), _dev(ks))
+    assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(O.G1.naive_multiexp(bases, ks)))
+
+
+def test_codec_roundtrip_and_error(zk, worker):
+    pts = inputs.bases_progression_cpu(1, 33, seed=830)
+    enc = zk.ceremony.encode_points(_dev(pts), compressed=True)
+    assert np.array_equal(enc.cpu().numpy(), O.encode_points(1, pts, True))
+    back = zk.ceremony.decode_points(enc, 1, compressed=True)
+    assert np.array_equal(_host(back), pts)
+    bad = enc.clone()
+    bad[20, 0] = 0x7F                                               # infinity flag + stray bits
+    with pytest.raises(zk.ceremony.GroupDecodingError) as e:
+        zk.ceremony.decode_points(bad, 1, compressed=True)
+    assert e.value.kind == "UnexpectedInformation" and e.value.index == 20
+    lag = zk.ceremony.point_ifft(_dev(inputs.bases_progression_cpu(1, 8, seed=831)))
+    assert np.array_equal(_host(zk.ceremony.point_fft(lag)), inputs.bases_progression_cpu(1, 8, seed=831))
