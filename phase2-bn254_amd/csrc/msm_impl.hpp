@@ -141,14 +141,29 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 // 3. bucket boundaries in the sorted pair list; bucket id = window * nb + bucket
 __global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t c, uint32_t nb,
                                                         uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
-  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  uint32_t k = keys[j];
-  uint32_t field = k & ((1u << c) - 1u);
-  if (field >= nb) return;
-  uint32_t id = (k >> c) * nb + field;
-  if (j == 0 || keys[j - 1] != k) first[id] = (uint32_t)j;
-  if (j + 1 == m || keys[j + 1] != k) last[id] = (uint32_t)j + 1;
+  // four consecutive keys per lane (one 16-byte load) plus the two neighbours: a streaming pass over the keys
+  const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (j0 >= m) return;
+  uint32_t k[6];
+  if (j0 + 4 <= m) {
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + j0);
+    k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+  } else {
+    for (int t = 0; t < 4; ++t) k[1 + t] = j0 + t < m ? keys[j0 + t] : 0xffffffffu;
+  }
+  k[0] = j0 ? keys[j0 - 1] : ~k[1];
+  k[5] = j0 + 4 < m ? keys[j0 + 4] : ~k[4];
+  const uint32_t mask = (1u << c) - 1u;
+#pragma unroll
+  for (int t = 1; t <= 4; ++t) {
+    const uint64_t j = j0 + (uint64_t)(t - 1);
+    if (j >= m) break;
+    const uint32_t field = k[t] & mask;
+    if (field >= nb) continue;
+    const uint32_t id = (k[t] >> c) * nb + field;
+    if (k[t - 1] != k[t]) first[id] = (uint32_t)j;
+    if (j + 1 == m || k[t + 1] != k[t]) last[id] = (uint32_t)j + 1;
+  }
 }
 
 // 3b. buckets ordered by size (descending) so that the 64 lanes of a wave own buckets of (nearly) equal length --
@@ -657,7 +672,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   prof_begin(slot_sort, st);
   ZK_HIP(rocprim::radix_sort_pairs((void*)(ws + o_sort), sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, G.c, st));
-  hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, keys_b, m, G.c, G.nb, first, last);
+  hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, st, keys_b, m, G.c, G.nb, first, last);
   ZK_HIP(hipGetLastError());
   msm_order_by_size(first, last, n_buckets, size_hist, order, sizes_b, st);
   ZK_HIP(hipGetLastError());
