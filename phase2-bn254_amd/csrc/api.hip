@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -125,12 +127,16 @@ void prof_reset() {
 // the per-point `batch_exp` of the ceremony code (powersoftau/src/batched_accumulator.rs:1130-1181: point i
 // by its own tau-power; phase2/src/parameters.rs:423-470: every point by the same delta^-1) followed by the
 // normalisation to affine that `batch_normalization` performs there (ec.rs:251-299).  The reference uses
-// wNAF-4; the group element, hence the affine output, is the same for plain MSB-first double-and-add.
-// G1 runs on U-form arithmetic (curveu.hpp).
+// wNAF-4 and one inversion per chunk; the group element, hence the affine output, does not depend on the chain.
+//   G1: signed binary (NAF: one addition per three bits instead of two) on the U-form JACOBIAN accumulator of
+//       curveu.hpp (a doubling is 1071 mads against 1467 in XYZZ), X and Y parked in the output record and Z in a
+//       scratch array, then batch_normalize_kernel: 16 points per lane share one inversion (Montgomery's trick),
+//       which is what batch_normalization does with one inversion per CPU chunk.
+//   G2: MSB-first double-and-add on the memory-format XYZZ formulas, one inversion per point.
 template <class F>
 __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
                                                        const uint32_t* __restrict__ scalars, int same_scalar, uint64_t n,
-                                                       const uint32_t* __restrict__ base_index) {
+                                                       const uint32_t* __restrict__ base_index, F* __restrict__ zbuf) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -138,19 +144,45 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = sp[l];
   const Affine<F> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
-  XYZZ<F> res = XYZZ<F>::zero();
-  if (!base.is_zero()) {
-    bool found = false;
-    if constexpr (std::is_same<F, Fq>::value) {
-      XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
-      for (int bit = 255; bit >= 0; --bit) {
-        bool b = (s[bit >> 5] >> (bit & 31)) & 1;
-        if (found) acc = xyzzu_double(acc);
-        else found = b;
-        if (b) xyzzu_add_mixed(acc, base.x, base.y, false);
+  if constexpr (std::is_same<F, Fq>::value) {
+    JacU<FqParams> acc = JacU<FqParams>::zero();
+    if (!base.is_zero()) {
+      // NAF digits d_j = bit_{j+1}(3k) - bit_{j+1}(k):  pos = (3k >> 1) & ~(k >> 1),  neg = (k >> 1) & ~(3k >> 1)
+      uint32_t k3[9];
+      uint64_t carry = 0;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        uint64_t t = (uint64_t)s[l] * 3u + carry;
+        k3[l] = (uint32_t)t;
+        carry = t >> 32;
       }
-      res = xyzzu_to_std(acc);
-    } else {
+      k3[8] = (uint32_t)carry;
+      uint32_t pos[8], neg[8];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        uint32_t a = (k3[l] >> 1) | (k3[l + 1] << 31);
+        uint32_t b = (s[l] >> 1) | (l < 7 ? s[l + 1] << 31 : 0u);
+        pos[l] = a & ~b;
+        neg[l] = b & ~a;
+      }
+      const FqU C = UPow2<FqParams, 266>::get();           // x*2^256 * 2^266 / 2^261 = x * 2^261
+      const FqU x2 = u_mul(u_from_std(base.x), C);          // < 2p, N
+      const FqU y2 = u_mul(u_from_std(base.y), C);
+      bool found = false;
+      for (int bit = 255; bit >= 0; --bit) {
+        const bool p = (pos[bit >> 5] >> (bit & 31)) & 1, m = (neg[bit >> 5] >> (bit & 31)) & 1;
+        if (found) acc = jacu_double(acc);
+        else found = p;                                     // the leading NAF digit of a positive number is +1
+        if (p | m) jacu_add_mixed(acc, x2, y2, m);
+      }
+    }
+    const Jacobian<F> r = jacu_to_std(acc);
+    out[i] = Affine<F>{r.x, r.y};
+    zbuf[i] = r.z;
+  } else {
+    XYZZ<F> res = XYZZ<F>::zero();
+    if (!base.is_zero()) {
+      bool found = false;
       for (int bit = 255; bit >= 0; --bit) {
         bool b = (s[bit >> 5] >> (bit & 31)) & 1;
         if (found) res = xyzz_double(res);
@@ -158,8 +190,77 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
         if (b) xyzz_add_mixed(res, base.x, base.y, false);
       }
     }
+    out[i] = xyzz_to_affine(res);
   }
-  out[i] = xyzz_to_affine(res);
+}
+
+// io[i] = (X, Y) of a Jacobian point whose Z is z[i]  ->  the affine record (X / Z^2, Y / Z^3); Z == 0 -> all-zero record.
+// K consecutive points per lane share ONE inversion (prefix products, ec.rs:251-299's scheme).
+template <int K>
+__global__ void __launch_bounds__(256) batch_normalize_kernel(Affine<Fq>* __restrict__ io, const Fq* __restrict__ z, uint64_t n) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * K;
+  if (i0 >= n) return;
+  Fq pre[K];
+  Fq run = Fq::one();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    pre[k] = run;
+    if (i0 + k < n) {
+      const Fq zk = z[i0 + k];
+      if (!zk.is_zero()) run = mul(run, zk);
+    }
+  }
+  Fq inv_run = inv(run);
+#pragma unroll
+  for (int k = K - 1; k >= 0; --k) {
+    if (i0 + k >= n) continue;
+    const Fq zk = z[i0 + k];
+    Affine<Fq> p{Fq::zero(), Fq::zero()};
+    if (!zk.is_zero()) {
+      const Fq zi = mul(inv_run, pre[k]);
+      inv_run = mul(inv_run, zk);
+      const Fq zi2 = sqr(zi);
+      const Affine<Fq> xy = io[i0 + k];
+      p.x = mul(xy.x, zi2);
+      p.y = mul(xy.y, mul(zi2, zi));
+    }
+    io[i0 + k] = p;
+  }
+}
+
+// per (device, stream) scratch for the Z coordinates between the two kernels (grow-only; freed at shutdown)
+struct ExpScratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+static std::mutex g_exp_mu;
+static std::map<std::pair<int, void*>, ExpScratch> g_exp_scratch;
+
+static int exp_scratch(size_t bytes, void* stream, void** out) {
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_exp_mu);
+  ExpScratch& sb = g_exp_scratch[std::make_pair(dev, stream)];
+  if (sb.bytes < bytes) {
+    if (sb.p) {
+      ZK_HIP(hipStreamSynchronize((hipStream_t)stream));  // earlier launches on this stream may still use the old buffer
+      ZK_HIP(hipFree(sb.p));
+    }
+    sb.p = nullptr;
+    sb.bytes = 0;
+    ZK_HIP(hipMalloc(&sb.p, bytes));
+    sb.bytes = bytes;
+  }
+  *out = sb.p;
+  return ZK_OK;
+}
+void exp_scratch_release_all() {
+  std::lock_guard<std::mutex> lk(g_exp_mu);
+  for (auto& kv : g_exp_scratch) {
+    (void)hipSetDevice(kv.first.first);
+    (void)hipFree(kv.second.p);
+  }
+  g_exp_scratch.clear();
 }
 
 template <class F>
@@ -167,9 +268,23 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
               const uint32_t* d_base_index = nullptr) {
   if (!d_out || !d_bases || !d_scalars) return n ? ZK_ERR_BAD_ARGS : ZK_OK;
   if (n == 0) return ZK_OK;
+  F* zbuf = nullptr;
+  if constexpr (std::is_same<F, Fq>::value) {
+    void* p = nullptr;
+    int rc = exp_scratch(n * sizeof(Fq), stream, &p);
+    if (rc) return rc;
+    zbuf = (F*)p;
+  }
   hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (Affine<F>*)d_out,
-                     (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n, d_base_index);
+                     (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n, d_base_index, zbuf);
   ZK_HIP(hipGetLastError());
+  if constexpr (std::is_same<F, Fq>::value) {
+    constexpr int K = 16;
+    const uint64_t lanes = (n + K - 1) / K;
+    hipLaunchKernelGGL(batch_normalize_kernel<K>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (Affine<Fq>*)d_out,
+                       (const Fq*)zbuf, (uint64_t)n);
+    ZK_HIP(hipGetLastError());
+  }
   return ZK_OK;
 }
 
@@ -401,6 +516,7 @@ int mi355zk_init(const int* device_ids, int n_devices) {
 
 void mi355zk_shutdown(void) {
   ntt_release_all();
+  exp_scratch_release_all();
   msm_release_g1();
   msm_release_g2();
 }

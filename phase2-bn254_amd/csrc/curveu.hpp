@@ -150,6 +150,97 @@ ZK_HD XYZZ<Fp<PR>> xyzzu_to_std(const XYZZU<PR>& a) {
 }
 
 // =================================================================================================
+// Jacobian accumulator on U-form elements, for SCALAR MULTIPLICATION (batch_exp): a doubling is cheaper in
+// Jacobian coordinates (dbl-2009-l: 4 squarings + 3 products here, 1071 mads) than in XYZZ (1467), and a scalar
+// multiplication is doublings first of all.  Every coordinate lives in the same 2^261 domain (the base point is
+// converted once per scalar multiplication), so formulas are the textbook ones.
+//   Invariants (N-form):  X < 6p,  Y < 2p,  Z < 2p;   infinity is Z == literal zero limbs.
+//   c = p / 2^261 < 0.006:  u_mul(a, b) < (a/p)(b/p) c p + p.
+template <class PR>
+struct JacU {
+  FpU<PR> x, y, z;
+  ZK_HD static JacU zero() { return JacU{FpU<PR>::zero(), FpU<PR>::zero(), FpU<PR>::zero()}; }
+  ZK_HD bool is_zero() const { return z.limbs_all_zero(); }
+};
+
+// 2 * a   [dbl-2009-l with D = 4 X B taken as a product: the textbook (X+B)^2 - A - C costs a squaring instead, but its
+// lazy subtractions would let X grow past the invariant]
+template <class PR>
+ZK_HD JacU<PR> jacu_double(const JacU<PR>& a) {
+  if (a.is_zero()) return a;
+  FpU<PR> A = u_sqr(a.x);                                   // 36c + 1 < 1.22p
+  FpU<PR> B = u_sqr(a.y);                                   // 4c + 1 < 1.03p
+  FpU<PR> C = u_sqr(B);                                     // < 1.01p
+  FpU<PR> D = u_mul(u_dbl(u_dbl(a.x)), B);                  // 4 X B: limbs of 4X < 2^31;  4*6*1.03 c + 1 < 1.15p
+  FpU<PR> E = u_carry(u_add(u_dbl(A), A));                  // 3A < 3.66p, N
+  FpU<PR> F = u_sqr(E);                                     // < 1.08p
+  JacU<PR> r;
+  r.x = u_sub<4, 2>(F, u_dbl(D));                           // 2D < 2.3p <= 4p, limbs < 2^30;  X3 < 5.08p
+  FpU<PR> dmx = u_sub<8, 1>(D, r.x);                        // < 9.15p, N
+  FpU<PR> negc = u_sub<2, 1>(FpU<PR>::zero(), C);           // 2p - C in (0, 2p], N
+  r.y = u_mul2(E, dmx, negc, UPow2<PR, 264>::get());        // E (D - X3) - 8 C: (3.66*9.15 + 2) c + 1 < 1.22p
+  r.z = u_mul(u_dbl(a.y), a.z);                             // 2 Y Z: 8c + 1 < 1.05p
+  return r;
+}
+
+// acc += (+/-)(x2, y2);  x2, y2: the base point in the 2^261 domain, N-form, < 2p, not infinity   [madd-2007-bl]
+template <class PR>
+ZK_HD void jacu_add_mixed(JacU<PR>& acc, const FpU<PR>& x2, const FpU<PR>& y2in, bool negate) {
+  FpU<PR> y2 = y2in;
+  {
+    FpU<PR> ny = u_sub<2, 1>(FpU<PR>::zero(), y2in);        // 2p - y2 in (0, 2p], N
+#pragma unroll
+    for (int i = 0; i < 9; ++i) y2.l[i] = negate ? ny.l[i] : y2in.l[i];
+  }
+  if (acc.is_zero()) {
+    acc.x = x2;
+    acc.y = y2;
+    acc.z = UPow2<PR, 261>::get();                          // one
+    return;
+  }
+  FpU<PR> z1z1 = u_sqr(acc.z);                              // 4c + 1 < 1.03p
+  FpU<PR> u2 = u_mul(x2, z1z1);                             // < 1.02p
+  FpU<PR> s2 = u_mul(y2, u_mul(acc.z, z1z1));               // < 1.02p
+  FpU<PR> h = u_sub<8, 1>(u2, acc.x);                       // X < 6p <= 8p;  H < 9.02p, N
+  FpU<PR> hh = u_sqr(h);                                    // 81.4c + 1 < 1.49p
+  FpU<PR> i4 = u_dbl(u_dbl(hh));                            // I = 4 HH < 5.94p, limbs < 2^31
+  FpU<PR> j = u_mul(h, i4);                                 // < 1.32p
+  FpU<PR> r = u_carry(u_dbl(u_sub<2, 1>(s2, acc.y)));       // 2 (S2 - Y1 + 2p) < 6.04p, N
+  FpU<PR> v = u_mul(acc.x, i4);                             // < 1.22p
+  FpU<PR> rr = u_sqr(r);                                    // 36.5c + 1 < 1.22p
+  FpU<PR> x3 = u_sub<4, 3>(rr, u_add(j, u_dbl(v)));         // J + 2V < 3.76p <= 4p, limbs < 3 * 2^29;  X3 < 5.22p
+  FpU<PR> vmx = u_sub<8, 1>(v, x3);                         // < 9.22p, N
+  FpU<PR> ny2 = u_sub<4, 2>(FpU<PR>::zero(), u_dbl(acc.y)); // 4p - 2 Y1 in (0, 4p], N
+  FpU<PR> y3 = u_mul2(r, vmx, ny2, j);                      // r (V - X3) - 2 Y1 J: (6.04*9.22 + 4*1.32) c + 1 < 1.37p
+  FpU<PR> z3 = u_mul(u_dbl(acc.z), h);                      // (Z1 + H)^2 - Z1Z1 - HH = 2 Z1 H: 36.1c + 1 < 1.22p
+  if (u_is_zero_lt2p(z3)) {
+    // H == 0 (Z1 != 0): the points have the same x.  Same point -> double (ec.rs:483-485); opposite -> infinity (ec.rs:487).
+    if (u_is_zero_lt8p(r)) {
+      JacU<PR> b{x2, y2, UPow2<PR, 261>::get()};
+      acc = jacu_double(b);
+    } else {
+      acc = JacU<PR>::zero();
+    }
+    return;
+  }
+  acc.x = x3;
+  acc.y = y3;
+  acc.z = z3;
+}
+
+// accumulator -> memory-format Jacobian (canonical coordinates, 2^256 domain); infinity -> z == 0 (x, y zero too)
+template <class PR>
+ZK_HD Jacobian<Fp<PR>> jacu_to_std(const JacU<PR>& a) {
+  Jacobian<Fp<PR>> r{Fp<PR>::zero(), Fp<PR>::zero(), Fp<PR>::zero()};
+  if (a.is_zero()) return r;
+  const FpU<PR> c256 = UPow2<PR, 256>::get();               // v*2^261 * 2^256 / 2^261 = v * 2^256
+  r.x = u_to_std_lt2p(u_mul(a.x, c256));
+  r.y = u_to_std_lt2p(u_mul(a.y, c256));
+  r.z = u_to_std_lt2p(u_mul(a.z, c256));
+  return r;
+}
+
+// =================================================================================================
 // G2: the same accumulator over Fq2 = Fq[u]/(u^2+1) with U-form components (Fq2U, fieldu.hpp).
 // An Fq2 product is two sums of two Fq products, each with ONE Montgomery reduction (u_mul2):
 //     (a0 + a1 u)(b0 + b1 u) = (a0 b0 + a1 (-b1)) + (a0 b1 + a1 b0) u          486 mads, like Karatsuba's 3 x 162,
