@@ -228,6 +228,73 @@ ZK_HD void jacu_add_mixed(JacU<PR>& acc, const FpU<PR>& x2, const FpU<PR>& y2in,
   acc.z = z3;
 }
 
+// A table entry for windowed scalar multiplication: a Jacobian point together with Z^2 and Z^3, so that adding it costs
+// 3 squarings + 9 products + 1 fused pair (2079 mads) instead of add-2007-bl's 4 + 10 + 1.  48 words = 192 bytes.
+// Invariants as JacU, ZZ < 2p, ZZZ < 2p.
+template <class PR>
+struct alignas(16) JacTabU {
+  FpU<PR> x, y, z, zz, zzz;
+  uint32_t pad[3];
+};
+template <class PR>
+ZK_HD JacTabU<PR> jacu_tab_entry(const JacU<PR>& q) {
+  JacTabU<PR> t;
+  t.x = q.x;
+  t.y = q.y;
+  t.z = q.z;
+  t.zz = u_sqr(q.z);                                        // 4c + 1 < 1.03p
+  t.zzz = u_mul(q.z, t.zz);                                 // < 1.02p
+  t.pad[0] = t.pad[1] = t.pad[2] = 0;
+  return t;
+}
+
+// acc += (+/-) t;  t != infinity   [add-2007-bl with the entry's Z^2, Z^3 given]
+template <class PR>
+ZK_HD void jacu_add_tab(JacU<PR>& acc, const JacTabU<PR>& t, bool negate) {
+  FpU<PR> y2 = t.y;
+  {
+    FpU<PR> ny = u_sub<2, 1>(FpU<PR>::zero(), t.y);         // 2p - Y2 in (0, 2p], N
+#pragma unroll
+    for (int i = 0; i < 9; ++i) y2.l[i] = negate ? ny.l[i] : t.y.l[i];
+  }
+  if (acc.is_zero()) {
+    acc.x = t.x;
+    acc.y = y2;
+    acc.z = t.z;
+    return;
+  }
+  FpU<PR> z1z1 = u_sqr(acc.z);                              // < 1.03p
+  FpU<PR> u1 = u_mul(acc.x, t.zz);                          // 6*2c + 1 < 1.08p
+  FpU<PR> u2 = u_mul(t.x, z1z1);                            // 6*1.03c + 1 < 1.04p
+  FpU<PR> s1 = u_mul(acc.y, t.zzz);                         // < 1.03p
+  FpU<PR> s2 = u_mul(y2, u_mul(acc.z, z1z1));               // < 1.02p
+  FpU<PR> h = u_sub<2, 1>(u2, u1);                          // < 3.04p, N
+  FpU<PR> hh = u_sqr(h);                                    // 9.3c + 1 < 1.06p
+  FpU<PR> i4 = u_dbl(u_dbl(hh));                            // I = 4 HH < 4.24p, limbs < 2^31
+  FpU<PR> j = u_mul(h, i4);                                 // < 1.08p
+  FpU<PR> r = u_carry(u_dbl(u_sub<2, 1>(s2, s1)));          // 2 (S2 - S1 + 2p) < 6.04p, N
+  FpU<PR> v = u_mul(u1, i4);                                // < 1.03p
+  FpU<PR> rr = u_sqr(r);                                    // < 1.22p
+  FpU<PR> x3 = u_sub<4, 3>(rr, u_add(j, u_dbl(v)));         // J + 2V < 3.14p <= 4p, limbs < 3 * 2^29;  X3 < 5.22p
+  FpU<PR> vmx = u_sub<8, 1>(v, x3);                         // < 9.03p, N
+  FpU<PR> n2s1 = u_sub<4, 2>(FpU<PR>::zero(), u_dbl(s1));   // 4p - 2 S1 in (0, 4p], N
+  FpU<PR> y3 = u_mul2(r, vmx, n2s1, j);                     // r (V - X3) - 2 S1 J: (6.04*9.03 + 4*1.08) c + 1 < 1.36p
+  FpU<PR> z3 = u_mul(u_mul(u_dbl(acc.z), t.z), h);          // 2 Z1 Z2 H: (8c + 1) * 3.04 c + 1 < 1.02p
+  if (u_is_zero_lt2p(z3)) {
+    // H == 0: same x.  Same point -> double; opposite -> infinity (ec.rs:398-408).
+    if (u_is_zero_lt8p(r)) {
+      JacU<PR> b{t.x, y2, t.z};
+      acc = jacu_double(b);
+    } else {
+      acc = JacU<PR>::zero();
+    }
+    return;
+  }
+  acc.x = x3;
+  acc.y = y3;
+  acc.z = z3;
+}
+
 // accumulator -> memory-format Jacobian (canonical coordinates, 2^256 domain); infinity -> z == 0 (x, y zero too)
 template <class PR>
 ZK_HD Jacobian<Fp<PR>> jacu_to_std(const JacU<PR>& a) {
