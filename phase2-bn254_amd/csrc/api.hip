@@ -256,33 +256,105 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
   zbuf[i] = r.z;
 }
 
+// G2 (memory-format Fq2 arithmetic, curve.hpp): the same fixed signed 4-bit windows on a JACOBIAN accumulator
+// (doubling 2M + 5S against XYZZ's 6M + 3S; 254 doublings + ~60 full additions + the table against 254 x (doubling +
+// mixed addition) when lanes diverge).  Table build and main loop run through ONE loop with a single inlined
+// jac_double and a single inlined jac_add: the Fq2 group law is > 100 KB of code per copy.
+//   step = (load entry, double?, add entry, store entry); entries 1..8 hold 1P..8P, 0 = none.
+template <class F>
+__global__ void __launch_bounds__(256) batch_exp_win_std_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
+                                                               const uint32_t* __restrict__ scalars, int same_scalar, uint64_t i0,
+                                                               uint64_t n_chunk, const uint32_t* __restrict__ base_index,
+                                                               F* __restrict__ zbuf, Jacobian<F>* __restrict__ tab) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunk) return;
+  const uint64_t i = i0 + t;
+  uint32_t s[8];
+  const uint32_t* sp = scalars + (same_scalar ? 0 : i * 8);
+#pragma unroll
+  for (int l = 0; l < 8; ++l) s[l] = sp[l];
+  const Affine<F> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
+  Jacobian<F> acc{F::zero(), F::zero(), F::zero()};
+  if (!base.is_zero()) {
+    tab[t] = Jacobian<F>{base.x, base.y, F::one()};
+    uint32_t mag[8], sgn[2] = {0, 0};  // signed digits d_j in [-8, 8]: k = sum d_j 16^j
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        uint32_t d = ((s[w] >> (4 * q)) & 15u) + carry;
+        carry = d > 8u ? 1u : 0u;
+        if (carry) {
+          d = 16u - d;
+          sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+        }
+        m |= d << (4 * q);
+      }
+      mag[w] = m;
+    }
+    // table program, one nibble per field (load, double, add, store):  2P = 2*1P, 3P = 2P + 1P, 4P = 2*2P, 5P = 4P + 1P, ...
+    constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};
+#pragma unroll 1
+    for (int step = 0; step < 7 + 256; ++step) {
+      uint32_t load = 0, dbl_it = 1, add = 0, store = 0, negate = 0;
+      if (step < 7) {
+        const uint32_t pr = PROG[step];
+        load = pr >> 12;
+        dbl_it = (pr >> 8) & 15u;
+        add = (pr >> 4) & 15u;
+        store = pr & 15u;
+      } else {
+        const int m = step - 7;        // 256 doublings; after the 4th of each window the window's digit is added
+        if (m == 0) acc = Jacobian<F>{F::zero(), F::zero(), F::zero()};
+        if ((m & 3) == 3) {
+          const int j = 63 - (m >> 2);
+          add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
+          negate = (sgn[j >> 5] >> (j & 31)) & 1u;
+        }
+      }
+      if (load) acc = tab[(uint64_t)(load - 1) * n_chunk + t];
+      if (dbl_it) jac_double(acc);
+      if (add) {
+        Jacobian<F> o = tab[(uint64_t)(add - 1) * n_chunk + t];
+        if (negate) o.y = neg(o.y);
+        jac_add(acc, o);
+      }
+      if (store) tab[(uint64_t)(store - 1) * n_chunk + t] = acc;
+    }
+  }
+  out[i] = Affine<F>{acc.x, acc.y};
+  zbuf[i] = acc.z;
+}
+
 // io[i] = (X, Y) of a Jacobian point whose Z is z[i]  ->  the affine record (X / Z^2, Y / Z^3); Z == 0 -> all-zero record.
 // K consecutive points per lane share ONE inversion (prefix products, ec.rs:251-299's scheme).
-template <int K>
-__global__ void __launch_bounds__(256) batch_normalize_kernel(Affine<Fq>* __restrict__ io, const Fq* __restrict__ z, uint64_t n) {
+template <class F, int K>
+__global__ void __launch_bounds__(256) batch_normalize_kernel(Affine<F>* __restrict__ io, const F* __restrict__ z, uint64_t n) {
   const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * K;
   if (i0 >= n) return;
-  Fq pre[K];
-  Fq run = Fq::one();
+  F pre[K];
+  F run = F::one();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     pre[k] = run;
     if (i0 + k < n) {
-      const Fq zk = z[i0 + k];
+      const F zk = z[i0 + k];
       if (!zk.is_zero()) run = mul(run, zk);
     }
   }
-  Fq inv_run = inv(run);
+  F inv_run = inv(run);
 #pragma unroll
   for (int k = K - 1; k >= 0; --k) {
     if (i0 + k >= n) continue;
-    const Fq zk = z[i0 + k];
-    Affine<Fq> p{Fq::zero(), Fq::zero()};
+    const F zk = z[i0 + k];
+    Affine<F> p{F::zero(), F::zero()};
     if (!zk.is_zero()) {
-      const Fq zi = mul(inv_run, pre[k]);
+      const F zi = mul(inv_run, pre[k]);
       inv_run = mul(inv_run, zk);
-      const Fq zi2 = sqr(zi);
-      const Affine<Fq> xy = io[i0 + k];
+      const F zi2 = sqr(zi);
+      const Affine<F> xy = io[i0 + k];
       p.x = mul(xy.x, zi2);
       p.y = mul(xy.y, mul(zi2, zi));
     }
@@ -353,12 +425,28 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
     ZK_HIP(hipGetLastError());
     constexpr int K = 16;
     const uint64_t lanes = (n + K - 1) / K;
-    hipLaunchKernelGGL(batch_normalize_kernel<K>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Fq*)zbuf,
+    hipLaunchKernelGGL((batch_normalize_kernel<Fq, K>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Fq*)zbuf,
                        (uint64_t)n);
     ZK_HIP(hipGetLastError());
   } else {
-    hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, (const Affine<F>*)d_bases,
-                       same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n, d_base_index, (F*)nullptr);
+    const size_t chunk = n < ((size_t)1 << 18) ? n : ((size_t)1 << 18);
+    const size_t z_bytes = (n * sizeof(F) + 255) & ~(size_t)255;
+    void* p = nullptr;
+    int rc = exp_scratch(z_bytes + (size_t)EXP_TAB * chunk * sizeof(Jacobian<F>), stream, &p);
+    if (rc) return rc;
+    F* zbuf = (F*)p;
+    Jacobian<F>* tab = (Jacobian<F>*)((char*)p + z_bytes);
+    for (size_t i0 = 0; i0 < n; i0 += chunk) {
+      const size_t m = n - i0 < chunk ? n - i0 : chunk;
+      hipLaunchKernelGGL(batch_exp_win_std_kernel<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out,
+                         (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
+                         zbuf, tab);
+    }
+    ZK_HIP(hipGetLastError());
+    constexpr int K = 8;
+    const uint64_t lanes = (n + K - 1) / K;
+    hipLaunchKernelGGL((batch_normalize_kernel<F, K>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, (const F*)zbuf,
+                       (uint64_t)n);
     ZK_HIP(hipGetLastError());
   }
   return ZK_OK;

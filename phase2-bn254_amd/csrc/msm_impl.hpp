@@ -8,16 +8,19 @@
 // and the group law underneath (pairing/src/bn256/ec.rs:301-536).
 //
 // MI355X design (DESIGN.md "MSM"), not the reference's one-thread-per-window scan:
-//   1. msm_digits_kernel      every scalar -> W signed c-bit digits; one (bucket key, base index|sign)
-//                             pair per window; identity-base check (source.rs:50-52) fused in.
-//   2. radix sort by key      (rocPRIM device radix sort; HBM-bound, ~3 passes over 8 B/pair)
-//   3. msm_bounds_kernel      first/last position of every bucket in the sorted pair list
+//   1. msm_digits_kernel      every scalar -> W signed digits; one (key, base index | sign) pair per window, written
+//                             window-major; identity-base check (source.rs:50-52) fused in.
+//   2. radix sort             rocPRIM onesweep on the LOW c key bits only (stable + window-major input keeps every
+//                             (window, bucket) run contiguous); HBM-bound, ~3 passes over 8 B/pair.
+//   3. msm_bounds_kernel      first/last position of every bucket in the sorted pair list;
+//      msm_size_*_kernel      counting sort of the buckets by size (wave-level load balance, heavy buckets first).
 //   4. msm_accumulate_kernel  ONE LANE PER BUCKET for all W * 2^(c-1) buckets at once (2^19 lanes at
-//                             2^20 points): gathers its affine bases and folds them into an XYZZ
-//                             accumulator held in VGPRs (8M+2S per point) -- the dominant kernel.
-//   5. msm_reduce_kernel(s)   sum_k k*B_k per window: chunked running sums + small scalar fix-up,
-//                             then an LDS tree per window.
-//   6. host                   join of W window sums: c doublings + add per window (multiexp.rs:146-154).
+//                             2^20 points), in size order: gathers its affine bases and folds them into a U-form
+//                             XYZZ accumulator held in VGPRs (8M+2S per point) -- the dominant kernel;
+//      msm_accumulate_heavy / msm_heavy_combine   segment-parallel path for buckets far longer than the mean.
+//   5. msm_reduce_level_kernel  sum_k k*B_k per window by chunked running sums (levels), then
+//      msm_tree_kernel          pairwise trees: plain sums of the levels' A[] and the bit decomposition of the rest.
+//   6. host                   ONE Horner pass over all partial sums, grouped by their power of two (multiexp.rs:146-154).
 // The result is a group element; the reference compares/normalises projective points by value
 // (ec.rs:45-85, 596-629), so parity is defined on the affine normalisation.
 #include <hip/hip_runtime.h>
@@ -52,7 +55,6 @@ struct MsmGeom {
   uint32_t c;        // widest window, bits
   uint32_t W;        // windows
   uint32_t nb;       // bucket slots per window = 2^(c-1) (narrower windows leave their upper slots empty)
-  uint32_t invalid;  // key of "no contribution" = W * nb
   uint8_t width[64]; // bits of window w (c >= 4: at most 64 windows)
   uint8_t shift[64]; // first bit of window w
 };
@@ -518,7 +520,6 @@ MsmGeom make_geom(uint32_t c) {
   while ((W - 1) * c + (c - 1) < 254) ++W;      // smallest W with (W-1) windows of <= c bits + a top window of <= c-1 bits
   G.W = W;
   G.nb = 1u << (c - 1);
-  G.invalid = W * G.nb;
   uint32_t top = c - 1;
   if (W == 1) top = 254 < top ? 254 : top;
   uint32_t rest = 254 > top ? 254 - top : 0;    // bits for windows 0..W-2
@@ -625,7 +626,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_err = take(8);
   size_t o_sort = take(sort_tmp_bytes);
 
-  std::lock_guard<std::mutex> lk(g_ws_mu);
+  std::unique_lock<std::mutex> lk(g_ws_mu);
   void* base = nullptr;
   int rc = ws_reserve(dev, off, &base);
   if (rc) return rc;
@@ -679,7 +680,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   prof_end(slot_sort, st);
   if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
 
-  auto run_set = [&](const Affine<F>* bases_set, Jacobian<F>* result) -> int {
+  auto run_set = [&](const Affine<F>* bases_set, Jacobian<F>* result, bool last_set) -> int {
     {
       prof_begin(slot_heavy, st);
       hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
@@ -756,6 +757,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
+    // flight, prover.rs:250-298) start while this thread joins its partial sums
+    if (last_set) lk.unlock();
     if (h_err != ~0ull) {
       *err_index_out = (long long)h_err;
       return ZK_ERR_UNEXPECTED_IDENTITY;
@@ -785,9 +789,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     *result = acc;
     return (int)ZK_OK;
   };
-  int rc_set = run_set(d_bases, out);
+  int rc_set = run_set(d_bases, out, d_bases2 == nullptr || out2 == nullptr);
   if (rc_set != ZK_OK) return rc_set;
-  if (d_bases2 != nullptr && out2 != nullptr) return run_set(d_bases2, out2);
+  if (d_bases2 != nullptr && out2 != nullptr) return run_set(d_bases2, out2, true);
   return ZK_OK;
 }
 
