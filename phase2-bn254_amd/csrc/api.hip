@@ -362,6 +362,16 @@ __global__ void __launch_bounds__(256) batch_normalize_kernel(Affine<F>* __restr
   }
 }
 
+int batch_normalize_g1(void* d_io_affine, const void* d_z, uint64_t n, hipStream_t st) {
+  if (n == 0) return ZK_OK;
+  constexpr int K = 16;
+  const uint64_t lanes = (n + K - 1) / K;
+  hipLaunchKernelGGL((batch_normalize_kernel<Fq, K>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_io_affine,
+                     (const Fq*)d_z, n);
+  ZK_HIP(hipGetLastError());
+  return ZK_OK;
+}
+
 // per (device, stream) scratch for the Z coordinates between the two kernels (grow-only; freed at shutdown)
 struct ExpScratch {
   void* p = nullptr;

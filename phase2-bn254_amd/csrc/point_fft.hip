@@ -5,154 +5,182 @@
 // driven by powersoftau/src/bin/prepare_phase2.rs:68-131 (affine tau-powers -> ifft -> batch_normalization ->
 // Lagrange-basis points) -- the dominant cost of `prepare_phase2`.
 //
-// Every butterfly is a 254-bit scalar multiplication, so the work is n/2 * log n * ~3700 field products: pure
-// integer-ALU work.  Layout: a working array of XYZZ points in U-form (fieldu.hpp, all four coordinates in the
-// 2^261 domain, 144 B per point) in HBM; one lane per butterfly per stage, DIT after a bit-reversed load;
-// twiddles come from a table of CANONICAL scalars w^e (e < n/2).  Input and output are affine raw records
-// (64 B, all-zero = infinity), i.e. the output is what `batch_normalization` + `into_affine` leave
+// Every butterfly is a 254-bit scalar multiplication, so the work is n/2 * log n * ~400k integer mads: pure ALU.
+// Layout: a working array of U-form JACOBIAN points (curveu.hpp JacU, every coordinate in the 2^261 domain, 112 B per
+// point) in HBM; one lane per butterfly per stage, DIT after a bit-reversed load.  The twiddle multiplication uses
+// fixed signed 4-bit windows over a per-lane table {1..8} * t in a scratch array laid out [entry][lane] (JacTabU:
+// Jacobian + Z^2 + Z^3), so all 64 lanes of a wave add at the same 64 places although their twiddles differ --
+// plain double-and-add would make the wave pay an addition on nearly every bit.  Table build, the 256 doublings and
+// the closing u + t / u - t run through ONE loop with a single inlined doubling and a single inlined addition.
+// Input and output are affine raw records (64 B, all-zero = infinity); the output is normalised with one inversion
+// per 16 points (api.hip batch_normalize), i.e. it is what `batch_normalization` + `into_affine` leave
 // (ec.rs:251-299, 596-629), which makes parity bit-exact.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <map>
-#include <mutex>
-#include <utility>
 
 #include "../../include/mi355zk.h"
 #include "curveu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
+
+// api.hip: io[i] = (X, Y), z[i] = Z  ->  affine records, 16 points per inversion
+int batch_normalize_g1(void* d_io_affine, const void* d_z, uint64_t n, hipStream_t st);
+
 namespace {
 
-using XU = XYZZU<FqParams>;
+using JU = JacU<FqParams>;
+using TU = JacTabU<FqParams>;
 
-// a + b for two accumulators whose coordinates all live in the 2^261 domain (add-2008-s), complete.
-// Invariants in and out: X < 6p, Y < 2p, ZZ < 2p, ZZZ < 2p, N-form (same bookkeeping as curveu.hpp).
-__device__ XU xu_add(const XU& a, const XU& b) {
-  if (a.is_zero()) return b;
-  if (b.is_zero()) return a;
-  FqU u1 = u_mul(a.x, b.zz);                       // 6 * 2 c + 1 < 1.08p
-  FqU u2 = u_mul(b.x, a.zz);
-  FqU s1 = u_mul(a.y, b.zzz);                      // < 1.03p
-  FqU s2 = u_mul(b.y, a.zzz);
-  FqU p = u_sub<2, 1>(u2, u1);                     // < 3.1p, N
-  FqU r = u_sub<2, 1>(s2, s1);                     // < 3.1p, N
-  FqU pp = u_sqr(p);                               // < 1.06p
-  FqU ppp = u_mul(p, pp);                          // < 1.02p
-  FqU q = u_mul(u1, pp);                           // < 1.01p
-  FqU rr = u_sqr(r);                               // < 1.06p
-  XU o;
-  o.x = u_sub<4, 3>(rr, u_add(ppp, u_dbl(q)));     // PPP + 2Q < 3.1p, limbs < 3 * 2^29;  X3 < 5.1p
-  FqU d = u_sub<8, 1>(q, o.x);                     // < 9.1p
-  FqU ns1 = u_sub<2, 1>(FqU::zero(), s1);          // 2p - S1
-  o.y = u_mul2(r, d, ns1, ppp);                    // R*D - S1*PPP: (3.1 * 9.1 + 2 * 1.02) c + 1 < 1.2p
-  o.zz = u_mul(u_mul(a.zz, b.zz), pp);             // < 2p
-  o.zzz = u_mul(u_mul(a.zzz, b.zzz), ppp);
-  if (u_is_zero_lt2p(o.zz)) {                      // P == 0: same x (ec.rs:398-408)
-    if (u_is_zero_lt8p(r)) return xyzzu_double(a);
-    return XU::zero();
-  }
-  return o;
-}
-
-__device__ __forceinline__ XU xu_neg(const XU& a) {
-  if (a.is_zero()) return a;
-  XU r = a;
-  r.y = u_sub<2, 1>(FqU::zero(), a.y);             // 2p - Y
-  return r;
-}
-
-// k * b, k a canonical 256-bit scalar (MSB-first double-and-add: the group element ec.rs:544-563 computes)
-__device__ XU xu_mul(const XU& b, const uint32_t k[8]) {
-  XU acc = XU::zero();
-  bool found = false;
-  for (int bit = 255; bit >= 0; --bit) {
-    bool on = (k[bit >> 5] >> (bit & 31)) & 1;
-    if (found) acc = xyzzu_double(acc);
-    else found = on;
-    if (on) acc = xu_add(acc, b);
-  }
-  return acc;
-}
-
-struct alignas(16) PtU {
-  uint32_t w[36];
+struct alignas(16) PtJ {
+  uint32_t w[28];  // x, y, z (9 limbs each) + 1 pad
 };
-__device__ __forceinline__ XU pt_load(const PtU* p) {
-  PtU t;
+__device__ __forceinline__ JU pt_load(const PtJ* p) {
+  PtJ t;
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint4* d = reinterpret_cast<uint4*>(&t);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) d[i] = q[i];
-  XU r;
+  for (int i = 0; i < 7; ++i) d[i] = q[i];
+  JU r;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { r.x.l[i] = t.w[i]; r.y.l[i] = t.w[9 + i]; r.zz.l[i] = t.w[18 + i]; r.zzz.l[i] = t.w[27 + i]; }
+  for (int i = 0; i < 9; ++i) { r.x.l[i] = t.w[i]; r.y.l[i] = t.w[9 + i]; r.z.l[i] = t.w[18 + i]; }
   return r;
 }
-__device__ __forceinline__ void pt_store(PtU* p, const XU& v) {
-  PtU t;
+__device__ __forceinline__ void pt_store(PtJ* p, const JU& v) {
+  PtJ t;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { t.w[i] = v.x.l[i]; t.w[9 + i] = v.y.l[i]; t.w[18 + i] = v.zz.l[i]; t.w[27 + i] = v.zzz.l[i]; }
+  for (int i = 0; i < 9; ++i) { t.w[i] = v.x.l[i]; t.w[9 + i] = v.y.l[i]; t.w[18 + i] = v.z.l[i]; }
+  t.w[27] = 0;
   const uint4* s = reinterpret_cast<const uint4*>(&t);
   uint4* d = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) d[i] = s[i];
+  for (int i = 0; i < 7; ++i) d[i] = s[i];
 }
 
 // affine raw records -> working points at the bit-reversed position (domain.rs:288-293)
-__global__ void __launch_bounds__(256) pfft_load_kernel(const G1Affine* __restrict__ in, PtU* __restrict__ work, uint32_t log_n) {
+__global__ void __launch_bounds__(256) pfft_load_kernel(const G1Affine* __restrict__ in, PtJ* __restrict__ work, uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
   G1Affine a = in[i];
-  XU v = XU::zero();
+  JU v = JU::zero();
   if (!a.is_zero()) {
     const FqU c266 = UPow2<FqParams, 266>::get();   // x*2^256 * 2^266 / 2^261 = x * 2^261
     v.x = u_mul(u_from_std(a.x), c266);
     v.y = u_mul(u_from_std(a.y), c266);
-    v.zz = UPow2<FqParams, 261>::get();             // one
-    v.zzz = v.zz;
+    v.z = UPow2<FqParams, 261>::get();              // one
   }
   uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0;
   pt_store(work + r, v);
 }
 
-// stage s (m = 2^s):  t = w^(j * n/2m) * a[k+j+m];  a[k+j+m] = a[k+j] - t;  a[k+j] += t   (domain.rs:303-309)
-__global__ void __launch_bounds__(256) pfft_stage_kernel(PtU* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
-                                                        uint32_t s) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= (1u << (log_n - 1))) return;
-  const uint32_t m = 1u << s, j = b & (m - 1);
-  const uint32_t i0 = ((b >> s) << (s + 1)) + j, i1 = i0 + m;
-  XU u = pt_load(work + i0);
-  XU t = pt_load(work + i1);
-  if (j != 0) {  // w^0 = 1
-    uint32_t k[8];
-    const uint32_t* kp = tw_canon + ((uint64_t)j << (log_n - 1 - s)) * 8;
+// signed 4-bit digits of a canonical scalar: k = sum d_j 16^j, d_j in [-8, 8]; magnitudes as nibbles, signs as bits
+__device__ __forceinline__ void recode16(const uint32_t* k, uint32_t mag[8], uint32_t sgn[2]) {
+  sgn[0] = sgn[1] = 0;
+  uint32_t carry = 0;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) k[l] = kp[l];
-    t = xu_mul(t, k);
+  for (int w = 0; w < 8; ++w) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t d = ((k[w] >> (4 * q)) & 15u) + carry;
+      carry = d > 8u ? 1u : 0u;
+      if (carry) {
+        d = 16u - d;
+        sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+      }
+      m |= d << (4 * q);
+    }
+    mag[w] = m;
   }
-  pt_store(work + i0, xu_add(u, t));
-  pt_store(work + i1, xu_add(u, xu_neg(t)));
 }
 
-// (optional) scale by the canonical scalar `c` (ifft: m^-1, domain.rs:163-173), then normalise to affine
-__global__ void __launch_bounds__(256) pfft_store_kernel(const PtU* __restrict__ work, G1Affine* __restrict__ out, uint32_t log_n, int scale,
-                                                        Fr c_canon) {
+// The shared program.  Entries 1..8 of the lane's table hold 1t..8t (entry 1 is rewritten with the product at the end).
+//   steps 0..6    table:  2t = 2*1t, 3t = 2t + 1t, 4t = 2*2t, 5t = 4t + 1t, 6t = 2*3t, 7t = 6t + 1t, 8t = 2*4t
+//   steps 7..262  256 doublings; after every 4th the window's digit entry is added
+//   step  263     (mode butterfly) entry 1 := product;  steps 264 / 265: a[i0] = u + product, a[i1] = u - product
+// mode 0: butterfly of stage s (domain.rs:303-309);  mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173)
+__global__ void __launch_bounds__(256) pfft_stage_kernel(PtJ* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
+                                                        uint32_t s, uint64_t b0, uint64_t n_chunk, TU* __restrict__ tab, int mode, Fr c) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunk) return;
+  const uint64_t b = b0 + t;
+  uint64_t i0, i1;
+  uint32_t kk[8];
+  bool unit = false;  // twiddle w^0 = 1: no multiplication
+  if (mode == 0) {
+    const uint64_t m = 1ull << s, j = b & (m - 1);
+    i0 = ((b >> s) << (s + 1)) + j;
+    i1 = i0 + m;
+    unit = j == 0;
+    const uint32_t* kp = tw_canon + (j << (log_n - 1 - s)) * 8;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) kk[l] = kp[l];
+  } else {
+    i0 = i1 = b;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) kk[l] = c.l[l];
+  }
+  const JU u = mode == 0 ? pt_load(work + i0) : JU::zero();
+  JU acc = pt_load(work + i1);
+  uint32_t mag[8], sgn[2];
+  recode16(kk, mag, sgn);
+  const bool t_inf = acc.is_zero();
+  if (t_inf && mode == 1) return;
+  TU e1 = jacu_tab_entry(acc);  // 1t (an infinity t keeps z == 0: every sum below then returns the other operand)
+  tab[t] = e1;
+  constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};  // nibbles: load, double, add, store
+  const int first = (unit || t_inf) ? 263 : 0;
+  const int last = mode == 0 ? 265 : 262;
+#pragma unroll 1
+  for (int step = first; step <= last; ++step) {
+    uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0;
+    if (step < 7) {
+      const uint32_t pr = PROG[step];
+      load = pr >> 12;
+      dbl_it = (pr >> 8) & 15u;
+      add = (pr >> 4) & 15u;
+      store = pr & 15u;
+    } else if (step < 263) {
+      const int m = step - 7;
+      if (m == 0) acc = JU::zero();
+      dbl_it = 1;
+      if ((m & 3) == 3) {
+        const int j = 63 - (m >> 2);
+        add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
+        negate = (sgn[j >> 5] >> (j & 31)) & 1u;
+      }
+    } else if (step == 263) {
+      store = 1;                       // the product (or t itself when the twiddle is 1) becomes entry 1
+    } else {
+      acc = u;
+      add = 1;
+      negate = step == 265;
+    }
+    if (load) {
+      const TU e = tab[(uint64_t)(load - 1) * n_chunk + t];
+      acc = JU{e.x, e.y, e.z};
+    }
+    if (dbl_it) acc = jacu_double(acc);
+    if (add) {
+      const TU e = tab[(uint64_t)(add - 1) * n_chunk + t];
+      if (!e.z.limbs_all_zero()) jacu_add_tab(acc, e, negate != 0);
+    }
+    if (store) tab[(uint64_t)(store - 1) * n_chunk + t] = jacu_tab_entry(acc);
+    if (step == 264) pt_store(work + i0, acc);
+    if (step == 265) pt_store(work + i1, acc);
+  }
+  if (mode == 1) pt_store(work + i0, acc);
+}
+
+// working points -> (X, Y) in the output record and Z in zbuf, memory format; batch_normalize_g1 finishes
+__global__ void __launch_bounds__(256) pfft_store_kernel(const PtJ* __restrict__ work, G1Affine* __restrict__ out, Fq* __restrict__ zbuf,
+                                                        uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
-  XU v = pt_load(work + i);
-  if (scale) v = xu_mul(v, c_canon.l);
-  G1XYZZ sres = G1XYZZ::zero();
-  if (!v.is_zero()) {
-    const FqU c256 = UPow2<FqParams, 256>::get();   // v*2^261 * 2^256 / 2^261 = v * 2^256 (memory format)
-    sres.x = u_to_std_lt2p(u_mul(v.x, c256));
-    sres.y = u_to_std_lt2p(u_mul(v.y, c256));
-    sres.zz = u_to_std_lt2p(u_mul(v.zz, c256));
-    sres.zzz = u_to_std_lt2p(u_mul(v.zzz, c256));
-  }
-  out[i] = xyzz_to_affine(sres);
+  const G1Jacobian r = jacu_to_std(pt_load(work + i));
+  out[i] = G1Affine{r.x, r.y};
+  zbuf[i] = r.z;
 }
 
 // tw[e] = canonical(omega^e), e < count
@@ -166,25 +194,38 @@ __global__ void pfft_twiddle_kernel(uint32_t* tw, Fr omega, uint64_t count) {
 
 }  // namespace
 
-// d_points: 2^log_n affine raw records, in place.  inverse != 0: omega = omegainv and every output is scaled by minv.
+// d_points: 2^log_n affine raw records, in place.  scale: every output is multiplied by scale_canon (ifft: m^-1).
 int point_fft_g1(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st) {
   const uint64_t n = 1ull << log_n;
-  PtU* work = nullptr;
-  uint32_t* tw = nullptr;
-  ZK_HIP(hipMalloc(&work, n * sizeof(PtU)));
-  hipError_t e = hipMalloc(&tw, (n / 2 + 1) * 32);
-  if (e != hipSuccess) { (void)hipFree(work); ZK_HIP(e); }
-  auto fail = [&](hipError_t err) { (void)hipFree(work); (void)hipFree(tw); return err; };
+  const uint64_t lanes_max = scale ? n : (n >= 2 ? n / 2 : 1);
+  const uint64_t chunk = lanes_max < (1ull << 20) ? lanes_max : (1ull << 20);  // table: 8 x 192 B per lane
+  char* buf = nullptr;
+  const size_t o_work = 0, o_tw = o_work + ((n * sizeof(PtJ) + 255) & ~(size_t)255), o_z = o_tw + (((n / 2 + 1) * 32 + 255) & ~(size_t)255),
+               o_tab = o_z + ((n * sizeof(Fq) + 255) & ~(size_t)255), total = o_tab + 8 * chunk * sizeof(TU);
+  ZK_HIP(hipMalloc(&buf, total));
+  PtJ* work = (PtJ*)(buf + o_work);
+  uint32_t* tw = (uint32_t*)(buf + o_tw);
+  Fq* zbuf = (Fq*)(buf + o_z);
+  TU* tab = (TU*)(buf + o_tab);
   if (n >= 2) hipLaunchKernelGGL(pfft_twiddle_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, tw, omega, n / 2);
   hipLaunchKernelGGL(pfft_load_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const G1Affine*)d_points, work, log_n);
   for (uint32_t s = 0; s < log_n; ++s)
-    hipLaunchKernelGGL(pfft_stage_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s);
-  hipLaunchKernelGGL(pfft_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, (G1Affine*)d_points, log_n, scale ? 1 : 0,
-                     scale_canon);
-  e = hipGetLastError();
+    for (uint64_t b0 = 0; b0 < n / 2; b0 += chunk) {
+      const uint64_t m = n / 2 - b0 < chunk ? n / 2 - b0 : chunk;
+      hipLaunchKernelGGL(pfft_stage_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s, b0, m, tab, 0, Fr::zero());
+    }
+  if (scale)
+    for (uint64_t b0 = 0; b0 < n; b0 += chunk) {
+      const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
+      hipLaunchKernelGGL(pfft_stage_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, 0u, b0, m, tab, 1, scale_canon);
+    }
+  hipLaunchKernelGGL(pfft_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, (G1Affine*)d_points, zbuf, log_n);
+  hipError_t e = hipGetLastError();
+  int rc = e == hipSuccess ? batch_normalize_g1(d_points, zbuf, n, st) : ZK_ERR_DEVICE;
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  ZK_HIP(fail(e));
-  return ZK_OK;
+  (void)hipFree(buf);
+  ZK_HIP(e);
+  return rc;
 }
 
 }  // namespace zk
