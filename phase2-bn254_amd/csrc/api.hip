@@ -372,6 +372,16 @@ int batch_normalize_g1(void* d_io_affine, const void* d_z, uint64_t n, hipStream
   return ZK_OK;
 }
 
+int batch_normalize_g2(void* d_io_affine, const void* d_z, uint64_t n, hipStream_t st) {
+  if (n == 0) return ZK_OK;
+  constexpr int K = 8;
+  const uint64_t lanes = (n + K - 1) / K;
+  hipLaunchKernelGGL((batch_normalize_kernel<Fq2, K>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, (Affine<Fq2>*)d_io_affine,
+                     (const Fq2*)d_z, n);
+  ZK_HIP(hipGetLastError());
+  return ZK_OK;
+}
+
 // per (device, stream) scratch for the Z coordinates between the two kernels (grow-only; freed at shutdown)
 struct ExpScratch {
   void* p = nullptr;

@@ -2,10 +2,13 @@
 //
 // Reference path: bellman/src/group.rs:22-51 under bellman/src/domain.rs:154-173,274-317, driven by
 // powersoftau/src/bin/prepare_phase2.rs:68-131 (the tau-powers in G2 -> Lagrange basis, `coeffs_g2`).
-// Same network and data flow as point_fft.hip (G1): bit-reversed load into a working array of XYZZ points,
-// one lane per butterfly per stage with the twiddle scalar multiplication done by double-and-add, affine raw
-// records (128 B, all-zero = infinity) in and out.  The group law runs on the memory-format Fq2 arithmetic
-// (curve.hpp / field.hpp); every butterfly is ~380 G2 operations, pure integer-ALU work.
+// Same network and the same program as point_fft.hip (G1): bit-reversed load into a working array of JACOBIAN
+// points, one lane per butterfly per stage, the twiddle multiplication by fixed signed 4-bit windows over a per-lane
+// table {1..8} * t in scratch ([entry][lane]) so that the lanes of a wave add at the same places, affine raw records
+// (128 B, all-zero = infinity) in and out with one inversion per 8 points.  The group law runs on the memory-format
+// Fq2 arithmetic (curve.hpp / field.hpp); table build, doublings and the closing u + t / u - t share ONE inlined
+// jac_double and ONE inlined jac_add (the Fq2 group law is > 100 KB of gfx950 code per copy, and out-of-line calls
+// with these operands go through scratch and crawl).
 #include <hip/hip_runtime.h>
 
 #include "../../include/mi355zk.h"
@@ -13,97 +16,137 @@
 #include "device_util.hpp"
 
 namespace zk {
+
+// api.hip: io[i] = (X, Y), z[i] = Z  ->  affine records, 8 points per inversion
+int batch_normalize_g2(void* d_io_affine, const void* d_z, uint64_t n, hipStream_t st);
+
 namespace {
 
-using P2 = XYZZ<Fq2>;
+using J2 = Jacobian<Fq2>;
 
-__device__ __forceinline__ P2 p2_load(const P2* p) {
-  P2 r;
+__device__ __forceinline__ J2 j2_load(const J2* p) {
+  J2 r;
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint4* d = reinterpret_cast<uint4*>(&r);
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(P2) / 16); ++i) d[i] = q[i];
+  for (int i = 0; i < (int)(sizeof(J2) / 16); ++i) d[i] = q[i];
   return r;
 }
-__device__ __forceinline__ void p2_store(P2* p, const P2& v) {
+__device__ __forceinline__ void j2_store(J2* p, const J2& v) {
   const uint4* s = reinterpret_cast<const uint4*>(&v);
   uint4* d = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(P2) / 16); ++i) d[i] = s[i];
+  for (int i = 0; i < (int)(sizeof(J2) / 16); ++i) d[i] = s[i];
 }
+__device__ __forceinline__ J2 j2_zero() { return J2{Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
 
-// Scalar multiplication is MSB-first double-and-add (the group element ec.rs:544-563 computes).  Each kernel below
-// keeps exactly ONE inlined xyzz_add and ONE inlined xyzz_double: the Fq2 group law is ~150 KB of gfx950 code per
-// copy, and out-of-line (noinline) device calls with these 256-byte operands go through scratch and crawl.
-__global__ void __launch_bounds__(256) pfft2_load_kernel(const G2Affine* __restrict__ in, P2* __restrict__ work, uint32_t log_n) {
+__global__ void __launch_bounds__(256) pfft2_load_kernel(const G2Affine* __restrict__ in, J2* __restrict__ work, uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
   G2Affine a = in[i];
-  P2 v = P2::zero();
-  if (!a.is_zero()) {
-    v.x = a.x;
-    v.y = a.y;
-    v.zz = Fq2::one();
-    v.zzz = Fq2::one();
-  }
+  J2 v = j2_zero();
+  if (!a.is_zero()) v = J2{a.x, a.y, Fq2::one()};
   uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0;
-  p2_store(work + r, v);
+  j2_store(work + r, v);
 }
 
-// stage s (m = 2^s):  t = w^(j * n/2m) * a[k+j+m];  a[k+j+m] = a[k+j] - t;  a[k+j] += t   (domain.rs:303-309).
-// Iterations 0..255 are the bits of the twiddle (skipped for w^0 = 1), iterations 256 / 257 the sum and the difference.
-__global__ void __launch_bounds__(256) pfft2_stage_kernel(P2* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
-                                                         uint32_t s) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= (1u << (log_n - 1))) return;
-  const uint32_t m = 1u << s, j = b & (m - 1);
-  const uint32_t i0 = ((b >> s) << (s + 1)) + j, i1 = i0 + m;
-  const P2 u = p2_load(work + i0);
-  const P2 t = p2_load(work + i1);
-  const uint32_t* k = tw_canon + ((uint64_t)j << (log_n - 1 - s)) * 8;
-  P2 acc = j == 0 ? t : P2::zero();
-  bool found = false;
-  for (int it = j == 0 ? 256 : 0; it < 258; ++it) {
-    P2 A, B;
-    bool do_add = true;
-    if (it < 256) {
-      const int bit = 255 - it;
-      const bool on = (k[bit >> 5] >> (bit & 31)) & 1;
-      if (found) acc = xyzz_double(acc);
-      else found = on;
-      do_add = on;
-      A = acc;
-      B = t;
-    } else {
-      A = u;
-      B = acc;
-      if (it == 257) B.y = neg(B.y);
-    }
-    if (do_add) {
-      xyzz_add(A, B);
-      if (it < 256) acc = A;
-      else p2_store(work + (it == 256 ? i0 : i1), A);
-    }
+// The program of point_fft.hip's pfft_stage_kernel, on memory-format Jacobian points:
+//   steps 0..6 table (2t .. 8t), steps 7..262 the 256 doublings with a digit addition after every 4th,
+//   step 263 entry 1 := product, steps 264 / 265: a[i0] = u + product, a[i1] = u - product   (mode 0, domain.rs:303-309)
+//   mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173)
+__global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
+                                                         uint32_t s, uint64_t b0, uint64_t n_chunk, J2* __restrict__ tab, int mode, Fr c) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunk) return;
+  const uint64_t b = b0 + t;
+  uint64_t i0, i1;
+  uint32_t kk[8];
+  bool unit = false;
+  if (mode == 0) {
+    const uint64_t m = 1ull << s, j = b & (m - 1);
+    i0 = ((b >> s) << (s + 1)) + j;
+    i1 = i0 + m;
+    unit = j == 0;
+    const uint32_t* kp = tw_canon + (j << (log_n - 1 - s)) * 8;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) kk[l] = kp[l];
+  } else {
+    i0 = i1 = b;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) kk[l] = c.l[l];
   }
+  const J2 u = mode == 0 ? j2_load(work + i0) : j2_zero();
+  J2 acc = j2_load(work + i1);
+  // signed 4-bit digits: k = sum d_j 16^j, d_j in [-8, 8]
+  uint32_t mag[8], sgn[2] = {0, 0};
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t d = ((kk[w] >> (4 * q)) & 15u) + carry;
+      carry = d > 8u ? 1u : 0u;
+      if (carry) {
+        d = 16u - d;
+        sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+      }
+      m |= d << (4 * q);
+    }
+    mag[w] = m;
+  }
+  const bool t_inf = acc.is_zero();
+  if (t_inf && mode == 1) return;
+  j2_store(tab + t, acc);
+  constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};  // nibbles: load, double, add, store
+  const int first = (unit || t_inf) ? 263 : 0;
+  const int last = mode == 0 ? 265 : 262;
+#pragma unroll 1
+  for (int step = first; step <= last; ++step) {
+    uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0;
+    if (step < 7) {
+      const uint32_t pr = PROG[step];
+      load = pr >> 12;
+      dbl_it = (pr >> 8) & 15u;
+      add = (pr >> 4) & 15u;
+      store = pr & 15u;
+    } else if (step < 263) {
+      const int m = step - 7;
+      if (m == 0) acc = j2_zero();
+      dbl_it = 1;
+      if ((m & 3) == 3) {
+        const int j = 63 - (m >> 2);
+        add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
+        negate = (sgn[j >> 5] >> (j & 31)) & 1u;
+      }
+    } else if (step == 263) {
+      store = 1;
+    } else {
+      acc = u;
+      add = 1;
+      negate = step == 265;
+    }
+    if (load) acc = j2_load(tab + (uint64_t)(load - 1) * n_chunk + t);
+    if (dbl_it) jac_double(acc);
+    if (add) {
+      J2 o = j2_load(tab + (uint64_t)(add - 1) * n_chunk + t);
+      if (negate) o.y = neg(o.y);
+      jac_add(acc, o);
+    }
+    if (store) j2_store(tab + (uint64_t)(store - 1) * n_chunk + t, acc);
+    if (step == 264) j2_store(work + i0, acc);
+    if (step == 265) j2_store(work + i1, acc);
+  }
+  if (mode == 1) j2_store(work + i0, acc);
 }
 
-__global__ void __launch_bounds__(256) pfft2_store_kernel(const P2* __restrict__ work, G2Affine* __restrict__ out, uint32_t log_n, int scale,
-                                                         Fr c_canon) {
+__global__ void __launch_bounds__(256) pfft2_store_kernel(const J2* __restrict__ work, G2Affine* __restrict__ out, Fq2* __restrict__ zbuf,
+                                                         uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
-  P2 v = p2_load(work + i);
-  if (scale) {
-    const P2 base = v;
-    bool found = false;
-    v = P2::zero();
-    for (int bit = 255; bit >= 0; --bit) {
-      const bool on = (c_canon.l[bit >> 5] >> (bit & 31)) & 1;
-      if (found) v = xyzz_double(v);
-      else found = on;
-      if (on) xyzz_add(v, base);
-    }
-  }
-  out[i] = xyzz_to_affine(v);
+  const J2 r = j2_load(work + i);
+  out[i] = G2Affine{r.x, r.y};
+  zbuf[i] = r.z;
 }
 
 __global__ void pfft2_twiddle_kernel(uint32_t* tw, Fr omega, uint64_t count) {
@@ -119,22 +162,35 @@ __global__ void pfft2_twiddle_kernel(uint32_t* tw, Fr omega, uint64_t count) {
 // d_points: 2^log_n affine raw G2 records (128 B), in place.  scale: every output is multiplied by scale_canon (ifft: m^-1).
 int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st) {
   const uint64_t n = 1ull << log_n;
-  P2* work = nullptr;
-  uint32_t* tw = nullptr;
-  ZK_HIP(hipMalloc(&work, n * sizeof(P2)));
-  hipError_t e = hipMalloc(&tw, (n / 2 + 1) * 32);
-  if (e != hipSuccess) { (void)hipFree(work); ZK_HIP(e); }
-  auto fail = [&](hipError_t err) { (void)hipFree(work); (void)hipFree(tw); return err; };
+  const uint64_t lanes_max = scale ? n : (n >= 2 ? n / 2 : 1);
+  const uint64_t chunk = lanes_max < (1ull << 19) ? lanes_max : (1ull << 19);  // table: 8 x 192 B per lane
+  char* buf = nullptr;
+  const size_t o_work = 0, o_tw = o_work + ((n * sizeof(J2) + 255) & ~(size_t)255), o_z = o_tw + (((n / 2 + 1) * 32 + 255) & ~(size_t)255),
+               o_tab = o_z + ((n * sizeof(Fq2) + 255) & ~(size_t)255), total = o_tab + 8 * chunk * sizeof(J2);
+  ZK_HIP(hipMalloc(&buf, total));
+  J2* work = (J2*)(buf + o_work);
+  uint32_t* tw = (uint32_t*)(buf + o_tw);
+  Fq2* zbuf = (Fq2*)(buf + o_z);
+  J2* tab = (J2*)(buf + o_tab);
   if (n >= 2) hipLaunchKernelGGL(pfft2_twiddle_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, tw, omega, n / 2);
   hipLaunchKernelGGL(pfft2_load_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const G2Affine*)d_points, work, log_n);
   for (uint32_t s = 0; s < log_n; ++s)
-    hipLaunchKernelGGL(pfft2_stage_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s);
-  hipLaunchKernelGGL(pfft2_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, (G2Affine*)d_points, log_n, scale ? 1 : 0,
-                     scale_canon);
-  e = hipGetLastError();
+    for (uint64_t b0 = 0; b0 < n / 2; b0 += chunk) {
+      const uint64_t m = n / 2 - b0 < chunk ? n / 2 - b0 : chunk;
+      hipLaunchKernelGGL(pfft2_stage_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s, b0, m, tab, 0, Fr::zero());
+    }
+  if (scale)
+    for (uint64_t b0 = 0; b0 < n; b0 += chunk) {
+      const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
+      hipLaunchKernelGGL(pfft2_stage_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, 0u, b0, m, tab, 1, scale_canon);
+    }
+  hipLaunchKernelGGL(pfft2_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, (G2Affine*)d_points, zbuf, log_n);
+  hipError_t e = hipGetLastError();
+  int rc = e == hipSuccess ? batch_normalize_g2(d_points, zbuf, n, st) : ZK_ERR_DEVICE;
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  ZK_HIP(fail(e));
-  return ZK_OK;
+  (void)hipFree(buf);
+  ZK_HIP(e);
+  return rc;
 }
 
 }  // namespace zk
