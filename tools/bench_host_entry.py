@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the HOST-buffer entry point mi355zk_bn254_g1_msm (what a bellman shim calls when the CRS is not
+kept on the device): bases and scalars start in pageable host memory, every call uploads both.  Never bench.py's `value`."""
+import argparse, ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import phase2_bn254_amd as zk, inputs, bench
+
+ap = argparse.ArgumentParser(); ap.add_argument("--log-n", type=int, nargs="+", default=[20, 24]); ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+L = zk.lib.load(); w = zk.Worker(0); dev = torch.device("cuda", 0)
+gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+out = {}
+for ln in a.log_n:
+    n = 1 << ln
+    k = bench.gen_scalars(n, 5, dev); s = bench.gen_scalars(n, 6, dev)
+    b = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    assert L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(b.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+    want = zk.multiexp(w, (b, 0), zk.FullDensity(), s).wait()
+    hb, hs = b.cpu().numpy().view(np.uint64), s.cpu().numpy().view(np.uint64)
+    del b, s, k
+    got = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()
+    t = time.perf_counter()
+    for _ in range(a.iters): got = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()
+    dt = (time.perf_counter() - t) / a.iters
+    out[f"2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mscalar_mul_per_s": round(n / dt / 1e6, 1), "host_bytes_per_call": 96 * n,
+                      "effective_GBs_incl_compute": round(96 * n / dt / 1e9, 2), "same_result_as_device_resident": bool(np.array_equal(got, want))}
+print(json.dumps({"entry": "mi355zk_bn254_g1_msm (host buffers, pageable)", **out}))
