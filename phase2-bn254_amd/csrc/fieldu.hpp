@@ -187,6 +187,21 @@ ZK_HD FpU<PR> u_sub(const FpU<PR>& a, const FpU<PR>& b) {
   return u_carry(t);
 }
 
+// acc += a * b.  With ZK_CHAIN_MAD (defined by a translation unit before it includes this header) every accumulation
+// on the device is followed by an EMPTY asm statement that pins `acc` in a VGPR pair: hipcc cannot reassociate the
+// column sum across it, so each column is ONE dependent chain of v_mad_u64_u32 seeded with the carry of the previous
+// column.  Left alone, hipcc splits every column into two chains (latency) and merges them with a 64-bit add
+// (v_lshl_add_u64) -- 144 extra instructions per mixed addition.  Whether that pays depends on the kernel: with
+// 4 waves per SIMD the chain latency is hidden (msm_accumulate_kernel<Fq> 61.3 -> 59.0 ms, ntt_pass_kernel -2 %), the
+// register-heavier kernels (Fq2 accumulation, the windowed scalar multiplications) lose.  The s_nop hipcc pads after
+// each asm statement issues on the scalar port and costs next to nothing.
+ZK_HD void u_mad(uint64_t& acc, uint32_t a, uint32_t b) {
+  acc += (uint64_t)a * b;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_CHAIN_MAD)
+  asm("" : "+v"(acc));
+#endif
+}
+
 // Montgomery product on 29-bit limbs: a * b * 2^-261 mod p.
 //   preconditions: max_limb(a) * max_limb(b) < 2^60.5 (e.g. both < 2^30, or one < 2^29 and the other < 2^31.5),
 //                  so that every column sum (9 products + 9 m_i*p_j terms + carry) stays below 2^64.
@@ -203,20 +218,20 @@ ZK_HD FpU<PR> u_mul(const FpU<PR>& a, const FpU<PR>& b) {
     for_limbs<9>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int j = k - i;
-      if constexpr (j >= 0 && j < 9) acc += (uint64_t)a.l[i] * b.l[j];
+      if constexpr (j >= 0 && j < 9) u_mad(acc, a.l[i], b.l[j]);
     });
     for_limbs<9>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int j = k - i;
       if constexpr (j >= 0 && j < 9 && (k >= 9 || i < k)) {
         constexpr uint32_t pj = UParams<PR>::P(j);
-        acc += (uint64_t)m[i] * pj;
+        u_mad(acc, m[i], pj);
       }
     });
     if constexpr (k < 9) {
       constexpr uint32_t p0 = UParams<PR>::P(0);
       m[k] = ((uint32_t)acc * UParams<PR>::INV) & U_MASK;
-      acc += (uint64_t)m[k] * p0;  // low 29 bits are now zero
+      u_mad(acc, m[k], p0);  // low 29 bits are now zero
     } else {
       r.l[k - 9] = (uint32_t)acc & U_MASK;
     }
@@ -241,13 +256,13 @@ ZK_HD FpU<PR> u_montgomery_columns(ProductTerms&& terms) {
       constexpr int j = k - i;
       if constexpr (j >= 0 && j < 9 && (k >= 9 || i < k)) {
         constexpr uint32_t pj = UParams<PR>::P(j);
-        acc += (uint64_t)m[i] * pj;
+        u_mad(acc, m[i], pj);
       }
     });
     if constexpr (k < 9) {
       constexpr uint32_t p0 = UParams<PR>::P(0);
       m[k] = ((uint32_t)acc * UParams<PR>::INV) & U_MASK;
-      acc += (uint64_t)m[k] * p0;  // low 29 bits are now zero
+      u_mad(acc, m[k], p0);  // low 29 bits are now zero
     } else {
       r.l[k - 9] = (uint32_t)acc & U_MASK;
     }
@@ -271,8 +286,8 @@ ZK_HD FpU<PR> u_sqr(const FpU<PR>& a) {
       constexpr int i = decltype(ic)::value;
       constexpr int j = k - i;
       if constexpr (j >= 0 && j < 9) {
-        if constexpr (i < j) acc += (uint64_t)a2[i] * a.l[j];
-        else if constexpr (i == j) acc += (uint64_t)a.l[i] * a.l[i];
+        if constexpr (i < j) u_mad(acc, a2[i], a.l[j]);
+        else if constexpr (i == j) u_mad(acc, a.l[i], a.l[i]);
       }
     });
   });
@@ -289,8 +304,8 @@ ZK_HD FpU<PR> u_mul2(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const
       constexpr int i = decltype(ic)::value;
       constexpr int j = k - i;
       if constexpr (j >= 0 && j < 9) {
-        acc += (uint64_t)a.l[i] * b.l[j];
-        acc += (uint64_t)c.l[i] * d.l[j];
+        u_mad(acc, a.l[i], b.l[j]);
+        u_mad(acc, c.l[i], d.l[j]);
       }
     });
   });
@@ -308,10 +323,10 @@ ZK_HD FpU<PR> u_mul4(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const
       constexpr int i = decltype(ic)::value;
       constexpr int j = k - i;
       if constexpr (j >= 0 && j < 9) {
-        acc += (uint64_t)a.l[i] * b.l[j];
-        acc += (uint64_t)c.l[i] * d.l[j];
-        acc += (uint64_t)e.l[i] * f.l[j];
-        acc += (uint64_t)g.l[i] * h.l[j];
+        u_mad(acc, a.l[i], b.l[j]);
+        u_mad(acc, c.l[i], d.l[j]);
+        u_mad(acc, e.l[i], f.l[j]);
+        u_mad(acc, g.l[i], h.l[j]);
       }
     });
   });

@@ -1,4 +1,5 @@
 // G1 instantiation of the Pippenger pipeline (msm_impl.hpp); see there for the design.
+#define ZK_CHAIN_MAD 1  // fieldu.hpp u_mad: one dependent mad chain per column (measured faster in this TU)
 #include "msm_impl.hpp"
 
 namespace zk {

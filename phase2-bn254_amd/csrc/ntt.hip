@@ -23,6 +23,7 @@
 // are carried every 4th stage (the bound of each call is noted at the call).
 // The mathematical result X[k] = sum_i a[i] w^(ik) is unique and the stored elements are fully
 // reduced, so the output bytes are identical to serial_fft's.
+#define ZK_CHAIN_MAD 1  // fieldu.hpp u_mad: one dependent mad chain per column (measured faster in this TU)
 #include <hip/hip_runtime.h>
 
 #include <map>
