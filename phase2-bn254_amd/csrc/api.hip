@@ -336,30 +336,32 @@ __global__ void __launch_bounds__(256) batch_normalize_kernel(Affine<F>* __restr
   if (i0 >= n) return;
   F pre[K];
   F run = F::one();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
+  // for_limbs: the index is a compile-time constant, which keeps pre[] in registers (a "#pragma unroll" over these bodies is refused)
+  for_limbs<K>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     pre[k] = run;
     if (i0 + k < n) {
       const F zk = z[i0 + k];
       if (!zk.is_zero()) run = mul(run, zk);
     }
-  }
+  });
   F inv_run = inv(run);
-#pragma unroll
-  for (int k = K - 1; k >= 0; --k) {
-    if (i0 + k >= n) continue;
-    const F zk = z[i0 + k];
-    Affine<F> p{F::zero(), F::zero()};
-    if (!zk.is_zero()) {
-      const F zi = mul(inv_run, pre[k]);
-      inv_run = mul(inv_run, zk);
-      const F zi2 = sqr(zi);
-      const Affine<F> xy = io[i0 + k];
-      p.x = mul(xy.x, zi2);
-      p.y = mul(xy.y, mul(zi2, zi));
+  for_limbs<K>([&](auto kc) {
+    constexpr int k = K - 1 - decltype(kc)::value;
+    if (i0 + k < n) {
+      const F zk = z[i0 + k];
+      Affine<F> p{F::zero(), F::zero()};
+      if (!zk.is_zero()) {
+        const F zi = mul(inv_run, pre[k]);
+        inv_run = mul(inv_run, zk);
+        const F zi2 = sqr(zi);
+        const Affine<F> xy = io[i0 + k];
+        p.x = mul(xy.x, zi2);
+        p.y = mul(xy.y, mul(zi2, zi));
+      }
+      io[i0 + k] = p;
     }
-    io[i0 + k] = p;
-  }
+  });
 }
 
 int batch_normalize_g1(void* d_io_affine, const void* d_z, uint64_t n, hipStream_t st) {
