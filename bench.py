@@ -39,6 +39,10 @@ LOG_SHARD = 20  # input-generation granularity: identical total input for every 
 R_TOP = 0x30644E72E131A029  # most-significant u64 limb of r
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SCALAR_MUL = 96  # 64 B affine base + 32 B scalar, each read once
+MADS_PER_MIXED_ADD = 1467  # curveu.hpp xyzzu_add_mixed: 7 u_mul (162) + 2 u_sqr (126) + 1 u_mul2 (243) v_mad_u64_u32
+# integer-multiplier peak: one wave64 v_mad_u64_u32 per 4 cycles per SIMD (tools/ubench_valu.hip) = 16 lane-mads / cycle / SIMD,
+# 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+MAD_PEAK_PER_S = 16 * 4 * 256 * 2.4e9
 
 
 def gen_scalars(n: int, seed: int, device) -> torch.Tensor:
@@ -217,7 +221,12 @@ def main() -> int:
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6) if achieved else None,
                          "traffic": traffic,
                          "kernel_ms": {k: (round(v, 4) if v is not None else None) for k, v in kern.items()},
-                         "alu_model": {"fq_mul_per_s": fq_mul_per_s, "note": "W*10 Fq mul per scalar-mul in msm_accumulate; MSM is integer-ALU bound (SURVEY 8d)"}},
+                         "alu_model": {"fq_mul_per_s": fq_mul_per_s,
+                                       "mad_u64_u32_per_s": (nw.value * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3)) if acc_ms else None,
+                                       "mad_peak_per_s": MAD_PEAK_PER_S,
+                                       "frac": round(nw.value * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3) / MAD_PEAK_PER_S, 4) if acc_ms else None,
+                                       "note": "W mixed adds (10 Fq products = 1467 v_mad_u64_u32) per scalar-mul in msm_accumulate; "
+                                               "MSM is integer-ALU bound (SURVEY 8d), the multiplier instructions alone are this fraction of peak issue"}},
             "result_affine_x_limb0": hex(int(aff[0])),
             "full_size_linearity_check": additive_ok,
             "input_gen_s": round(t_gen, 2),
