@@ -30,6 +30,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -52,11 +53,17 @@ constexpr uint32_t SIGN_BIT = 0x80000000u;
 // digits (d in [-2^(width-1), 2^(width-1)], width <= c); the TOP window is at most c-1 bits wide and keeps its
 // digits unsigned (value + carry <= 2^(c-1) = nb), which is also what absorbs the final carry.
 struct MsmGeom {
-  uint32_t c;        // widest window, bits
+  uint32_t c;        // bits of the sort field: bucket slots 0..nb-1, nb itself = "no bucket"
   uint32_t W;        // windows
-  uint32_t nb;       // bucket slots per window = 2^(c-1) (narrower windows leave their upper slots empty)
-  uint8_t width[64]; // bits of window w (c >= 4: at most 64 windows)
-  uint8_t shift[64]; // first bit of window w
+  uint32_t nb;       // bucket slots per window (power-of-two layout: 2^(c-1); narrower windows leave their upper slots empty)
+  uint8_t width[64]; // power-of-two layout: bits of window w (c >= 4: at most 64 windows)
+  uint8_t shift[64]; // power-of-two layout: first bit of window w
+  // MIXED-RADIX layout (rmul != 1): digits in base B = rmul * 2^rshift instead of a power of two, so that the window
+  // count is not tied to whole bits -- 254 bits in 12 windows need 21.2 bits each: B = 5 * 2^19 takes 12 windows of
+  // 1.31 M buckets where c = 20 takes 13 (one accumulation pass and one sort-pass share less) and c = 22 would pay
+  // 2.1 M buckets per window in the reduction.  k = sum_w d_w B^w, d_w in (-B/2, B/2], top digit unsigned <= nb = B/2.
+  uint32_t rmul;     // 1 (power-of-two layout), 3 or 5
+  uint32_t rshift;
 };
 
 template <class F>
@@ -119,6 +126,50 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   // (dense_multiexp of powersoftau/src/utils.rs:189-292 has no such check: there infinity bases simply add nothing)
   if (check_identity && load_affine(bases + bi).is_zero()) atomicMin(err_index, (unsigned long long)i);
   uint32_t carry = 0;
+  if (G.rmul != 1) {
+    // mixed radix: repeatedly  low = q mod 2^rshift;  q >>= rshift;  (q, r) = divmod(q, rmul);  digit = low + 2^rshift * r
+    uint32_t q[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) q[l] = s[l];
+    const uint32_t sh = G.rshift, B = G.rmul << sh;
+    for (uint32_t w = 0; w < G.W; ++w) {
+      uint32_t d, neg = 0;
+      if (w + 1 < G.W) {
+        const uint32_t low = q[0] & ((1u << sh) - 1u);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
+        uint32_t rem = 0;
+        if (G.rmul == 3) {
+#pragma unroll
+          for (int l = 7; l >= 0; --l) {
+            const uint64_t cur = ((uint64_t)rem << 32) | q[l];
+            q[l] = (uint32_t)(cur / 3u);
+            rem = (uint32_t)(cur % 3u);
+          }
+        } else {
+#pragma unroll
+          for (int l = 7; l >= 0; --l) {
+            const uint64_t cur = ((uint64_t)rem << 32) | q[l];
+            q[l] = (uint32_t)(cur / 5u);
+            rem = (uint32_t)(cur % 5u);
+          }
+        }
+        d = low + (rem << sh) + carry;
+        carry = 0;
+        if (d > G.nb) {          // d in (B/2, B]  ->  d - B in (-B/2, 0]
+          d = B - d;
+          neg = d ? SIGN_BIT : 0;
+          carry = 1;
+        }
+      } else {
+        d = q[0] + carry;        // top digit, unsigned: <= nb by the choice of B (make_geom_radix)
+      }
+      const uint64_t o = (uint64_t)w * n + i;
+      keys[o] = (w << G.c) | (d ? d - 1 : G.nb);
+      vals[o] = (uint32_t)bi | neg;
+    }
+    return;
+  }
   for (uint32_t w = 0; w < G.W; ++w) {
     const uint32_t width = G.width[w], bit = G.shift[w];
     uint32_t limb = bit >> 5, off = bit & 31;
@@ -132,7 +183,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       carry = 1;
     }
     uint64_t o = (uint64_t)w * n + i;
-    keys[o] = (w << G.c) | (d ? d - 1 : G.nb);  // sort field = low c bits: bucket, or 2^(c-1) = "no bucket" (sorts last)
+    keys[o] = (w << G.c) | (d ? d - 1 : G.nb);  // sort field = low c bits: bucket, or nb = "no bucket" (sorts last)
     vals[o] = (uint32_t)bi | neg;
   }
 }
@@ -531,6 +582,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // widths for a maximum window size c: top window c-1 bits (unsigned), the rest as even as possible, all <= c
 MsmGeom make_geom(uint32_t c) {
   MsmGeom G{};
+  G.rmul = 1;
   G.c = c;
   uint32_t W = 1;
   while ((W - 1) * c + (c - 1) < 254) ++W;      // smallest W with (W-1) windows of <= c bits + a top window of <= c-1 bits
@@ -551,27 +603,61 @@ MsmGeom make_geom(uint32_t c) {
   return G;
 }
 
+// mixed-radix layout: B = rmul * 2^rshift, nb = B/2, the smallest W with B^(W-1) * nb >= 2^254 (scalars are < r < 2^254)
+MsmGeom make_geom_radix(uint32_t rmul, uint32_t rshift) {
+  MsmGeom G{};
+  G.rmul = rmul;
+  G.rshift = rshift;
+  const double B = std::ldexp((double)rmul, (int)rshift);
+  G.nb = (rmul << rshift) / 2;
+  G.c = 1;
+  while ((1u << G.c) <= G.nb) ++G.c;           // field values 0..nb
+  uint32_t W = 2;
+  while ((W - 1) * std::log2(B) + std::log2((double)G.nb) < 254.001) ++W;
+  G.W = W;
+  return G;
+}
+
+double geom_cost(double W, double nbk, double field_bits, uint64_t n) {
+  // per (point, window): one mixed add (10 units) + one radix-sort pass per 8 key bits (0.7 units each,
+  // measured); per bucket: ~45 units of reduction
+  double cost = W * ((10.0 + 0.7 * std::ceil(field_bits / 8.0)) * (double)n + 45.0 * nbk);
+  // occupancy term: fewer than ~2^17 bucket lanes leaves CUs idle during accumulation
+  double lanes = W * nbk;
+  if (lanes < 131072.0) cost *= (1.0 + 0.5 * (131072.0 / lanes - 1.0));
+  return cost;
+}
+
 MsmGeom choose_geom(uint64_t n, int group) {
   static const char* env = std::getenv("MI355ZK_MSM_C");
+  static const char* env_radix = std::getenv("MI355ZK_MSM_RADIX");  // "0": power-of-two layouts only; "m,s": force B = m * 2^s (m = 3 or 5)
+  (void)group;
+  if (env_radix) {
+    int rm = 0, rs = 0;
+    if (std::sscanf(env_radix, "%d,%d", &rm, &rs) == 2 && (rm == 3 || rm == 5) && rs >= 2 && rs <= 22) return make_geom_radix((uint32_t)rm, (uint32_t)rs);
+  }
+  if (env) {
+    int v = std::atoi(env);
+    if (v >= 2 && v <= 24) return make_geom((uint32_t)v);
+  }
   uint32_t best_c = 0;
   double best = 1e300;
   for (uint32_t c = 4; c <= 24; ++c) {
     double W = std::ceil((254.0 + 1.0) / c);  // (W-1)*c + (c-1) >= 254
-    double nbk = std::ldexp(1.0, (int)c - 1);
-    // per (point, window): one mixed add (10 units) + one radix-sort pass per 8 key bits (0.7 units each,
-    // measured); per bucket: ~45 units of reduction
-    double cost = W * ((10.0 + 0.7 * std::ceil(c / 8.0)) * (double)n + 45.0 * nbk);
-    // occupancy term: fewer than ~2^17 bucket lanes leaves CUs idle during accumulation
-    double lanes = W * nbk;
-    if (lanes < 131072.0) cost *= (1.0 + 0.5 * (131072.0 / lanes - 1.0));
+    double cost = geom_cost(W, std::ldexp(1.0, (int)c - 1), c, n);
     if (cost < best) { best = cost; best_c = c; }
   }
-  (void)group;
-  if (env) {
-    int v = std::atoi(env);
-    if (v >= 2 && v <= 24) best_c = (uint32_t)v;
-  }
-  return make_geom(best_c);
+  MsmGeom G = make_geom(best_c);
+  if (env_radix && env_radix[0] == '0') return G;
+  // a mixed-radix layout must win by 1.5 % to be taken (its host join is slightly longer)
+  for (uint32_t rmul = 3; rmul <= 5; rmul += 2)
+    for (uint32_t rshift = 6; rshift <= 22; ++rshift) {
+      MsmGeom R = make_geom_radix(rmul, rshift);
+      if (R.W > 64 || R.c > 24) continue;
+      double cost = geom_cost(R.W, R.nb, R.c, n);
+      if (cost < 0.985 * best) { best = cost / 0.985; G = R; }
+    }
+  return G;
 }
 
 template <class F>
@@ -790,17 +876,38 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       e_lv += lvl_logl[lv];
     }
     for (uint32_t j = 0; j < final_bits; ++j) e_k[n_levels + j] = e_lv + j;
-    const uint32_t t_max = G.shift[G.W - 1] + e_k[n_out - 1];
-    std::vector<Jacobian<F>> by_exp((size_t)t_max + 1, Jacobian<F>::zero());
-    for (uint32_t w = 0; w < G.W; ++w)
-      for (uint32_t k = 0; k < n_out; ++k) {
-        const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
-        if (!pt.is_zero()) jac_add(by_exp[G.shift[w] + e_k[k]], xyzz_to_jacobian(pt));
+    auto horner = [](std::vector<Jacobian<F>>& by_exp) {  // sum_t 2^t by_exp[t]
+      Jacobian<F> acc = by_exp.back();
+      for (int t = (int)by_exp.size() - 2; t >= 0; --t) {
+        jac_double(acc);
+        if (!by_exp[t].is_zero()) jac_add(acc, by_exp[t]);
       }
-    Jacobian<F> acc = by_exp[t_max];
-    for (int t = (int)t_max - 1; t >= 0; --t) {
-      jac_double(acc);
-      if (!by_exp[t].is_zero()) jac_add(acc, by_exp[t]);
+      return acc;
+    };
+    Jacobian<F> acc;
+    if (G.rmul == 1) {
+      std::vector<Jacobian<F>> by_exp((size_t)G.shift[G.W - 1] + e_k[n_out - 1] + 1, Jacobian<F>::zero());
+      for (uint32_t w = 0; w < G.W; ++w)
+        for (uint32_t k = 0; k < n_out; ++k) {
+          const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
+          if (!pt.is_zero()) jac_add(by_exp[G.shift[w] + e_k[k]], xyzz_to_jacobian(pt));
+        }
+      acc = horner(by_exp);
+    } else {
+      // mixed radix: T_w by its own Horner pass, then  acc = B * acc + T_w  with  B = rmul * 2^rshift
+      acc = Jacobian<F>::zero();
+      for (int w = (int)G.W - 1; w >= 0; --w) {
+        std::vector<Jacobian<F>> by_exp((size_t)e_k[n_out - 1] + 1, Jacobian<F>::zero());
+        for (uint32_t k = 0; k < n_out; ++k) {
+          const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
+          if (!pt.is_zero()) jac_add(by_exp[e_k[k]], xyzz_to_jacobian(pt));
+        }
+        const Jacobian<F> one_acc = acc;            // rmul * acc = (rmul - 1) * acc + acc, rmul - 1 in {2, 4}
+        for (uint32_t r = G.rmul - 1; r > 1; r >>= 1) jac_double(acc);
+        jac_add(acc, one_acc);
+        for (uint32_t r = 0; r < G.rshift; ++r) jac_double(acc);
+        jac_add(acc, horner(by_exp));
+      }
     }
     *result = acc;
     return (int)ZK_OK;
