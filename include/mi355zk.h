@@ -104,7 +104,8 @@ int mi355zk_bn254_g1_merge_pairs_dev(const void *d_v1, const void *d_v2, const v
 int mi355zk_bn254_g2_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[24], uint64_t out_sx[24]);
 /* exponent index at which the last failing multiexp of this thread raised its error, or -1 */
 long long mi355zk_last_error_index(void);
-/* window size c and window count the library would use for n scalars (diagnostics / DESIGN.md) */
+/* bits of the bucket field (c for the power-of-two window layouts, ceil(log2(B/2 + 1)) for the mixed-radix ones) and
+ * the window count the library would use for n scalars (diagnostics / DESIGN.md section 4) */
 int mi355zk_msm_window_bits(size_t n_scalars, int *n_windows);
 
 /* ---- Fr NTT.  Replaces bellman/src/domain.rs:263 `best_fft` for T = Scalar<Bn256>:
