@@ -82,4 +82,6 @@ def test_window_geometry_is_sane():
     for n in (1, 100, 1 << 16, 1 << 20, 1 << 26):
         nw = C.c_int()
         c = lib.mi355zk_msm_window_bits(n, C.byref(nw))
-        assert 2 <= c <= 24 and nw.value * c >= 254 and (nw.value - 1) * c < 254 + c
+        # c = bits of the bucket field: nb <= 2^c - 1 slots per window, digits in base B = 2 nb (a power of two or 3 / 5 times
+        # one), so 2^(c-1) <= B <= 2^(c+1): the windows must cover 254 bits without a spare one
+        assert 2 <= c <= 24 and nw.value * (c + 1) >= 254 and (nw.value - 1) * (c - 1) < 254 + c
