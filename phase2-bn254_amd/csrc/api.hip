@@ -612,7 +612,25 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
   if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index);
   else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index);
   if (d_density) (void)hipFree(d_density);
-  if (rc == ZK_ERR_UNEXPECTED_IDENTITY) { t_last_err_index = err_index; return rc; }
+  if (rc == ZK_ERR_UNEXPECTED_IDENTITY) {
+    // the kernels report the lowest BASE index that was the identity under a non-zero exponent; the exponent that owns it
+    // is the (index - base_offset)-th selected one (source.rs:101-118): itself under FullDensity
+    long long rank = err_index - (long long)base_offset;
+    if (density != nullptr) {
+      size_t w = 0;
+      const size_t words = (n + 31) / 32;
+      while (w + 1 < words && (long long)P.prefix[w + 1] <= rank) ++w;
+      uint32_t word = density[w];
+      if ((w + 1) * 32 > n) word &= (n & 31) ? ((1u << (n & 31)) - 1u) : 0xffffffffu;
+      long long need = rank - (long long)P.prefix[w];
+      uint32_t b = 0;
+      for (; b < 32; ++b)
+        if ((word >> b) & 1u) { if (need == 0) break; --need; }
+      rank = (long long)(w * 32 + b);
+    }
+    t_last_err_index = rank;
+    return rc;
+  }
   if (rc != ZK_OK) return rc;
   if (P.eof_index >= 0) { t_last_err_index = P.eof_index; return ZK_ERR_UNEXPECTED_EOF; }
   return ZK_OK;

@@ -99,11 +99,9 @@ __device__ __forceinline__ T load_vec(const T* p) {
 //    Otherwise bit i of `density` selects exponent i and the bases are compacted (source.rs:101-118):
 //    rank(i) = dprefix[i/32] + popc(density[i/32] & ((1<<i%32)-1)).
 template <class F>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, const Affine<F>* __restrict__ bases,
-                                                        uint64_t n, uint64_t base_offset, const uint32_t* __restrict__ density,
-                                                        const uint32_t* __restrict__ dprefix, MsmGeom G, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, unsigned long long* __restrict__ err_index,
-                                                        int check_identity) {
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t base_offset,
+                                                        const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
+                                                        MsmGeom G, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool active = true;
@@ -122,9 +120,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
     for (uint32_t w = 0; w < G.W; ++w) keys[(uint64_t)w * n + i] = (w << G.c) | G.nb;
     return;
   }
-  // a selected base with a non-zero exponent must not be the identity (source.rs:50-52)
-  // (dense_multiexp of powersoftau/src/utils.rs:189-292 has no such check: there infinity bases simply add nothing)
-  if (check_identity && load_affine(bases + bi).is_zero()) atomicMin(err_index, (unsigned long long)i);
+  // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is loaded
+  // anyway, in accumulate_run -- testing it here cost a second pass over all bases)
   uint32_t carry = 0;
   if (G.rmul != 1) {
     // mixed radix: repeatedly  low = q mod 2^rshift;  q >>= rshift;  (q, r) = divmod(q, rmul);  digit = low + 2^rshift * r
@@ -302,7 +299,10 @@ constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take 
 
 template <class F>
 __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
-                                                  uint32_t stride, bool skip_zero) {
+                                                  uint32_t stride, bool skip_zero, unsigned long long* __restrict__ err_base) {
+  // the all-zero record is the point at infinity (no curve point has y == 0).  skip_zero (dense mode, powersoftau's
+  // dense_multiexp): it adds nothing.  Otherwise it is the reference's UnexpectedIdentity (source.rs:50-52: a selected base
+  // with a non-zero exponent): the lowest such BASE index is reported and the record skipped.
   if constexpr (std::is_same<F, Fq>::value) {
     XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
     if (j >= e) return XYZZ<F>::zero();
@@ -320,8 +320,8 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
         vn = vals[jn];
         pn = load_affine(bases + (vn & ~SIGN_BIT));
       }
-      if (!(skip_zero && p.y.is_zero()))  // dense mode: the all-zero record (no curve point has y == 0) adds nothing
-        xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+      if (!p.y.is_zero()) xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+      else if (!skip_zero) atomicMin(err_base, (unsigned long long)(v & ~SIGN_BIT));
       if (!more) break;
       v = vn;
       p = pn;
@@ -333,7 +333,10 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
     for (; j < e; j += stride) {
       uint32_t v = vals[j];
       Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
-      if (skip_zero && p.y.is_zero()) continue;
+      if (p.y.is_zero()) {
+        if (!skip_zero) atomicMin(err_base, (unsigned long long)(v & ~SIGN_BIT));
+        continue;
+      }
       xyzzu2_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
     return xyzzu2_to_std(acc);
@@ -383,7 +386,8 @@ template <class F>
 __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                                   const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_off,
-                                                                  uint32_t hb, XYZZ<F>* __restrict__ seg_sums, int skip_zero) {
+                                                                  uint32_t hb, XYZZ<F>* __restrict__ seg_sums, int skip_zero,
+                                                                  unsigned long long* __restrict__ err_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t total = item_off[hb];
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
     const uint32_t b = order[lo];
     const uint32_t j0 = first[b] + (item - item_off[lo]) * MSM_HEAVY_SEG;
     const uint32_t e = j0 + MSM_HEAVY_SEG < last[b] ? j0 + MSM_HEAVY_SEG : last[b];
-    sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0);
+    sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0, err_base);
     __syncthreads();
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
       if (threadIdx.x < s) {
@@ -447,13 +451,13 @@ template <class F>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                             const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
-                                                            XYZZ<F>* __restrict__ buckets, int skip_zero) {
+                                                            XYZZ<F>* __restrict__ buckets, int skip_zero, unsigned long long* __restrict__ err_base) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_buckets) return;
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
   if (i < hb && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
-  store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1, skip_zero != 0));
+  store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1, skip_zero != 0, err_base));
 }
 
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
@@ -767,8 +771,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
                    slot_red = prof_slot("msm_reduce");
 
   prof_begin(slot_digits, st);
-  hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_bases, n, base_offset,
-                     d_density, d_dprefix, G, keys_a, vals_a, d_err, dense ? 0 : 1);
+  hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, base_offset,
+                     d_density, d_dprefix, G, keys_a, vals_a);
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
   if (checkpoint("digits")) return ZK_ERR_DEVICE;
@@ -789,7 +793,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       ZK_HIP(hipGetLastError());
       const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
       hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st,
-                         bases_set, vals_b, first, last, order, item_off, hb, seg_sums, dense ? 1 : 0);
+                         bases_set, vals_b, first, last, order, item_off, hb, seg_sums, dense ? 1 : 0, d_err);
       ZK_HIP(hipGetLastError());
       hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off,
                          hb, buckets);
@@ -797,7 +801,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       prof_end(slot_heavy, st);
       prof_begin(slot_acc, st);
       hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order, heavy,
-                         hb, n_buckets, buckets, dense ? 1 : 0);
+                         hb, n_buckets, buckets, dense ? 1 : 0, d_err);
       ZK_HIP(hipGetLastError());
     }
     prof_end(slot_acc, st);
@@ -972,11 +976,11 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
   const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
   hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st, d_points,
-                     vals, first, last, order, item_off, hb, seg_sums, 1);
+                     vals, first, last, order, item_off, hb, seg_sums, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, hb,
                      buckets);
   hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
-                     n_rows, buckets, 1);
+                     n_rows, buckets, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_to_affine_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, buckets, d_out, n_rows);
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipStreamSynchronize(st));  // the workspace is shared: finish before releasing the lock
