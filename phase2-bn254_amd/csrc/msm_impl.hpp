@@ -9,14 +9,15 @@
 //
 // MI355X design (DESIGN.md "MSM"), not the reference's one-thread-per-window scan:
 //   1. msm_digits_kernel      every scalar -> W signed digits; one (key, base index | sign) pair per window, written
-//                             window-major; identity-base check (source.rs:50-52) fused in.
+//                             window-major.
 //   2. radix sort             rocPRIM onesweep on the LOW c key bits only (stable + window-major input keeps every
 //                             (window, bucket) run contiguous); HBM-bound, ~3 passes over 8 B/pair.
 //   3. msm_bounds_kernel      first/last position of every bucket in the sorted pair list;
 //      msm_size_*_kernel      counting sort of the buckets by size (wave-level load balance, heavy buckets first).
 //   4. msm_accumulate_kernel  ONE LANE PER BUCKET for all W * 2^(c-1) buckets at once (2^19 lanes at
 //                             2^20 points), in size order: gathers its affine bases and folds them into a U-form
-//                             XYZZ accumulator held in VGPRs (8M+2S per point) -- the dominant kernel;
+//                             XYZZ accumulator held in VGPRs (8M+2S per point) -- the dominant kernel; the
+//                             identity-base check (source.rs:50-52) is fused in;
 //      msm_accumulate_heavy / msm_heavy_combine   segment-parallel path for buckets far longer than the mean.
 //   5. msm_reduce_level_kernel  sum_k k*B_k per window by chunked running sums (levels), then
 //      msm_tree_kernel          pairwise trees: plain sums of the levels' A[] and the bit decomposition of the rest.
