@@ -83,6 +83,36 @@ def test_error_index_and_order(zk, worker):
     assert rc == 2
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_identity_error_index_under_a_density_map(zk, worker, group):
+    """The kernels find an identity base by its BASE index; the error must name the EXPONENT that owns it: the
+    (base - offset)-th selected one (source.rs:101-118).  Two identities: the lower exponent wins; an identity whose
+    exponent is zero or not selected is never looked at."""
+    G = O.G1 if group == 1 else O.G2
+    n = 200
+    rng = np.random.default_rng(77)
+    bits = rng.random(n) < 0.5
+    sel = np.nonzero(bits)[0]
+    bases = inputs.bases_progression_cpu(group, len(sel) + 3, seed=41)
+    scalars = inputs.random_scalars(n, seed=42)
+    dm = zk.DensityTracker.from_bools(bits)
+    got = zk.multiexp(worker, (bases, 3), dm, scalars).wait()
+    rc, want = G.multiexp(bases, scalars, density=GU.density_words(bits), density_bits=n, base_offset=3)
+    assert rc == 0 and np.array_equal(G.to_affine(got), G.to_affine(want))
+    bad = bases.copy()
+    bad[3 + 70] = 0   # owned by exponent sel[70]
+    bad[3 + 41] = 0   # owned by exponent sel[41]: reported
+    bad[3 + 10] = 0   # owned by exponent sel[10], whose scalar is zero: skipped (multiexp.rs:95-96)
+    bad[1] = 0        # below the source offset: never read
+    sc = scalars.copy()
+    sc[sel[10]] = 0
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (bad, 3), dm, sc).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == int(sel[41])
+    rc_o, _ = G.multiexp(bad, sc, density=GU.density_words(bits), density_bits=n, base_offset=3)
+    assert rc_o == 1
+
+
 def test_empty_input_is_identity(zk, worker):
     got = zk.multiexp(worker, (np.zeros((0, 8), np.uint64), 0), zk.FullDensity(), np.zeros((0, 4), np.uint64)).wait()
     assert not got[8:12].any()  # Z == 0
