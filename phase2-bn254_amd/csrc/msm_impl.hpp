@@ -63,7 +63,7 @@ struct MsmGeom {
   // count is not tied to whole bits -- 254 bits in 12 windows need 21.2 bits each: B = 5 * 2^19 takes 12 windows of
   // 1.31 M buckets where c = 20 takes 13 (one accumulation pass and one sort-pass share less) and c = 22 would pay
   // 2.1 M buckets per window in the reduction.  k = sum_w d_w B^w, d_w in (-B/2, B/2], top digit unsigned <= nb = B/2.
-  uint32_t rmul;     // 1 (power-of-two layout), 3 or 5
+  uint32_t rmul;     // 1 (power-of-two layout) or an odd multiplier 3..15
   uint32_t rshift;
 };
 
@@ -99,6 +99,19 @@ __device__ __forceinline__ T load_vec(const T* p) {
 // 1. digits.  density == nullptr: FullDensity (source.rs:80-99): base of exponent i is base_offset+i.
 //    Otherwise bit i of `density` selects exponent i and the bases are compacted (source.rs:101-118):
 //    rank(i) = dprefix[i/32] + popc(density[i/32] & ((1<<i%32)-1)).
+// q = q div M, returns q mod M   (256-bit q on 8 words, M a small constant)
+template <uint32_t M>
+__device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8]) {
+  uint32_t rem = 0;
+#pragma unroll
+  for (int l = 7; l >= 0; --l) {
+    const uint64_t cur = ((uint64_t)rem << 32) | q[l];
+    q[l] = (uint32_t)(cur / M);
+    rem = (uint32_t)(cur % M);
+  }
+  return rem;
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t base_offset,
                                                         const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
@@ -137,20 +150,14 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 #pragma unroll
         for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
         uint32_t rem = 0;
-        if (G.rmul == 3) {
-#pragma unroll
-          for (int l = 7; l >= 0; --l) {
-            const uint64_t cur = ((uint64_t)rem << 32) | q[l];
-            q[l] = (uint32_t)(cur / 3u);
-            rem = (uint32_t)(cur % 3u);
-          }
-        } else {
-#pragma unroll
-          for (int l = 7; l >= 0; --l) {
-            const uint64_t cur = ((uint64_t)rem << 32) | q[l];
-            q[l] = (uint32_t)(cur / 5u);
-            rem = (uint32_t)(cur % 5u);
-          }
+        switch (G.rmul) {  // division by a compile-time constant (multiply-high), not by a runtime value
+          case 3: rem = msm_divmod_small<3>(q); break;
+          case 5: rem = msm_divmod_small<5>(q); break;
+          case 7: rem = msm_divmod_small<7>(q); break;
+          case 9: rem = msm_divmod_small<9>(q); break;
+          case 11: rem = msm_divmod_small<11>(q); break;
+          case 13: rem = msm_divmod_small<13>(q); break;
+          default: rem = msm_divmod_small<15>(q); break;
         }
         d = low + (rem << sh) + carry;
         carry = 0;
@@ -635,11 +642,11 @@ double geom_cost(double W, double nbk, double field_bits, uint64_t n) {
 
 MsmGeom choose_geom(uint64_t n, int group) {
   static const char* env = std::getenv("MI355ZK_MSM_C");
-  static const char* env_radix = std::getenv("MI355ZK_MSM_RADIX");  // "0": power-of-two layouts only; "m,s": force B = m * 2^s (m = 3 or 5)
+  static const char* env_radix = std::getenv("MI355ZK_MSM_RADIX");  // "0": power-of-two layouts only; "m,s": force B = m * 2^s (m odd, 3..15)
   (void)group;
   if (env_radix) {
     int rm = 0, rs = 0;
-    if (std::sscanf(env_radix, "%d,%d", &rm, &rs) == 2 && (rm == 3 || rm == 5) && rs >= 2 && rs <= 22) return make_geom_radix((uint32_t)rm, (uint32_t)rs);
+    if (std::sscanf(env_radix, "%d,%d", &rm, &rs) == 2 && rm >= 3 && rm <= 15 && (rm & 1) && rs >= 2 && rs <= 22) return make_geom_radix((uint32_t)rm, (uint32_t)rs);
   }
   if (env) {
     int v = std::atoi(env);
@@ -655,8 +662,8 @@ MsmGeom choose_geom(uint64_t n, int group) {
   MsmGeom G = make_geom(best_c);
   if (env_radix && env_radix[0] == '0') return G;
   // a mixed-radix layout must win by 1.5 % to be taken (its host join is slightly longer)
-  for (uint32_t rmul = 3; rmul <= 5; rmul += 2)
-    for (uint32_t rshift = 6; rshift <= 22; ++rshift) {
+  for (uint32_t rmul = 3; rmul <= 15; rmul += 2)
+    for (uint32_t rshift = 4; rshift <= 22; ++rshift) {
       MsmGeom R = make_geom_radix(rmul, rshift);
       if (R.W > 64 || R.c > 24) continue;
       double cost = geom_cost(R.W, R.nb, R.c, n);
@@ -907,9 +914,13 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
           const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
           if (!pt.is_zero()) jac_add(by_exp[e_k[k]], xyzz_to_jacobian(pt));
         }
-        const Jacobian<F> one_acc = acc;            // rmul * acc = (rmul - 1) * acc + acc, rmul - 1 in {2, 4}
-        for (uint32_t r = G.rmul - 1; r > 1; r >>= 1) jac_double(acc);
-        jac_add(acc, one_acc);
+        const Jacobian<F> one_acc = acc;            // rmul * acc by double-and-add over the bits of rmul (<= 15)
+        int top = 3;
+        while (!((G.rmul >> top) & 1u)) --top;
+        for (int bit = top - 1; bit >= 0; --bit) {
+          jac_double(acc);
+          if ((G.rmul >> bit) & 1u) jac_add(acc, one_acc);
+        }
         for (uint32_t r = 0; r < G.rshift; ++r) jac_double(acc);
         jac_add(acc, horner(by_exp));
       }
