@@ -9,6 +9,7 @@
 #include <random>
 
 #include "../../phase2-bn254_amd/host/bellman.hpp"
+#include "../../phase2-bn254_amd/host/ceremony.hpp"
 
 extern "C" {
 void oracle_g1_mul_many_affine(uint64_t* out_affine, const uint64_t base_affine[8], const uint64_t* ks, size_t n);
@@ -16,6 +17,10 @@ void oracle_g1_naive_multiexp(const uint64_t* bases, const uint64_t* scalars, si
 void oracle_g1_to_affine(uint64_t r[8], const uint64_t p[12]);
 int oracle_fr_domain_op(uint64_t* a, uint32_t log_n, int op, uint32_t log_cpus);
 void oracle_fe_from_canonical(int which, uint64_t r[4], const uint64_t a[4]);
+void oracle_g1_mul(uint64_t p[12], const uint64_t k[4]);
+void oracle_g1_from_affine(uint64_t r[12], const uint64_t p[8]);
+void oracle_g1_add(uint64_t p[12], const uint64_t o[12]);
+void oracle_g1_encode(uint8_t* out, const uint64_t* affine, size_t n, int compressed);
 }
 
 using namespace bellman;
@@ -93,5 +98,64 @@ int main() {
     CHECK(d.exp() == 3 && d.as_ref().size() == 8 && d.as_ref()[7] == (Fr{0, 0, 0, 0}));
   }
   std::puts("ok evaluation_domain");
+
+  {  // ceremony.hpp: the reference's test_power_pairs (powersoftau/src/utils.rs:90-109) with the known x instead of the pairing
+    const size_t n = 100;
+    FrRepr x = rand_scalar(gen);
+    std::vector<FrRepr> ones(n, FrRepr{1, 0, 0, 0});
+    std::vector<G1Affine> gens(n);
+    for (auto& p : gens) std::memcpy(&p, g1, 64);
+    // v[i] = x^i * G by repeated batch_exp with the shared scalar x:  v[0] = G, v[i+1] = x * v[i]
+    std::vector<G1Affine> v(1), cur(1);
+    std::memcpy(&v[0], g1, 64);
+    cur = v;
+    for (size_t i = 1; i < n; ++i) { cur = ceremony::batch_exp(cur, x); v.push_back(cur[0]); }
+    std::vector<FrRepr> rho(n - 1);
+    for (auto& r : rho) r = rand_scalar(gen);
+    auto [s, sx] = ceremony::power_pairs(v, rho);
+    uint64_t xs[12], a[8], b[8];
+    std::memcpy(xs, &s, 96);
+    oracle_g1_mul(xs, x.data());
+    oracle_g1_to_affine(a, xs);
+    oracle_g1_to_affine(b, reinterpret_cast<const uint64_t*>(&sx));
+    CHECK(std::memcmp(a, b, 64) == 0);                       // same_ratio(power_pairs(v), (g2, g2^x))
+    // batch_exp with per-point exponents against the oracle
+    std::vector<FrRepr> es(8);
+    for (auto& e : es) e = rand_scalar(gen);
+    std::vector<G1Affine> first8(v.begin(), v.begin() + 8);
+    auto scaled = ceremony::batch_exp(first8, es);
+    for (size_t i = 0; i < 8; ++i) {
+      uint64_t j[12], want[8];
+      oracle_g1_from_affine(j, reinterpret_cast<const uint64_t*>(&first8[i]));
+      oracle_g1_mul(j, es[i].data());
+      oracle_g1_to_affine(want, j);
+      CHECK(std::memcmp(&scaled[i], want, 64) == 0);
+    }
+    // eval_qap on a 2-row CSR: row 0 = es[0]*v[1] + es[1]*v[3], row 1 empty
+    auto rows = ceremony::eval_qap<G1Affine>(v, {0, 2, 2}, {1, 3}, {es[0], es[1]});
+    uint64_t t0[12], t1[12], want[8];
+    oracle_g1_from_affine(t0, reinterpret_cast<const uint64_t*>(&v[1])); oracle_g1_mul(t0, es[0].data());
+    oracle_g1_from_affine(t1, reinterpret_cast<const uint64_t*>(&v[3])); oracle_g1_mul(t1, es[1].data());
+    oracle_g1_add(t0, t1);
+    oracle_g1_to_affine(want, t0);
+    CHECK(std::memcmp(&rows[0], want, 64) == 0 && rows[1].is_zero());
+    // codecs: bytes equal the oracle's, round trip, and the reference's error for a corrupted record
+    auto enc = ceremony::encode_points(first8, true);
+    std::vector<uint8_t> want_enc(8 * 32);
+    oracle_g1_encode(want_enc.data(), reinterpret_cast<const uint64_t*>(first8.data()), 8, 1);
+    CHECK(enc == want_enc);
+    auto back = ceremony::decode_points<G1Affine>(enc, true);
+    CHECK(std::memcmp(back.data(), first8.data(), 8 * 64) == 0);
+    enc[5 * 32] = 0x7f;
+    try { ceremony::decode_points<G1Affine>(enc, true); CHECK(false); }
+    catch (const ceremony::GroupDecodingError& e) { CHECK(e.kind == ceremony::GroupDecodingError::UnexpectedInformation && e.index == 5); }
+    // point fft round trip
+    std::vector<G1Affine> pts(v.begin(), v.begin() + 16), orig = pts;
+    ceremony::point_ifft(pts);
+    CHECK(std::memcmp(pts.data(), orig.data(), 16 * 64) != 0);
+    ceremony::point_fft(pts, false);
+    CHECK(std::memcmp(pts.data(), orig.data(), 16 * 64) == 0);
+  }
+  std::puts("ok ceremony_mirror");
   return 0;
 }
