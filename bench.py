@@ -40,9 +40,9 @@ R_TOP = 0x30644E72E131A029  # most-significant u64 limb of r
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SCALAR_MUL = 96  # 64 B affine base + 32 B scalar, each read once
 MADS_PER_MIXED_ADD = 1467  # curveu.hpp xyzzu_add_mixed: 7 u_mul (162) + 2 u_sqr (126) + 1 u_mul2 (243) v_mad_u64_u32
-# integer-multiplier peak: one wave64 v_mad_u64_u32 per 4 cycles per SIMD (tools/ubench_valu.hip) = 16 lane-mads / cycle / SIMD,
-# 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
-MAD_PEAK_PER_S = 16 * 4 * 256 * 2.4e9
+# integer-multiplier peak, MEASURED (tools/ubench_valu.hip, 4 waves/SIMD, independent chains): 28.3 T lane v_mad_u64_u32 / s on
+# one MI355X (5.55 cycles per wave64 instruction per SIMD at the nominal 2.4 GHz; the 16-lane quarter-rate ideal would be 39.3 T)
+MAD_PEAK_PER_S = 28.3e12
 
 
 def gen_scalars(n: int, seed: int, device) -> torch.Tensor:
@@ -226,7 +226,7 @@ def main() -> int:
                                        "mad_peak_per_s": MAD_PEAK_PER_S,
                                        "frac": round(nw.value * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3) / MAD_PEAK_PER_S, 4) if acc_ms else None,
                                        "note": "W mixed adds (10 Fq products = 1467 v_mad_u64_u32) per scalar-mul in msm_accumulate; "
-                                               "MSM is integer-ALU bound (SURVEY 8d), the multiplier instructions alone are this fraction of peak issue"}},
+                                               "MSM is integer-ALU bound (SURVEY 8d), the multiplier instructions alone are this fraction of the measured v_mad_u64_u32 peak"}},
             "result_affine_x_limb0": hex(int(aff[0])),
             "full_size_linearity_check": additive_ok,
             "input_gen_s": round(t_gen, 2),

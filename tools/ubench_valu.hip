@@ -26,6 +26,10 @@ struct OpDot4 { using T = uint32_t; static __device__ void op(T& x, uint32_t a, 
 struct OpDot2 { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b)); } };
 struct OpMadU16 { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b)); } };
 struct OpPkMadU16 { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b)); } };
+struct OpLshr64 { using T = uint64_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(x)); } };
+struct OpAlignbit { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(x) : "v"(a)); } };
+struct OpAnd { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(a)); } };
+struct OpLshr32 { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(x)); } };
 struct OpCndmask { using T = uint32_t; static __device__ void op(T& x, uint32_t a, uint32_t b) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : "vcc"); } };
 
 template <class Op>
@@ -76,7 +80,7 @@ int main() {
   uint32_t* d_out; CK(hipMalloc(&d_out, 4096));
   run<OpMad64>("v_mad_u64_u32", d_out); run<OpMulLo>("v_mul_lo_u32", d_out); run<OpMulHi>("v_mul_hi_u32", d_out);
   run<OpAdd>("v_add_u32", d_out); run<OpAddCo>("v_add_co_u32", d_out); run<OpAddcCo>("v_addc_co_u32", d_out);
-  run<OpLshlAdd64>("v_lshl_add_u64", d_out); run<OpMad24>("v_mad_u32_u24", d_out); run<OpMulHi24>("v_mul_hi_u32_u24", d_out);
+  run<OpLshlAdd64>("v_lshl_add_u64", d_out); run<OpLshr64>("v_lshrrev_b64", d_out); run<OpAlignbit>("v_alignbit_b32", d_out); run<OpAnd>("v_and_b32", d_out); run<OpLshr32>("v_lshrrev_b32", d_out); run<OpMad24>("v_mad_u32_u24", d_out); run<OpMulHi24>("v_mul_hi_u32_u24", d_out);
   run<OpFma64>("v_fma_f64", d_out); run<OpFma32>("v_fma_f32", d_out); run<OpDot4>("v_dot4_u32_u8", d_out);
   run<OpDot2>("v_dot2_u32_u16", d_out); run<OpMadU16>("v_mad_u32_u16", d_out); run<OpPkMadU16>("v_pk_mad_u16", d_out);
   run<OpCndmask>("v_cndmask_b32", d_out);
