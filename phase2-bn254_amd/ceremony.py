@@ -147,3 +147,90 @@ def decode_points(data, group: int, compressed: bool, checked: bool = True):
         raise GroupDecodingError(rc, idx.value)
     _check(rc, "decode_points")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# File containers around the codecs: byte layouts only -- the payload goes through the codec kernels.
+#   accumulator / challenge / response body   powersoftau/src/batched_accumulator.rs:88-170 (calculate_mmap_position),
+#                                             powersoftau/src/parameters.rs:74-105: 64-byte hash, then TauG1[2^(p+1) - 1],
+#                                             TauG2[2^p], AlphaG1[2^p], BetaG1[2^p], BetaG2[1]; every element compressed or not
+#   phase1radix2m{p}                          written by powersoftau/src/bin/prepare_phase2.rs:160-240, read by
+#                                             phase2/src/parameters.rs:147-217: alpha_g1, beta_g1, beta_g2, coeffs_g1[m],
+#                                             coeffs_g2[m], alpha_coeffs_g1[m], beta_coeffs_g1[m], h[m - 1], all uncompressed
+class DeserializationError(Exception):
+    """powersoftau/src/utils.rs DeserializationError::PointAtInfinity / parameters.rs:164 "point at infinity"."""
+
+
+HASH_SIZE = 64  # parameters.rs:74
+
+_ACC_FIELDS = (("tau_g1", 1, lambda p: (2 << p) - 1), ("tau_g2", 2, lambda p: 1 << p), ("alpha_g1", 1, lambda p: 1 << p),
+               ("beta_g1", 1, lambda p: 1 << p), ("beta_g2", 2, lambda p: 1))
+
+
+def accumulator_layout(power: int, compressed: bool):
+    """[(name, group, count, byte offset)], total bytes (without a response's trailing public key)."""
+    off, out = HASH_SIZE, []
+    for name, g, cnt in _ACC_FIELDS:
+        out.append((name, g, cnt(power), off))
+        off += cnt(power) * _ENC_SIZE[(g, bool(compressed))]
+    return out, off
+
+
+def _no_infinity(points, what: str):
+    if bool((points == 0).all(dim=1).any().item()):
+        raise DeserializationError(f"PointAtInfinity in {what}")
+    return points
+
+
+def read_accumulator(data, power: int, compressed: bool, checked: bool = True):
+    """data: 1-D uint8 device tensor holding the file.  Returns {"hash": 64 bytes, "tau_g1": (2^(p+1)-1, 8), ...} of raw affine
+    device records; GroupDecodingError for an undecodable element, DeserializationError for the point at infinity
+    (batched_accumulator.rs read_points_chunk)."""
+    layout, total = accumulator_layout(power, compressed)
+    if data.numel() < total:
+        raise ValueError(f"accumulator of power {power} needs {total} bytes")
+    out = {"hash": data[:HASH_SIZE].clone()}
+    for name, g, cnt, off in layout:
+        sz = _ENC_SIZE[(g, bool(compressed))]
+        out[name] = _no_infinity(decode_points(data[off:off + cnt * sz].view(cnt, sz), g, compressed, checked), name)
+    return out
+
+
+def write_accumulator(acc, compressed: bool):
+    """The inverse of read_accumulator: one uint8 device tensor (hash, then the five vectors)."""
+    import torch
+
+    power = acc["tau_g2"].shape[0].bit_length() - 1
+    layout, total = accumulator_layout(power, compressed)
+    data = torch.zeros(total, dtype=torch.uint8, device=acc["tau_g1"].device)
+    data[:HASH_SIZE] = acc["hash"]
+    for name, g, cnt, off in layout:
+        if acc[name].shape[0] != cnt:
+            raise ValueError(f"{name}: {acc[name].shape[0]} elements, layout wants {cnt}")
+        enc = encode_points(acc[name], compressed)
+        data[off:off + enc.numel()] = enc.reshape(-1)
+    return data
+
+
+_RADIX_FIELDS = (("alpha_g1", 1, lambda m: 1), ("beta_g1", 1, lambda m: 1), ("beta_g2", 2, lambda m: 1), ("coeffs_g1", 1, lambda m: m),
+                 ("coeffs_g2", 2, lambda m: m), ("alpha_coeffs_g1", 1, lambda m: m), ("beta_coeffs_g1", 1, lambda m: m),
+                 ("h", 1, lambda m: m - 1))
+
+
+def read_phase1radix2m(data, m: int):
+    """data: 1-D uint8 device tensor of a phase1radix2m{log2 m} file -> dict of raw affine device records (parameters.rs:147-217:
+    into_affine_unchecked + the point-at-infinity test)."""
+    off, out = 0, {}
+    for name, g, cnt in _RADIX_FIELDS:
+        n, sz = cnt(m), _ENC_SIZE[(g, False)]
+        if data.numel() < off + n * sz:
+            raise ValueError("phase1radix2m file too short")
+        out[name] = _no_infinity(decode_points(data[off:off + n * sz].view(n, sz), g, False, checked=False), name)
+        off += n * sz
+    return out
+
+
+def write_phase1radix2m(params):
+    import torch
+
+    return torch.cat([encode_points(params[name], False).reshape(-1) for name, _, _ in _RADIX_FIELDS])

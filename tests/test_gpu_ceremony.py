@@ -79,3 +79,54 @@ def test_codec_roundtrip_and_error(zk, worker):
     assert e.value.kind == "UnexpectedInformation" and e.value.index == 20
     lag = zk.ceremony.point_ifft(_dev(inputs.bases_progression_cpu(1, 8, seed=831)))
     assert np.array_equal(_host(zk.ceremony.point_fft(lag)), inputs.bases_progression_cpu(1, 8, seed=831))
+
+
+def test_accumulator_and_phase1radix_containers(zk, worker):
+    """File layouts around the codecs (batched_accumulator.rs:88-170, parameters.rs:74-105 / 147-217): a power-3 accumulator
+    and an m = 8 phase1radix2m file are laid out on the CPU with the oracle's encoder, parsed on the device, compared
+    element for element, written back byte for byte; a corrupted element and a point at infinity raise what the reference raises."""
+    import torch
+
+    power, m = 3, 8
+    g1 = inputs.bases_progression_cpu(1, 64, seed=850)
+    g2 = inputs.bases_progression_cpu(2, 32, seed=851)
+    for compressed in (False, True):
+        layout, total = zk.ceremony.accumulator_layout(power, compressed)
+        assert [c for _, _, c, _ in layout] == [15, 8, 8, 8, 1]
+        g1_sz, g2_sz = (32, 64) if compressed else (64, 128)
+        assert total == 64 + 15 * g1_sz + 8 * g2_sz + 8 * g1_sz + 8 * g1_sz + g2_sz  # parameters.rs:83-89 / 99-105
+        blob = np.zeros(total, np.uint8)
+        blob[:64] = np.arange(64, dtype=np.uint8)
+        want, i1, i2 = {}, 0, 0
+        for name, g, cnt, off in layout:
+            src = g1 if g == 1 else g2
+            start = i1 if g == 1 else i2
+            want[name] = src[start:start + cnt]
+            if g == 1: i1 += cnt
+            else: i2 += cnt
+            enc = O.encode_points(g, want[name], compressed)
+            blob[off:off + enc.size] = enc.reshape(-1)
+        acc = zk.ceremony.read_accumulator(torch.from_numpy(blob).cuda(), power, compressed)
+        assert bytes(acc["hash"].cpu().numpy()) == bytes(range(64))
+        for name in want:
+            assert np.array_equal(_host(acc[name]), want[name]), name
+        assert np.array_equal(zk.ceremony.write_accumulator(acc, compressed).cpu().numpy(), blob)
+        bad = blob.copy()
+        off_alpha = [o for nme, _, _, o in layout if nme == "alpha_g1"][0]
+        bad[off_alpha + 2 * g1_sz] = 0x7F
+        with pytest.raises(zk.ceremony.GroupDecodingError) as e:
+            zk.ceremony.read_accumulator(torch.from_numpy(bad).cuda(), power, compressed)
+        assert e.value.index == 2
+        bad = blob.copy()
+        off_tau2 = [o for nme, _, _, o in layout if nme == "tau_g2"][0]
+        bad[off_tau2:off_tau2 + g2_sz] = 0
+        bad[off_tau2] = 0x40
+        with pytest.raises(zk.ceremony.DeserializationError):
+            zk.ceremony.read_accumulator(torch.from_numpy(bad).cuda(), power, compressed)
+    params = {"alpha_g1": g1[:1], "beta_g1": g1[1:2], "beta_g2": g2[:1], "coeffs_g1": g1[2:10], "coeffs_g2": g2[1:9],
+              "alpha_coeffs_g1": g1[10:18], "beta_coeffs_g1": g1[18:26], "h": g1[26:33]}
+    blob = np.concatenate([O.encode_points(1 if v.shape[1] == 8 else 2, v, False).reshape(-1) for v in params.values()])
+    got = zk.ceremony.read_phase1radix2m(torch.from_numpy(blob).cuda(), m)
+    for name, v in params.items():
+        assert np.array_equal(_host(got[name]), v), name
+    assert np.array_equal(zk.ceremony.write_phase1radix2m(got).cpu().numpy(), blob)
