@@ -234,3 +234,28 @@ def write_phase1radix2m(params):
     import torch
 
     return torch.cat([encode_points(params[name], False).reshape(-1) for name, _, _ in _RADIX_FIELDS])
+
+
+def prepare_phase2(acc, m: int):
+    """The device work of powersoftau/src/bin/prepare_phase2.rs:60-160 for one degree m = 2^k: Lagrange-basis conversion of the
+    tau powers (four point iffts) and the H bases  h[i] = tau_g1[i + m] - tau_g1[i]  (:137-147), all normalised to affine; returns
+    the dict write_phase1radix2m serialises.  `acc` is what read_accumulator returns."""
+    import torch
+
+    if m < 1 or m & (m - 1) or 2 * m - 1 > acc["tau_g1"].shape[0]:
+        raise ValueError("m must be a power of two within the accumulator's powers")
+    dev = acc["tau_g1"].device
+    out = {"alpha_g1": acc["alpha_g1"][:1].clone(), "beta_g1": acc["beta_g1"][:1].clone(), "beta_g2": acc["beta_g2"][:1].clone()}
+    for name, src in (("coeffs_g1", "tau_g1"), ("coeffs_g2", "tau_g2"), ("alpha_coeffs_g1", "alpha_g1"), ("beta_coeffs_g1", "beta_g1")):
+        out[name] = point_ifft(acc[src][:m].clone())
+    # h[i] = 1 * tau_g1[i + m] + (r - 1) * tau_g1[i]: a two-term row of the sparse matrix x point vector product
+    n_h = m - 1
+    r_minus_1 = [0x43E1F593F0000000, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029]
+    one = [1, 0, 0, 0]
+    to_i64 = lambda limbs: [v - (1 << 64) if v >= (1 << 63) else v for v in limbs]  # noqa: E731
+    coeff = torch.tensor([to_i64(one), to_i64(r_minus_1)], dtype=torch.int64, device=dev).repeat(max(n_h, 1), 1)[:2 * n_h]
+    idx = torch.arange(n_h, device=dev, dtype=torch.int32)
+    col = torch.stack([idx + m, idx], dim=1).reshape(-1).contiguous()
+    row_ptr = (2 * torch.arange(n_h + 1, device=dev, dtype=torch.int32)).contiguous()
+    out["h"] = eval_qap(acc["tau_g1"][:2 * m - 1].contiguous(), row_ptr, col, coeff.contiguous()) if n_h else acc["tau_g1"][:0].clone()
+    return out

@@ -130,3 +130,34 @@ def test_accumulator_and_phase1radix_containers(zk, worker):
     for name, v in params.items():
         assert np.array_equal(_host(got[name]), v), name
     assert np.array_equal(zk.ceremony.write_phase1radix2m(got).cpu().numpy(), blob)
+
+
+def test_prepare_phase2_flow_closed_form(zk, worker):
+    """prepare_phase2.rs:60-160 assembled from the pieces (containers -> point iffts -> H bases -> phase1radix2m file) on a
+    power-3 accumulator with KNOWN tau, alpha, beta.  Closed forms: coeffs_g1[j] = L_j(tau) G, alpha_coeffs_g1[j] = alpha L_j(tau) G,
+    coeffs_g2[j] = L_j(tau) G2, h[i] = (tau^m - 1) tau^i G;  L_j(tau) = (tau^m - 1) w^j / (m (tau - w^j))."""
+    import torch
+
+    power = 3
+    m = 1 << power
+    r = M.R_ORDER
+    tau, alpha, beta = 0x1234567 % r, 0x89ABCDEF01 % r, 0x55AA55AA55 % r
+    mul1 = lambda ks: O.G1.mul_many_affine(inputs.G1_GEN_RAW, np.stack([_limbs(k) for k in ks]))  # noqa: E731
+    mul2 = lambda ks: O.G2.mul_many_affine(inputs.G2_GEN_RAW, np.stack([_limbs(k) for k in ks]))  # noqa: E731
+    tp = [pow(tau, i, r) for i in range(2 * m - 1)]
+    acc = {"hash": torch.zeros(64, dtype=torch.uint8).cuda(), "tau_g1": _dev(mul1(tp)), "tau_g2": _dev(mul2(tp[:m])),
+           "alpha_g1": _dev(mul1([alpha * t for t in tp[:m]])), "beta_g1": _dev(mul1([beta * t for t in tp[:m]])), "beta_g2": _dev(mul2([beta]))}
+    blob = zk.ceremony.write_accumulator(acc, compressed=True)           # a (compressed) response body ...
+    acc2 = zk.ceremony.read_accumulator(blob, power, compressed=True)    # ... read back the way prepare_phase2 does
+    params = zk.ceremony.prepare_phase2(acc2, m)
+    w = M.domain_omega(power)
+    lag = [(pow(tau, m, r) - 1) * pow(w, j, r) % r * pow(m * (tau - pow(w, j, r)) % r, -1, r) % r for j in range(m)]
+    assert np.array_equal(_host(params["coeffs_g1"]), mul1(lag))
+    assert np.array_equal(_host(params["coeffs_g2"]), mul2(lag))
+    assert np.array_equal(_host(params["alpha_coeffs_g1"]), mul1([alpha * l for l in lag]))
+    assert np.array_equal(_host(params["beta_coeffs_g1"]), mul1([beta * l for l in lag]))
+    assert np.array_equal(_host(params["h"]), mul1([(pow(tau, m, r) - 1) * tp[i] for i in range(m - 1)]))
+    radix = zk.ceremony.write_phase1radix2m(params)
+    assert radix.numel() == 2 * 64 + 128 + m * 64 + m * 128 + 2 * m * 64 + (m - 1) * 64    # parameters.rs:183-217 reads exactly this
+    back = zk.ceremony.read_phase1radix2m(radix, m)
+    assert all(torch.equal(back[k], params[k]) for k in params)
