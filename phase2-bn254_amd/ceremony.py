@@ -259,3 +259,52 @@ def prepare_phase2(acc, m: int):
     row_ptr = (2 * torch.arange(n_h + 1, device=dev, dtype=torch.int32)).contiguous()
     out["h"] = eval_qap(acc["tau_g1"][:2 * m - 1].contiguous(), row_ptr, col, coeff.contiguous()) if n_h else acc["tau_g1"][:0].clone()
     return out
+
+
+_R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # fr.rs:4
+_G1_ONE_RAW = None
+
+
+def _limbs_i64(x: int):
+    out = []
+    for i in range(4):
+        v = (x >> (64 * i)) & ((1 << 64) - 1)
+        out.append(v - (1 << 64) if v >= (1 << 63) else v)
+    return out
+
+
+def scalar_powers(base: int, n: int, device, coeff: int = 1):
+    """(n, 4) canonical FrRepr rows  coeff * base^i mod r,  i < n, built on the device by repeated doubling with the pointwise
+    Montgomery product (what batched_accumulator.rs:1230-1260 computes per chunk with `pow` and a running product)."""
+    import torch
+
+    L = _lib.load()
+    mont = lambda v: (v % _R_ORDER) * (1 << 256) % _R_ORDER  # noqa: E731
+    pw = torch.empty((n, 4), dtype=torch.int64, device=device)
+    pw[0] = torch.tensor(_limbs_i64(mont(coeff)), dtype=torch.int64, device=device)
+    have = 1
+    while have < n:
+        take = min(have, n - have)
+        step = torch.tensor(_limbs_i64(mont(pow(base, have, _R_ORDER))), dtype=torch.int64, device=device).repeat(take, 1)
+        blk = pw[:take].clone()
+        _check(L.mi355zk_bn254_fr_mul_assign_dev(_p(blk), _p(step), take, _stream_ptr()), "fr_mul_assign")
+        pw[have:have + take] = blk
+        have += take
+    one = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=device).repeat(n, 1)
+    _check(L.mi355zk_bn254_fr_mul_assign_dev(_p(pw), _p(one), n, _stream_ptr()), "fr_mul_assign")  # x R * 1 / R = x: canonical
+    return pw
+
+
+def contribute_accumulator(acc, tau: int, alpha: int, beta: int):
+    """The device work of powersoftau `compute_constrained` (batched_accumulator.rs:1119-1292: every tau power by tau^i, the alpha /
+    beta vectors by alpha tau^i / beta tau^i, beta_g2 by beta), `batch_exp` + normalisation per vector.  Returns a new dict."""
+    dev = acc["tau_g1"].device
+    n1, n = acc["tau_g1"].shape[0], acc["tau_g2"].shape[0]
+    tp = scalar_powers(tau, n1, dev)
+    out = {"hash": acc["hash"].clone()}
+    out["tau_g1"] = batch_exp(acc["tau_g1"], tp)
+    out["tau_g2"] = batch_exp(acc["tau_g2"], tp[:n].contiguous())
+    out["alpha_g1"] = batch_exp(acc["alpha_g1"], scalar_powers(tau, n, dev, coeff=alpha))
+    out["beta_g1"] = batch_exp(acc["beta_g1"], scalar_powers(tau, n, dev, coeff=beta))
+    out["beta_g2"] = batch_exp(acc["beta_g2"], scalar_powers(tau, 1, dev, coeff=beta))
+    return out

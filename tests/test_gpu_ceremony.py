@@ -161,3 +161,33 @@ def test_prepare_phase2_flow_closed_form(zk, worker):
     assert radix.numel() == 2 * 64 + 128 + m * 64 + m * 128 + 2 * m * 64 + (m - 1) * 64    # parameters.rs:183-217 reads exactly this
     back = zk.ceremony.read_phase1radix2m(radix, m)
     assert all(torch.equal(back[k], params[k]) for k in params)
+
+
+def test_contribute_accumulator_like_compute_constrained(zk, worker):
+    """BASELINE config 1's compute step on the device (batched_accumulator.rs:1119-1292): the blank accumulator of
+    `new_constrained` (every element a generator, :1295-1347) contributed with a known key has tau_g1[i] = tau^i G,
+    alpha_g1[i] = alpha tau^i G, ...; a second contribution multiplies the keys."""
+    import torch
+
+    power = 3
+    n, n1 = 1 << power, (2 << power) - 1
+    r = M.R_ORDER
+    blank = {"hash": torch.zeros(64, dtype=torch.uint8).cuda(), "tau_g1": _dev(np.tile(inputs.G1_GEN_RAW, (n1, 1))),
+             "tau_g2": _dev(np.tile(inputs.G2_GEN_RAW, (n, 1))), "alpha_g1": _dev(np.tile(inputs.G1_GEN_RAW, (n, 1))),
+             "beta_g1": _dev(np.tile(inputs.G1_GEN_RAW, (n, 1))), "beta_g2": _dev(np.tile(inputs.G2_GEN_RAW, (1, 1)))}
+    tau, alpha, beta = 0xABCDEF123456789 % r, 0x1111222233334444 % r, 0x9999AAAABBBB % r
+    pw = zk.ceremony.scalar_powers(tau, 9, torch.device("cuda", 0), coeff=alpha)
+    assert [M.from_limbs([int(v) for v in row]) for row in _host(pw)] == [alpha * pow(tau, i, r) % r for i in range(9)]
+    acc = zk.ceremony.contribute_accumulator(blank, tau, alpha, beta)
+    mul1 = lambda ks: O.G1.mul_many_affine(inputs.G1_GEN_RAW, np.stack([_limbs(k) for k in ks]))  # noqa: E731
+    mul2 = lambda ks: O.G2.mul_many_affine(inputs.G2_GEN_RAW, np.stack([_limbs(k) for k in ks]))  # noqa: E731
+    tp = [pow(tau, i, r) for i in range(n1)]
+    assert np.array_equal(_host(acc["tau_g1"]), mul1(tp))
+    assert np.array_equal(_host(acc["tau_g2"]), mul2(tp[:n]))
+    assert np.array_equal(_host(acc["alpha_g1"]), mul1([alpha * t for t in tp[:n]]))
+    assert np.array_equal(_host(acc["beta_g1"]), mul1([beta * t for t in tp[:n]]))
+    assert np.array_equal(_host(acc["beta_g2"]), mul2([beta]))
+    t2, a2, b2 = 0x31415926535 % r, 0x27182818 % r, 0x16180339 % r
+    acc2 = zk.ceremony.contribute_accumulator(acc, t2, a2, b2)
+    assert np.array_equal(_host(acc2["tau_g1"]), mul1([pow(tau * t2, i, r) for i in range(n1)]))
+    assert np.array_equal(_host(acc2["alpha_g1"]), mul1([alpha * a2 * pow(tau * t2, i, r) for i in range(n)]))
