@@ -11,6 +11,9 @@ reference functions they replace:
   point_fft / point_ifft(points)           EvaluationDomain<Point<G>>::{fft, ifft}, powersoftau/src/bin/prepare_phase2.rs:68-131
   decode_points / encode_points            EncodedPoint::{into_affine[_unchecked], from_affine}, pairing/src/bn256/ec.rs:763-946, 1136-1344
 
+Flows assembled from them:  read_accumulator / write_accumulator, read_phase1radix2m / write_phase1radix2m (file containers),
+prepare_phase2 (prepare_phase2.rs:60-160), contribute_accumulator (compute_constrained), eval_qap_polynomials (MPCParameters::new eval).
+
 Points are raw affine records (n x 8 int64 for G1, n x 16 for G2; all-zero = infinity), scalars canonical FrRepr
 (n x 4 int64).  The group (1 or 2) is taken from the record width.  Work is issued on torch's current stream.
 """
@@ -308,3 +311,39 @@ def contribute_accumulator(acc, tau: int, alpha: int, beta: int):
     out["beta_g1"] = batch_exp(acc["beta_g1"], scalar_powers(tau, n, dev, coeff=beta))
     out["beta_g2"] = batch_exp(acc["beta_g2"], scalar_powers(tau, 1, dev, coeff=beta))
     return out
+
+
+def eval_qap_polynomials(radix, at, bt, ct):
+    """The `eval` of MPCParameters::new (phase2/src/parameters.rs:225-300) as four sparse products over the Lagrange bases of a
+    phase1radix2m file (`radix`: what read_phase1radix2m returns).  at / bt / ct: CSR triples (row_ptr int32 (n_vars + 1),
+    col int32 (nnz) = Lagrange index, coeff (nnz, 4) canonical) -- the QAP polynomials of keypair_assembly.rs:15-25, one row
+    per variable.  Returns affine (a_g1, b_g1, b_g2, ext) with
+        a_g1[v] = sum_at c L_g1[lag],  b_g1[v] = sum_bt c L_g1[lag],  b_g2[v] = sum_bt c L_g2[lag],
+        ext[v]  = sum_at c beta_L_g1[lag] + sum_bt c alpha_L_g1[lag] + sum_ct c L_g1[lag]          (ic / l before the delta split)."""
+    import torch
+
+    a_g1 = eval_qap(radix["coeffs_g1"], *at)
+    b_g1 = eval_qap(radix["coeffs_g1"], *bt)
+    b_g2 = eval_qap(radix["coeffs_g2"], *bt)
+    # ext: one product over the concatenated bases [beta_L | alpha_L | L] and the row-wise concatenated term lists
+    m = radix["coeffs_g1"].shape[0]
+    bases = torch.cat([radix["beta_coeffs_g1"], radix["alpha_coeffs_g1"], radix["coeffs_g1"]])
+    n_vars = at[0].shape[0] - 1
+    lens = [(t[0][1:] - t[0][:-1]).to(torch.int64) for t in (at, bt, ct)]
+    total = lens[0] + lens[1] + lens[2]
+    row_ptr = torch.zeros(n_vars + 1, dtype=torch.int64, device=bases.device)
+    row_ptr[1:] = torch.cumsum(total, 0)
+    nnz = int(row_ptr[-1].item())
+    col = torch.empty(nnz, dtype=torch.int32, device=bases.device)
+    coeff = torch.empty((nnz, 4), dtype=torch.int64, device=bases.device)
+    start = row_ptr[:-1].clone()
+    for k, (t, ln) in enumerate(zip((at, bt, ct), lens)):
+        # destination of term j of row v: start[v] + (j - t.row_ptr[v])
+        rows = torch.repeat_interleave(torch.arange(n_vars, device=bases.device), ln)
+        within = torch.arange(t[1].shape[0], device=bases.device) - t[0][:-1].to(torch.int64)[rows]
+        dst = start[rows] + within
+        col[dst] = t[1] + k * m
+        coeff[dst] = t[2]
+        start = start + ln
+    ext = eval_qap(bases, row_ptr.to(torch.int32), col, coeff)
+    return a_g1, b_g1, b_g2, ext

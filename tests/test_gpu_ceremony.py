@@ -191,3 +191,41 @@ def test_contribute_accumulator_like_compute_constrained(zk, worker):
     acc2 = zk.ceremony.contribute_accumulator(acc, t2, a2, b2)
     assert np.array_equal(_host(acc2["tau_g1"]), mul1([pow(tau * t2, i, r) for i in range(n1)]))
     assert np.array_equal(_host(acc2["alpha_g1"]), mul1([alpha * a2 * pow(tau * t2, i, r) for i in range(n)]))
+
+
+def test_eval_qap_polynomials_like_mpc_parameters_new(zk, worker):
+    """parameters.rs:225-300 on a toy QAP (5 variables over m = 8 Lagrange bases, ragged at / bt / ct incl. empty rows):
+    a_g1, b_g1, b_g2 and ext against the oracle's mul / add, term by term."""
+    import torch
+
+    m, n_vars = 8, 5
+    radix = {"coeffs_g1": inputs.bases_progression_cpu(1, m, seed=870), "coeffs_g2": inputs.bases_progression_cpu(2, m, seed=871),
+             "alpha_coeffs_g1": inputs.bases_progression_cpu(1, m, seed=872), "beta_coeffs_g1": inputs.bases_progression_cpu(1, m, seed=873)}
+    rng = np.random.default_rng(874)
+
+    def poly(lengths, seed):
+        rp = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+        col = rng.integers(0, m, size=int(rp[-1])).astype(np.int32)
+        cf = inputs.random_scalars(int(rp[-1]), seed=seed)
+        cf[::3] = np.array([1, 0, 0, 0], dtype=np.uint64)
+        return rp, col, cf
+
+    at, bt, ct = poly([2, 0, 3, 1, 1], 875), poly([1, 2, 0, 0, 4], 876), poly([0, 1, 1, 2, 0], 877)
+    dev_radix = {k: _dev(v) for k, v in radix.items()}
+    to_dev = lambda t: (_dev(t[0]), _dev(t[1]), _dev(t[2]))  # noqa: E731
+    a_g1, b_g1, b_g2, ext = zk.ceremony.eval_qap_polynomials(dev_radix, to_dev(at), to_dev(bt), to_dev(ct))
+
+    def rowsum(G, bases, t, v, acc=None):
+        acc = G.from_affine(np.zeros(G.aff, np.uint64)) if acc is None else acc
+        for j in range(t[0][v], t[0][v + 1]):
+            acc = G.add(acc, G.mul(G.from_affine(bases[t[1][j]]), t[2][j]))
+        return acc
+
+    for v in range(n_vars):
+        assert np.array_equal(_host(a_g1)[v], O.G1.to_affine(rowsum(O.G1, radix["coeffs_g1"], at, v)))
+        assert np.array_equal(_host(b_g1)[v], O.G1.to_affine(rowsum(O.G1, radix["coeffs_g1"], bt, v)))
+        assert np.array_equal(_host(b_g2)[v], O.G2.to_affine(rowsum(O.G2, radix["coeffs_g2"], bt, v)))
+        e = rowsum(O.G1, radix["beta_coeffs_g1"], at, v)
+        e = rowsum(O.G1, radix["alpha_coeffs_g1"], bt, v, e)
+        e = rowsum(O.G1, radix["coeffs_g1"], ct, v, e)
+        assert np.array_equal(_host(ext)[v], O.G1.to_affine(e))
