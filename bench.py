@@ -98,11 +98,16 @@ def main() -> int:
 
     log_n = args.log_n
     n_total = 1 << log_n
-    assert n_total % world == 0
-    n_local = n_total // world
+    # sharding (shard.plan): a few contiguous point ranges x groups of scalar windows; BENCH_SHARD=points forces point ranges only
+    if os.environ.get("BENCH_SHARD", "") == "points":
+        pgroups, pgroup, wgroups, wgroup = world, rank, 1, 0
+    else:
+        pgroups, pgroup, wgroups, wgroup = zk.shard.rank_groups(world, rank)
+    assert n_total % pgroups == 0
+    n_local = n_total // pgroups
     shard = min(1 << LOG_SHARD, n_local)
     shards_local = n_local // shard
-    first_shard = rank * shards_local
+    first_shard = pgroup * shards_local
 
     # ---- synthetic inputs, generated on the device (no reference files): bases P_i = k_i * G
     scalars = torch.empty((n_local, 4), dtype=torch.int64, device=dev)
@@ -121,7 +126,7 @@ def main() -> int:
     t_gen = time.time() - t_gen
 
     def step() -> np.ndarray:
-        part = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()  # (12,) u64 Jacobian partial
+        part = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars, window_group=(wgroups, wgroup)).wait()  # (12,) u64 Jacobian partial
         if world == 1:
             return part
         # the path's one exchange step: all-gather of the 96-byte partials, then local EC adds
@@ -160,6 +165,8 @@ def main() -> int:
     rc = L.mi355zk_bn254_fr_sub_assign_dev(C.c_void_p(sb.data_ptr()), C.c_void_p(sa.data_ptr()), n_local, None)
     assert rc == 0, rc
     torch.cuda.synchronize()
+    # (over ALL windows of the local points: the partial over a window group is not linear in the exponents, the carries of
+    # the signed digits cross windows)
     whole = result if world == 1 else zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
     part_a = zk.multiexp(worker, (bases, 0), zk.FullDensity(), sa).wait()
     part_b = zk.multiexp(worker, (bases, 0), zk.FullDensity(), sb).wait()
@@ -196,11 +203,12 @@ def main() -> int:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total / (elapsed / args.steps) / 1e6
         acc_ms = kern["msm_accumulate"]
-        achieved = BYTES_PER_SCALAR_MUL * n_local / (acc_ms * 1e-3) / 1e9 if acc_ms else None
         nw = C.c_int()
-        c_bits = L.mi355zk_msm_window_bits(n_local, C.byref(nw))
+        c_bits = L.mi355zk_msm_window_bits_groups(n_local, wgroups, C.byref(nw))
+        nw_rank = nw.value // wgroups  # windows one launch of this rank accumulates: that share of its scalar-muls' work
+        achieved = BYTES_PER_SCALAR_MUL * (n_local / wgroups) / (acc_ms * 1e-3) / 1e9 if acc_ms else None
         # integer-ALU model: W mixed adds per scalar-mul, 10 Fq mul each (XYZZ 8M+2S)
-        fq_mul_per_s = (nw.value * 10 * n_local / (acc_ms * 1e-3)) if acc_ms else None
+        fq_mul_per_s = (nw_rank * 10 * n_local / (acc_ms * 1e-3)) if acc_ms else None
         out = {
             "metric": "BN254 G1 MSM throughput (Mscalar-mul/s) at 2^%d points" % log_n,
             "value": round(value, 3),
@@ -216,15 +224,15 @@ def main() -> int:
             "data": "synthetic (bases k_i*G generated on device, scalars uniform < r)",
             "config": {"workload": "2^%d-point BN254 G1 Pippenger MSM, FullDensity, bases+scalars resident in HBM" % log_n,
                        "points_per_gpu": n_local, "window_bits": c_bits, "windows": nw.value,
-                       "parallelism": "point-range shards x%d, all-gather of 96-B partials" % world},
+                       "parallelism": "%d point range(s) x %d window group(s), all-gather of 96-B partials" % (pgroups, wgroups)},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6) if achieved else None,
                          "traffic": traffic,
                          "kernel_ms": {k: (round(v, 4) if v is not None else None) for k, v in kern.items()},
                          "alu_model": {"fq_mul_per_s": fq_mul_per_s,
-                                       "mad_u64_u32_per_s": (nw.value * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3)) if acc_ms else None,
+                                       "mad_u64_u32_per_s": (nw_rank * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3)) if acc_ms else None,
                                        "mad_peak_per_s": MAD_PEAK_PER_S,
-                                       "frac": round(nw.value * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3) / MAD_PEAK_PER_S, 4) if acc_ms else None,
+                                       "frac": round(nw_rank * MADS_PER_MIXED_ADD * n_local / (acc_ms * 1e-3) / MAD_PEAK_PER_S, 4) if acc_ms else None,
                                        "note": "W mixed adds (10 Fq products = 1467 v_mad_u64_u32) per scalar-mul in msm_accumulate; "
                                                "MSM is integer-ALU bound (SURVEY 8d), the multiplier instructions alone are this fraction of the measured v_mad_u64_u32 peak"}},
             "result_affine_x_limb0": hex(int(aff[0])),

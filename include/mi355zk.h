@@ -102,11 +102,24 @@ int mi355zk_bn254_g1_dense_multiexp_dev(const void *d_bases, const void *d_scala
 int mi355zk_bn254_g2_dense_multiexp_dev(const void *d_bases, const void *d_scalars, size_t n, void *stream, uint64_t out_xyz[24]);
 int mi355zk_bn254_g1_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[12], uint64_t out_sx[12]);
 int mi355zk_bn254_g2_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[24], uint64_t out_sx[24]);
+/* ONE WINDOW GROUP of a multiexp, for multi-GPU runs that shard by scalar windows as well as by point range: the windows of
+ * the geometry chosen for n_scalars (a window count divisible by window_groups) are dealt out in window_groups equal groups
+ * and only group `window_group` is evaluated: out = sum over its windows w of B^w * T_w.  The partials of all groups add up
+ * (mi355zk_bn254_g{1,2}_add) to what mi355zk_bn254_g{1,2}_msm_dev returns; errors and their indices are those of the full
+ * call.  (1, 0) is the full multiexp. */
+int mi355zk_bn254_g1_msm_part_dev(const void *d_bases, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
+                                  const uint32_t *density, size_t density_bits, uint32_t window_groups, uint32_t window_group,
+                                  void *stream, uint64_t out_xyz[12]);
+int mi355zk_bn254_g2_msm_part_dev(const void *d_bases, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
+                                  const uint32_t *density, size_t density_bits, uint32_t window_groups, uint32_t window_group,
+                                  void *stream, uint64_t out_xyz[24]);
 /* exponent index at which the last failing multiexp of this thread raised its error, or -1 */
 long long mi355zk_last_error_index(void);
 /* bits of the bucket field (c for the power-of-two window layouts, ceil(log2(B/2 + 1)) for the mixed-radix ones) and
  * the window count the library would use for n scalars (diagnostics / DESIGN.md section 4) */
 int mi355zk_msm_window_bits(size_t n_scalars, int *n_windows);
+/* the same for a run whose windows are dealt out in window_groups groups (the window count is then a multiple of it) */
+int mi355zk_msm_window_bits_groups(size_t n_scalars, uint32_t window_groups, int *n_windows);
 
 /* ---- Fr NTT.  Replaces bellman/src/domain.rs:263 `best_fft` for T = Scalar<Bn256>:
  * a[0..2^log_n) in place, natural order in and out, `omega` of order 2^log_n (Montgomery form). */

@@ -127,8 +127,9 @@ class _Ready:
         return self._value
 
 
-def multiexp(pool: Worker, bases, density_map, exponents) -> _Ready:
-    """bellman/src/multiexp.rs:330.  `bases` = (array, offset) like `(Arc<Vec<G>>, usize)`:
+def multiexp(pool: Worker, bases, density_map, exponents, window_group=None) -> _Ready:
+    """bellman/src/multiexp.rs:330.  (window_group = (groups, index), device-resident data only: the partial sum over one
+    of `groups` equal groups of scalar windows -- multi-GPU sharding by windows, shard.py; None = the whole multiexp.)  `bases` = (array, offset) like `(Arc<Vec<G>>, usize)`:
     array of shape (n_bases, 8) u64 for G1Affine raw records or (n_bases, 16) for G2Affine;
     `exponents` = (n, 4) u64 canonical FrRepr; `density_map` = FullDensity() or a DensityTracker.
     Returns a ready future whose wait() yields the Jacobian X||Y||Z limbs (12 / 24 u64)."""
@@ -146,12 +147,15 @@ def multiexp(pool: Worker, bases, density_map, exponents) -> _Ready:
         limbs = arr.shape[1]
         group = {8: 1, 16: 2}[limbs]
         out = np.zeros(12 * group, dtype=np.uint64)
-        fn = lib.mi355zk_bn254_g1_msm_dev if group == 1 else lib.mi355zk_bn254_g2_msm_dev
+        wg, wi = window_group if window_group is not None else (1, 0)
+        fn = lib.mi355zk_bn254_g1_msm_part_dev if group == 1 else lib.mi355zk_bn254_g2_msm_part_dev
         with torch.cuda.device(arr.device):
             rc = fn(C.c_void_p(arr.data_ptr()), arr.shape[0], offset, C.c_void_p(exponents.data_ptr()), n_exp,
-                    words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits, _stream_ptr(),
+                    words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits, int(wg), int(wi), _stream_ptr(),
                     out.ctypes.data_as(C.c_void_p))
     else:
+        if window_group is not None and tuple(window_group) != (1, 0):
+            raise ValueError("window groups need device-resident inputs")
         arr = np.ascontiguousarray(arr, dtype=np.uint64)
         exponents = np.ascontiguousarray(exponents, dtype=np.uint64)
         limbs = arr.shape[1] if arr.ndim == 2 else 8

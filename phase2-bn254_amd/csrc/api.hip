@@ -24,9 +24,9 @@ void ntt_release_all();
 int ntt_configure();
 // msm.hip
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
-                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index);
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup);
 int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
-                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index);
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup);
 int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
@@ -40,7 +40,7 @@ int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_p
 int segsum_g2_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
 void msm_release_g1();
 void msm_release_g2();
-void msm_geometry(uint64_t n, uint32_t* c, uint32_t* W);
+void msm_geometry(uint64_t n, uint32_t wgroups, uint32_t* c, uint32_t* W);
 
 // ------------------------------------------------------------------------------------------------
 // profiling hooks
@@ -590,7 +590,7 @@ int plan_density(size_t n_bases, size_t base_offset, size_t n_scalars, const uin
 
 template <int GROUP>
 int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
-                  const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz) {
+                  const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0) {
   t_last_err_index = -1;
   if (!out_xyz || (n_scalars && !d_scalars) || (n_bases && !d_bases)) return ZK_ERR_BAD_ARGS;
   if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
@@ -609,8 +609,8 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
     ZK_HIP(hipMemcpyAsync(d_prefix, P.prefix.data(), words * 4, hipMemcpyHostToDevice, st));
   }
   long long err_index = -1;
-  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index);
-  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index);
+  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup);
+  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup);
   if (d_density) (void)hipFree(d_density);
   if (rc == ZK_ERR_UNEXPECTED_IDENTITY) {
     // the kernels report the lowest BASE index that was the identity under a non-zero exponent; the exponent that owns it
@@ -743,6 +743,19 @@ int mi355zk_bn254_g2_msm_dev(const void* d_bases, size_t n_bases, size_t base_of
                              const uint32_t* density, size_t density_bits, void* stream, uint64_t out_xyz[24]) {
   return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
 }
+// one window group of a multiexp (multi-GPU sharding by windows; shard.py)
+int mi355zk_bn254_g1_msm_part_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                                  const uint32_t* density, size_t density_bits, uint32_t window_groups, uint32_t window_group, void* stream,
+                                  uint64_t out_xyz[12]) {
+  if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
+  return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
+}
+int mi355zk_bn254_g2_msm_part_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                                  const uint32_t* density, size_t density_bits, uint32_t window_groups, uint32_t window_group, void* stream,
+                                  uint64_t out_xyz[24]) {
+  if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
+  return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
+}
 int mi355zk_bn254_g1_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
   if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   return msm_g1_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
@@ -764,7 +777,13 @@ int mi355zk_bn254_g2_merge_pairs_dev(const void* d_v1, const void* d_v2, const v
 long long mi355zk_last_error_index(void) { return t_last_err_index; }
 int mi355zk_msm_window_bits(size_t n_scalars, int* n_windows) {
   uint32_t c = 0, W = 0;
-  msm_geometry(n_scalars, &c, &W);
+  msm_geometry(n_scalars, 1, &c, &W);
+  if (n_windows) *n_windows = (int)W;
+  return (int)c;
+}
+int mi355zk_msm_window_bits_groups(size_t n_scalars, uint32_t window_groups, int* n_windows) {
+  uint32_t c = 0, W = 0;
+  msm_geometry(n_scalars, window_groups, &c, &W);
   if (n_windows) *n_windows = (int)W;
   return (int)c;
 }

@@ -115,7 +115,10 @@ __device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8]) {
 template <class F>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t base_offset,
                                                         const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
-                                                        MsmGeom G, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                        MsmGeom G, uint32_t w_lo, uint32_t w_hi, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+  // only the windows w_lo <= w < w_hi are emitted (slot w - w_lo): a multi-GPU run may give every rank a subset of the
+  // windows of the same geometry; the carry chain of the signed digits still runs from window 0.
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool active = true;
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
   s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
   uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
   if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
-    for (uint32_t w = 0; w < G.W; ++w) keys[(uint64_t)w * n + i] = (w << G.c) | G.nb;
+    for (uint32_t w = w_lo; w < w_hi; ++w) keys[(uint64_t)(w - w_lo) * n + i] = ((w - w_lo) << G.c) | G.nb;
     return;
   }
   // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is loaded
@@ -169,9 +172,11 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       } else {
         d = q[0] + carry;        // top digit, unsigned: <= nb by the choice of B (make_geom_radix)
       }
-      const uint64_t o = (uint64_t)w * n + i;
-      keys[o] = (w << G.c) | (d ? d - 1 : G.nb);
-      vals[o] = (uint32_t)bi | neg;
+      if (w >= w_lo && w < w_hi) {
+        const uint64_t o = (uint64_t)(w - w_lo) * n + i;
+        keys[o] = ((w - w_lo) << G.c) | (d ? d - 1 : G.nb);
+        vals[o] = (uint32_t)bi | neg;
+      }
     }
     return;
   }
@@ -187,9 +192,11 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       neg = (d != 0) ? SIGN_BIT : 0;
       carry = 1;
     }
-    uint64_t o = (uint64_t)w * n + i;
-    keys[o] = (w << G.c) | (d ? d - 1 : G.nb);  // sort field = low c bits: bucket, or nb = "no bucket" (sorts last)
-    vals[o] = (uint32_t)bi | neg;
+    if (w >= w_lo && w < w_hi) {
+      uint64_t o = (uint64_t)(w - w_lo) * n + i;
+      keys[o] = ((w - w_lo) << G.c) | (d ? d - 1 : G.nb);  // sort field = low c bits: bucket, or nb = "no bucket" (sorts last)
+      vals[o] = (uint32_t)bi | neg;
+    }
   }
 }
 
@@ -640,32 +647,35 @@ double geom_cost(double W, double nbk, double field_bits, uint64_t n) {
   return cost;
 }
 
-MsmGeom choose_geom(uint64_t n, int group) {
+MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
   static const char* env = std::getenv("MI355ZK_MSM_C");
   static const char* env_radix = std::getenv("MI355ZK_MSM_RADIX");  // "0": power-of-two layouts only; "m,s": force B = m * 2^s (m odd, 3..15)
   (void)group;
-  if (env_radix) {
+  if (env_radix && wgroups == 1) {
     int rm = 0, rs = 0;
     if (std::sscanf(env_radix, "%d,%d", &rm, &rs) == 2 && rm >= 3 && rm <= 15 && (rm & 1) && rs >= 2 && rs <= 22) return make_geom_radix((uint32_t)rm, (uint32_t)rs);
   }
-  if (env) {
+  if (env && wgroups == 1) {
     int v = std::atoi(env);
     if (v >= 2 && v <= 24) return make_geom((uint32_t)v);
   }
+  // wgroups > 1: the windows are dealt out to that many ranks, so W must divide evenly (per-rank cost ~ total / wgroups)
   uint32_t best_c = 0;
   double best = 1e300;
   for (uint32_t c = 4; c <= 24; ++c) {
     double W = std::ceil((254.0 + 1.0) / c);  // (W-1)*c + (c-1) >= 254
+    if ((uint32_t)W % wgroups) continue;
     double cost = geom_cost(W, std::ldexp(1.0, (int)c - 1), c, n);
     if (cost < best) { best = cost; best_c = c; }
   }
-  MsmGeom G = make_geom(best_c);
-  if (env_radix && env_radix[0] == '0') return G;
+  MsmGeom G{};
+  if (best_c) G = make_geom(best_c);
+  if (env_radix && env_radix[0] == '0' && best_c) return G;
   // a mixed-radix layout must win by 1.5 % to be taken (its host join is slightly longer)
   for (uint32_t rmul = 3; rmul <= 15; rmul += 2)
     for (uint32_t rshift = 4; rshift <= 22; ++rshift) {
       MsmGeom R = make_geom_radix(rmul, rshift);
-      if (R.W > 64 || R.c > 24) continue;
+      if (R.W > 64 || R.c > 24 || R.W % wgroups) continue;
       double cost = geom_cost(R.W, R.nb, R.c, n);
       if (cost < 0.985 * best) { best = cost / 0.985; G = R; }
     }
@@ -675,7 +685,10 @@ MsmGeom choose_geom(uint64_t n, int group) {
 template <class F>
 int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n,
                const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out,
-               bool dense = false, const Affine<F>* d_bases2 = nullptr, Jacobian<F>* out2 = nullptr) {
+               bool dense = false, const Affine<F>* d_bases2 = nullptr, Jacobian<F>* out2 = nullptr, uint32_t wgroups = 1,
+               uint32_t wgroup = 0) {
+  // wgroups > 1: only window group `wgroup` of `wgroups` equal groups is evaluated -- the partial  sum_{w in group} B^w T_w
+  // of this point set; the partials of all groups (and of all point ranges) add up to the multiexp (shard.py).
   // dense == true: powersoftau's dense_multiexp contract (infinity bases add nothing, no Source errors);
   // d_bases2 != nullptr: a second base vector evaluated with the SAME exponents (merge_pairs), sharing the
   // digit extraction and the sorts.
@@ -686,10 +699,13 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   if (n_bases > 0x7fffffffull || n > 0x7fffffffull) return ZK_ERR_BAD_ARGS;
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
-  const MsmGeom G = choose_geom(n, (int)(sizeof(F) / sizeof(Fq)));
-  const uint64_t m = n * G.W;
+  if (wgroups == 0 || wgroup >= wgroups) return ZK_ERR_BAD_ARGS;
+  const MsmGeom G = choose_geom(n, (int)(sizeof(F) / sizeof(Fq)), wgroups);
+  if (G.W == 0 || G.W % wgroups) return ZK_ERR_BAD_ARGS;
+  const uint32_t WL = G.W / wgroups, w_lo = wgroup * WL, w_hi = w_lo + WL;  // this call's windows
+  const uint64_t m = n * WL;
   if (m > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
-  const uint32_t n_buckets = G.W * G.nb;
+  const uint32_t n_buckets = WL * G.nb;
   // reduction: running-sum levels (msm_reduce_level_kernel, chunk length L) while more than MSM_FINAL_MAX
   // elements per window are left, then the bit-decomposition stage (msm_tree_kernel)
   // chunk length per level: 2L serial additions per lane, so shorter chunks once lanes are scarce
@@ -697,7 +713,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint64_t total_chunks = 1;
   uint32_t final_cnt = G.nb;
   while (final_cnt > MSM_FINAL_MAX && n_levels < MSM_MAX_LEVELS) {
-    const uint32_t logl = (uint64_t)final_cnt * G.W >= (1ull << 20) ? 3 : 2;
+    const uint32_t logl = (uint64_t)final_cnt * WL >= (1ull << 20) ? 3 : 2;
     lvl_cnt[n_levels] = final_cnt;
     lvl_logl[n_levels] = logl;
     lvl_chunks[n_levels] = (final_cnt + (1u << logl) - 1) >> logl;
@@ -729,14 +745,14 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_item_off = take((size_t)(hb + 1) * 4);
   size_t o_seg_sums = take((size_t)max_items * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
-  size_t o_partA = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
-  size_t o_partS = take((size_t)G.W * total_chunks * sizeof(XYZZ<F>));
+  size_t o_partA = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
+  size_t o_partS = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
   const uint32_t n_out = n_levels + final_bits;  // per window: one A-sum per level, then one sum per bit
-  size_t o_wsums = take((size_t)G.W * n_out * sizeof(XYZZ<F>));
+  size_t o_wsums = take((size_t)WL * n_out * sizeof(XYZZ<F>));
   // slice sums of msm_tree_kernel (two ping-pong halves): n_out jobs per window, slices of the longest job
   const uint32_t tree_cnt = n_levels ? lvl_chunks[0] : final_cnt;
   const uint64_t tree_tmp = (uint64_t)n_out * ((tree_cnt + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE);
-  size_t o_sumtmp = take((size_t)G.W * tree_tmp * 2 * sizeof(XYZZ<F>));
+  size_t o_sumtmp = take((size_t)WL * tree_tmp * 2 * sizeof(XYZZ<F>));
   size_t o_err = take(8);
   size_t o_sort = take(sort_tmp_bytes);
 
@@ -771,7 +787,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     if (!debug) return 0;
     ZK_HIP(hipStreamSynchronize(st));
     std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u levels=%u: %s done\n", (int)(sizeof(F) / sizeof(Fq)),
-                 (unsigned long long)n, G.c, G.W, n_buckets, n_levels, what);
+                 (unsigned long long)n, G.c, WL, n_buckets, n_levels, what);
     return 0;
   };
   static const int slot_digits = prof_slot("msm_digits"), slot_sort = prof_slot("msm_sort"),
@@ -780,7 +796,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   prof_begin(slot_digits, st);
   hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, base_offset,
-                     d_density, d_dprefix, G, keys_a, vals_a);
+                     d_density, d_dprefix, G, w_lo, w_hi, keys_a, vals_a);
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
   if (checkpoint("digits")) return ZK_ERR_DEVICE;
@@ -822,11 +838,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       const XYZZ<F>* in = buckets;
       uint64_t o = 0;
       for (uint32_t lv = 0; lv < n_levels; ++lv) {
-        uint32_t threads = lvl_chunks[lv] * G.W;
-        XYZZ<F>* A = partA + o * G.W;
-        XYZZ<F>* S = partS + o * G.W;
+        uint32_t threads = lvl_chunks[lv] * WL;
+        XYZZ<F>* A = partA + o * WL;
+        XYZZ<F>* S = partS + o * WL;
         hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], 1u << lvl_logl[lv],
-                           lv == 0 ? 1u : 0u, G.W, A, S);
+                           lv == 0 ? 1u : 0u, WL, A, S);
         ZK_HIP(hipGetLastError());
         J.in[lv] = A;
         J.cnt[lv] = J.stride[lv] = lvl_chunks[lv];
@@ -851,7 +867,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
           if (sl > left) left = sl;
         }
         const bool last = left == 1;
-        hipLaunchKernelGGL(msm_tree_kernel<F>, dim3(J.first_block[n_out] * G.W), dim3(256), lds, st, J, last ? wsums : dst, left);
+        hipLaunchKernelGGL(msm_tree_kernel<F>, dim3(J.first_block[n_out] * WL), dim3(256), lds, st, J, last ? wsums : dst, left);
         ZK_HIP(hipGetLastError());
         if (last) break;
         for (uint32_t j = 0; j < n_out; ++j) {  // next launch: plain sums of the rows of slice sums
@@ -860,15 +876,15 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
           J.stride[j] = n_out * left;
           J.bit[j] = -1;
         }
-        dst = dst == sumtmp ? sumtmp + (uint64_t)G.W * tree_tmp : sumtmp;
+        dst = dst == sumtmp ? sumtmp + (uint64_t)WL * tree_tmp : sumtmp;
       }
     }
     prof_end(slot_red, st);
     if (checkpoint("reduce")) return (int)ZK_ERR_DEVICE;
 
-    std::vector<XYZZ<F>> h_wsums((size_t)G.W * n_out);
+    std::vector<XYZZ<F>> h_wsums((size_t)WL * n_out);
     unsigned long long h_err = 0;
-    ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)G.W * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)WL * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
@@ -898,22 +914,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     };
     Jacobian<F> acc;
     if (G.rmul == 1) {
-      std::vector<Jacobian<F>> by_exp((size_t)G.shift[G.W - 1] + e_k[n_out - 1] + 1, Jacobian<F>::zero());
-      for (uint32_t w = 0; w < G.W; ++w)
+      std::vector<Jacobian<F>> by_exp((size_t)G.shift[w_hi - 1] + e_k[n_out - 1] + 1, Jacobian<F>::zero());
+      for (uint32_t wl = 0; wl < WL; ++wl)
         for (uint32_t k = 0; k < n_out; ++k) {
-          const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
-          if (!pt.is_zero()) jac_add(by_exp[G.shift[w] + e_k[k]], xyzz_to_jacobian(pt));
+          const XYZZ<F>& pt = h_wsums[(size_t)wl * n_out + k];
+          if (!pt.is_zero()) jac_add(by_exp[G.shift[w_lo + wl] + e_k[k]], xyzz_to_jacobian(pt));
         }
       acc = horner(by_exp);
     } else {
-      // mixed radix: T_w by its own Horner pass, then  acc = B * acc + T_w  with  B = rmul * 2^rshift
+      // mixed radix: T_w by its own Horner pass, then  acc = B * acc + T_w  with  B = rmul * 2^rshift; the windows below this
+      // call's group contribute nothing here, only their powers of B
       acc = Jacobian<F>::zero();
-      for (int w = (int)G.W - 1; w >= 0; --w) {
-        std::vector<Jacobian<F>> by_exp((size_t)e_k[n_out - 1] + 1, Jacobian<F>::zero());
-        for (uint32_t k = 0; k < n_out; ++k) {
-          const XYZZ<F>& pt = h_wsums[(size_t)w * n_out + k];
-          if (!pt.is_zero()) jac_add(by_exp[e_k[k]], xyzz_to_jacobian(pt));
-        }
+      for (int w = (int)w_hi - 1; w >= 0; --w) {
         const Jacobian<F> one_acc = acc;            // rmul * acc by double-and-add over the bits of rmul (<= 15)
         int top = 3;
         while (!((G.rmul >> top) & 1u)) --top;
@@ -922,6 +934,12 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
           if ((G.rmul >> bit) & 1u) jac_add(acc, one_acc);
         }
         for (uint32_t r = 0; r < G.rshift; ++r) jac_double(acc);
+        if (w < (int)w_lo) continue;
+        std::vector<Jacobian<F>> by_exp((size_t)e_k[n_out - 1] + 1, Jacobian<F>::zero());
+        for (uint32_t k = 0; k < n_out; ++k) {
+          const XYZZ<F>& pt = h_wsums[(size_t)(w - (int)w_lo) * n_out + k];
+          if (!pt.is_zero()) jac_add(by_exp[e_k[k]], xyzz_to_jacobian(pt));
+        }
         jac_add(acc, horner(by_exp));
       }
     }

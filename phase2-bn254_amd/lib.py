@@ -26,12 +26,15 @@ SIGNATURES = {
     "mi355zk_bn254_g2_msm": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_msm_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g2_msm_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "mi355zk_bn254_g1_msm_part_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _vp, _vp]),
+    "mi355zk_bn254_g2_msm_part_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _vp, _vp]),
     "mi355zk_bn254_g1_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g2_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g1_merge_pairs_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "mi355zk_bn254_g2_merge_pairs_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "mi355zk_last_error_index": (C.c_longlong, []),
     "mi355zk_msm_window_bits": (_i, [_sz, C.POINTER(C.c_int)]),
+    "mi355zk_msm_window_bits_groups": (_i, [_sz, _u32, C.POINTER(C.c_int)]),
     "mi355zk_bn254_fr_ntt": (_i, [_vp, _u32, _vp]),
     "mi355zk_bn254_fr_domain_op": (_i, [_vp, _u32, _i]),
     "mi355zk_bn254_fr_fft": (_i, [_vp, _u32]),

@@ -1,4 +1,5 @@
 """Multi-GPU sharding of the multiexp: one process per GPU, contiguous point ranges,
+(or, shard.plan, a few point ranges x groups of scalar windows: mi355zk_bn254_g*_msm_part_dev),
 ONE exchange step -- an all-gather of the Jacobian partial sums (96 B for G1, 192 B for G2) over
 torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) followed
 by world-1 group additions on every rank.
@@ -21,6 +22,23 @@ def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
     base, rem = divmod(n, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def plan(world: int) -> tuple[int, int]:
+    """(point_groups, window_groups) with point_groups * window_groups == world.  Splitting by scalar WINDOWS first keeps every
+    rank on the large-n window geometry (fewer windows per scalar than a 1/world-size point range would get) at the price of
+    holding more bases per GPU; the window count of a geometry divides by at most 4 in practice (12 windows), beyond that the
+    points are split as well: 1 -> (1, 1), 2 -> (1, 2), 4 -> (1, 4), 8 -> (2, 4), 16 -> (4, 4); other sizes -> (world, 1)."""
+    if world >= 1 and world & (world - 1) == 0:
+        wg = min(world, 4)
+        return world // wg, wg
+    return world, 1
+
+
+def rank_groups(world: int, rank: int) -> tuple[int, int, int, int]:
+    """(point_groups, point_group, window_groups, window_group) of a rank: ranks that share a point range are adjacent."""
+    pg, wg = plan(world)
+    return pg, rank // wg, wg, rank % wg
 
 
 def density_base_offsets(density_bits, world: int) -> list[int]:

@@ -408,3 +408,48 @@ def test_baseline_size_2e26_closed_form_and_linearity(zk, worker):
     lo = zk.multiexp(worker, (bases[:h], 0), zk.FullDensity(), scalars[:h]).wait()
     hi = zk.multiexp(worker, (bases, h), zk.FullDensity(), scalars[h:]).wait()
     assert np.array_equal(O.G1.to_affine(zk.shard.join_partials(np.stack([lo, hi]))), O.G1.to_affine(total))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("log_n", [6, 12, 20])
+def test_window_group_partials_add_up(zk, worker, group, log_n):
+    """Multi-GPU sharding by scalar windows (shard.plan): the partials of all (point range, window group) cells add up to the
+    multiexp, for every split a power-of-two world produces, with a density map as well."""
+    if group == 2 and log_n == 20:
+        log_n = 16
+    n = 1 << log_n
+    G = O.G1 if group == 1 else O.G2
+    if log_n <= 12:
+        import torch
+
+        bases_h = inputs.bases_progression_cpu(group, n + 3, seed=1500 + log_n)
+        sc_h = inputs.random_scalars(n, seed=1501)
+        sc_h[::7] = 0
+        bases = torch.from_numpy(bases_h.view(np.int64)).cuda()
+        scalars = torch.from_numpy(sc_h.view(np.int64)).cuda()
+        rc, want = G.multiexp(bases_h, sc_h, base_offset=3)
+        assert rc == 0
+        off = 3
+    else:
+        bases, scalars, _ = _dev_inputs(zk, log_n, seed=1510) if group == 1 else (None, None, None)
+        if group == 2:
+            pytest.skip("covered at 2^12")
+        want = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+        off = 0
+    for world in (2, 4, 8):
+        pg, wg = zk.shard.plan(world)
+        parts = []
+        for rank in range(world):
+            _, p, _, w = zk.shard.rank_groups(world, rank)
+            lo, hi = zk.shard.shard_range(n, pg, p)
+            part = zk.multiexp(worker, (bases, off + lo), zk.FullDensity(), scalars[lo:hi], window_group=(wg, w)).wait()
+            parts.append(part)
+        got = zk.shard.join_partials(np.stack(parts))
+        assert np.array_equal(G.to_affine(got), G.to_affine(want)), (world, pg, wg)
+    if log_n == 12 and group == 1:  # density map + window groups
+        rng = np.random.default_rng(3)
+        bits = rng.random(n) < 0.5
+        rc, want_d = G.multiexp(bases_h, sc_h, density=GU.density_words(bits), density_bits=n, base_offset=3)
+        dm = zk.DensityTracker.from_bools(bits)
+        parts = [zk.multiexp(worker, (bases, 3), dm, scalars, window_group=(4, w)).wait() for w in range(4)]
+        assert rc == 0 and np.array_equal(G.to_affine(zk.shard.join_partials(np.stack(parts))), G.to_affine(want_d))

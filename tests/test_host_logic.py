@@ -52,3 +52,16 @@ def test_shard_ranges_cover_and_density_offsets():
         assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
     bits = [1, 0, 1, 1, 0, 0, 1, 1]
     assert zk.shard.density_base_offsets(bits, 2) == [0, 3] and zk.shard.density_base_offsets(bits, 4) == [0, 1, 3, 3]
+
+
+def test_shard_plan_covers_every_rank_once():
+    import phase2_bn254_amd as zk
+
+    assert [zk.shard.plan(w) for w in (1, 2, 4, 8, 16, 3, 6)] == [(1, 1), (1, 2), (1, 4), (2, 4), (4, 4), (3, 1), (6, 1)]
+    for world in (1, 2, 4, 8, 16, 5):
+        cells = set()
+        for rank in range(world):
+            pg, p, wg, w = zk.shard.rank_groups(world, rank)
+            assert pg * wg == world and 0 <= p < pg and 0 <= w < wg
+            cells.add((p, w))
+        assert len(cells) == world
