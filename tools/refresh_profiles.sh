@@ -23,4 +23,5 @@ timeout 300 python $R/tools/bench_g2.py > $O/g2_2e20.json 2>/dev/null
 timeout 400 python $R/tools/bench_next_rows.py --log-n 20 > $O/next_rows_2e20.json 2>/dev/null
 timeout 300 python $R/tools/bench_contribute.py > $O/contribute_2e20.json 2>/dev/null
 timeout 400 python $R/tools/bench_host_entry.py --log-n 20 24 26 > $O/host_entry.json 2>/dev/null
+timeout 400 python $R/tools/bench_shard_cells.py > $O/shard_cells_2e26.json 2>/dev/null
 ls -la $O

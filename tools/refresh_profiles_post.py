@@ -12,7 +12,7 @@ def put(src, dst, header=None):
         f.write(body)
 put("bench_n1.json", "bench_n1.json"); put("bench_2e20.json", "bench_2e20.json"); put("g2_2e20.json", "g2_2e20.json")
 put("next_rows_2e20.json", "next_rows_2e20.json"); put("ntt20.json", "ntt20.json")
-put("contribute_2e20.json", "contribute_2e20.json"); put("host_entry.json", "host_entry.json")
+put("contribute_2e20.json", "contribute_2e20.json"); put("host_entry.json", "host_entry.json"); put("shard_cells_2e26.json", "shard_cells_2e26.json")
 put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
     "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, 2^26-point G1 MSM)\n"
     "# summarised from the rocpd database with tools/rocpd_summary.py (ROCm 7.2 rocprofv3 writes rocpd; same numbers as --stats)\n"
