@@ -112,6 +112,23 @@ __device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8]) {
   return rem;
 }
 
+// two mixed-radix digits at once: (r0 + B r1) = q mod B^2, q = q div B^2, B = M * 2^sh (sh <= 22).  One multiword division by
+// M^2 instead of two by M: the multiword work is what the digit extraction costs.
+template <uint32_t M>
+__device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint32_t& r0, uint32_t& r1) {
+  const uint64_t low = (((uint64_t)q[1] << 32) | q[0]) & ((1ull << (2 * sh)) - 1ull);
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+#pragma unroll
+    for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
+  }
+  const uint32_t rem = msm_divmod_small<M * M>(q);
+  const uint64_t pv = low + ((uint64_t)rem << (2 * sh));  // < B^2 < 2^52
+  const uint64_t hi = (pv >> sh) / M;                      // pv div B
+  r1 = (uint32_t)hi;
+  r0 = (uint32_t)(pv - hi * ((uint64_t)M << sh));
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t base_offset,
                                                         const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
@@ -146,23 +163,43 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 #pragma unroll
     for (int l = 0; l < 8; ++l) q[l] = s[l];
     const uint32_t sh = G.rshift, B = G.rmul << sh;
+    uint32_t pending = 0;
+    bool have_pending = false;
     for (uint32_t w = 0; w < G.W; ++w) {
       uint32_t d, neg = 0;
       if (w + 1 < G.W) {
-        const uint32_t low = q[0] & ((1u << sh) - 1u);
+        uint32_t raw;
+        if (have_pending) {
+          raw = pending;
+          have_pending = false;
+        } else if (w + 2 < G.W) {  // this window and the next one, neither of them the top window
+          switch (G.rmul) {  // division by compile-time constants (multiply-high), not by runtime values
+            case 3: msm_two_digits<3>(q, sh, raw, pending); break;
+            case 5: msm_two_digits<5>(q, sh, raw, pending); break;
+            case 7: msm_two_digits<7>(q, sh, raw, pending); break;
+            case 9: msm_two_digits<9>(q, sh, raw, pending); break;
+            case 11: msm_two_digits<11>(q, sh, raw, pending); break;
+            case 13: msm_two_digits<13>(q, sh, raw, pending); break;
+            default: msm_two_digits<15>(q, sh, raw, pending); break;
+          }
+          have_pending = true;
+        } else {
+          const uint32_t low = q[0] & ((1u << sh) - 1u);
 #pragma unroll
-        for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
-        uint32_t rem = 0;
-        switch (G.rmul) {  // division by a compile-time constant (multiply-high), not by a runtime value
-          case 3: rem = msm_divmod_small<3>(q); break;
-          case 5: rem = msm_divmod_small<5>(q); break;
-          case 7: rem = msm_divmod_small<7>(q); break;
-          case 9: rem = msm_divmod_small<9>(q); break;
-          case 11: rem = msm_divmod_small<11>(q); break;
-          case 13: rem = msm_divmod_small<13>(q); break;
-          default: rem = msm_divmod_small<15>(q); break;
+          for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
+          uint32_t rem = 0;
+          switch (G.rmul) {
+            case 3: rem = msm_divmod_small<3>(q); break;
+            case 5: rem = msm_divmod_small<5>(q); break;
+            case 7: rem = msm_divmod_small<7>(q); break;
+            case 9: rem = msm_divmod_small<9>(q); break;
+            case 11: rem = msm_divmod_small<11>(q); break;
+            case 13: rem = msm_divmod_small<13>(q); break;
+            default: rem = msm_divmod_small<15>(q); break;
+          }
+          raw = low + (rem << sh);
         }
-        d = low + (rem << sh) + carry;
+        d = raw + carry;
         carry = 0;
         if (d > G.nb) {          // d in (B/2, B]  ->  d - B in (-B/2, 0]
           d = B - d;
