@@ -180,7 +180,7 @@ def main() -> int:
 
     # per-kernel durations measured with HIP events on the launch stream (library hooks)
     kern = {}
-    for name in ("msm_digits", "msm_sort", "msm_accumulate_heavy", "msm_accumulate", "msm_reduce"):
+    for name in ("msm_digits", "msm_sort", "msm_part_scan", "msm_scatter", "msm_bucket", "msm_accumulate_heavy", "msm_accumulate", "msm_reduce"):
         ms, cnt = C.c_double(), C.c_long()
         L.mi355zk_prof_get(name.encode(), C.byref(ms), C.byref(cnt))
         kern[name] = (ms.value / cnt.value) if cnt.value else None

@@ -113,6 +113,17 @@ int mi355zk_bn254_g1_msm_part_dev(const void *d_bases, size_t n_bases, size_t ba
 int mi355zk_bn254_g2_msm_part_dev(const void *d_bases, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
                                   const uint32_t *density, size_t density_bits, uint32_t window_groups, uint32_t window_group,
                                   void *stream, uint64_t out_xyz[24]);
+/* The general form: flags + window groups.  MI355ZK_MSM_SCALARS_MONTGOMERY: `d_scalars` holds Fr elements in MONTGOMERY form
+ * (the prover's `Vec<Scalar<E>>` / `Vec<E::Fr>`) instead of canonical FrRepr -- the O(m) conversion passes
+ * scalars_into_representations / field_elements_into_representations (bellman/src/groth16/prover.rs:89-129: `into_repr()` per
+ * element) are fused into the digit extraction (one Montgomery reduction per scalar, no extra pass over HBM). */
+#define MI355ZK_MSM_SCALARS_MONTGOMERY 1u
+int mi355zk_bn254_g1_msm_ex_dev(const void *d_bases, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
+                                const uint32_t *density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
+                                void *stream, uint64_t out_xyz[12]);
+int mi355zk_bn254_g2_msm_ex_dev(const void *d_bases, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
+                                const uint32_t *density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
+                                void *stream, uint64_t out_xyz[24]);
 /* exponent index at which the last failing multiexp of this thread raised its error, or -1 */
 long long mi355zk_last_error_index(void);
 /* bits of the bucket field (c for the power-of-two window layouts, ceil(log2(B/2 + 1)) for the mixed-radix ones) and
@@ -141,6 +152,15 @@ int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_
  * a[i] *= b[i] (mul_assign, domain.rs:236-249) and a[i] -= b[i] (sub_assign, domain.rs:251-260). */
 int mi355zk_bn254_fr_mul_assign_dev(void *d_a, const void *d_b, size_t n, void *stream);
 int mi355zk_bn254_fr_sub_assign_dev(void *d_a, const void *d_b, size_t n, void *stream);
+/* out[i] = into_repr(in[i]): Montgomery Fr -> canonical FrRepr (scalars_into_representations / field_elements_into_representations,
+ * prover.rs:89-129) as a standalone pass; d_out may alias d_in.  (The multiexp can take Montgomery scalars directly: msm_ex_dev.) */
+int mi355zk_bn254_fr_into_repr_dev(void *d_out, const void *d_in, size_t n, void *stream);
+/* EvaluationDomain::divide_by_z_on_coset (domain.rs:207-234): a[i] *= (g^m - 1)^-1 with m = 2^log_n and g = 7 the multiplicative
+ * generator (z(tau) = tau^m - 1, domain.rs:207-212) -- the division step of the prover's H polynomial (prover.rs:217-241), so that
+ * the whole ifft / coset_fft / mul / sub / divide / icoset_fft pipeline stays in HBM.  Asynchronous on `stream`. */
+int mi355zk_bn254_fr_divide_by_z_on_coset_dev(void *d_a, uint32_t log_n, void *stream);
+/* EvaluationDomain::z (domain.rs:207-212): out = tau^(2^log_n) - 1, Montgomery in and out (host arithmetic). */
+int mi355zk_bn254_fr_domain_z(uint32_t log_n, const uint64_t tau[4], uint64_t out[4]);
 /* Measured Montgomery-product rate of this library (the integer-ALU roofline the kernels are priced
  * against): `blocks` x 256 lanes each run 4 independent chains of `iters` products.  which: 0 Fq, 1 Fr.
  * out[0..3] = a*b^iters (Montgomery arithmetic, lane 0, chain 0) for a parity check; *ms = kernel time. */

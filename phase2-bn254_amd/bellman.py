@@ -127,9 +127,11 @@ class _Ready:
         return self._value
 
 
-def multiexp(pool: Worker, bases, density_map, exponents, window_group=None) -> _Ready:
+def multiexp(pool: Worker, bases, density_map, exponents, window_group=None, scalars_montgomery: bool = False) -> _Ready:
     """bellman/src/multiexp.rs:330.  (window_group = (groups, index), device-resident data only: the partial sum over one
-    of `groups` equal groups of scalar windows -- multi-GPU sharding by windows, shard.py; None = the whole multiexp.)  `bases` = (array, offset) like `(Arc<Vec<G>>, usize)`:
+    of `groups` equal groups of scalar windows -- multi-GPU sharding by windows, shard.py; None = the whole multiexp.
+    scalars_montgomery, device-resident data only: `exponents` are Montgomery-form Fr elements, i.e. the prover's vectors BEFORE
+    scalars_into_representations / field_elements_into_representations (prover.rs:89-129); the conversion is fused into the call.)  `bases` = (array, offset) like `(Arc<Vec<G>>, usize)`:
     array of shape (n_bases, 8) u64 for G1Affine raw records or (n_bases, 16) for G2Affine;
     `exponents` = (n, 4) u64 canonical FrRepr; `density_map` = FullDensity() or a DensityTracker.
     Returns a ready future whose wait() yields the Jacobian X||Y||Z limbs (12 / 24 u64)."""
@@ -148,14 +150,14 @@ def multiexp(pool: Worker, bases, density_map, exponents, window_group=None) -> 
         group = {8: 1, 16: 2}[limbs]
         out = np.zeros(12 * group, dtype=np.uint64)
         wg, wi = window_group if window_group is not None else (1, 0)
-        fn = lib.mi355zk_bn254_g1_msm_part_dev if group == 1 else lib.mi355zk_bn254_g2_msm_part_dev
+        fn = lib.mi355zk_bn254_g1_msm_ex_dev if group == 1 else lib.mi355zk_bn254_g2_msm_ex_dev
         with torch.cuda.device(arr.device):
             rc = fn(C.c_void_p(arr.data_ptr()), arr.shape[0], offset, C.c_void_p(exponents.data_ptr()), n_exp,
-                    words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits, int(wg), int(wi), _stream_ptr(),
-                    out.ctypes.data_as(C.c_void_p))
+                    words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits,
+                    _lib.MSM_SCALARS_MONTGOMERY if scalars_montgomery else 0, int(wg), int(wi), _stream_ptr(), out.ctypes.data_as(C.c_void_p))
     else:
-        if window_group is not None and tuple(window_group) != (1, 0):
-            raise ValueError("window groups need device-resident inputs")
+        if (window_group is not None and tuple(window_group) != (1, 0)) or scalars_montgomery:
+            raise ValueError("window groups / Montgomery scalars need device-resident inputs")
         arr = np.ascontiguousarray(arr, dtype=np.uint64)
         exponents = np.ascontiguousarray(exponents, dtype=np.uint64)
         limbs = arr.shape[1] if arr.ndim == 2 else 8
@@ -237,6 +239,38 @@ class EvaluationDomain:
 
     def icoset_fft(self, worker: Worker):  # domain.rs:197
         self._op(_lib.OP_ICOSET_FFT)
+
+    # ---- the elementwise steps of the prover's H pipeline (prover.rs:217-241), device-resident coefficients only
+    def _dev_coeffs(self):
+        if not _is_torch(self.coeffs):
+            raise ValueError("device-resident coefficients (a torch CUDA tensor) required")
+        return C.c_void_p(self.coeffs.data_ptr())
+
+    def z(self, tau):
+        """domain.rs:207-212: tau^m - 1 (tau, result: 4 u64 Montgomery limbs)."""
+        tau = np.ascontiguousarray(tau, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        rc = _lib.load().mi355zk_bn254_fr_domain_z(self.exp, tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise DeviceError(f"mi355zk domain_z failed rc={rc}")
+        return out
+
+    def divide_by_z_on_coset(self, worker: Worker):  # domain.rs:217-234
+        rc = _lib.load().mi355zk_bn254_fr_divide_by_z_on_coset_dev(self._dev_coeffs(), self.exp, _stream_ptr())
+        if rc != 0:
+            raise DeviceError(f"mi355zk divide_by_z_on_coset failed rc={rc}")
+
+    def mul_assign(self, worker: Worker, other: "EvaluationDomain"):  # domain.rs:236-249
+        assert self.coeffs.shape[0] == other.coeffs.shape[0]
+        rc = _lib.load().mi355zk_bn254_fr_mul_assign_dev(self._dev_coeffs(), other._dev_coeffs(), self.coeffs.shape[0], _stream_ptr())
+        if rc != 0:
+            raise DeviceError(f"mi355zk mul_assign failed rc={rc}")
+
+    def sub_assign(self, worker: Worker, other: "EvaluationDomain"):  # domain.rs:251-260
+        assert self.coeffs.shape[0] == other.coeffs.shape[0]
+        rc = _lib.load().mi355zk_bn254_fr_sub_assign_dev(self._dev_coeffs(), other._dev_coeffs(), self.coeffs.shape[0], _stream_ptr())
+        if rc != 0:
+            raise DeviceError(f"mi355zk sub_assign failed rc={rc}")
 
 
 def best_fft(a, worker: Worker, omega, log_n: int):

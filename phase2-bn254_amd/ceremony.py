@@ -265,7 +265,46 @@ def prepare_phase2(acc, m: int):
 
 
 _R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # fr.rs:4
-_G1_ONE_RAW = None
+
+# G1Affine::one() / G2Affine::one() as raw affine records (Montgomery limbs): the reference's literals
+# pairing/src/bn256/fq.rs:39-50 (G1_GENERATOR_X, _Y = (1, 2)) and :60-83 (G2_GENERATOR_X_C0, X_C1, Y_C0, Y_C1)
+G1_ONE_RAW = np.array([0xD35D438DC58F0D9D, 0x0A78EB28F5C70B3D, 0x666EA36F7879462C, 0x0E0A77C19A07DF2F,
+                       0xA6BA871B8B1E1B3A, 0x14F1D651EB8E167B, 0xCCDD46DEF0F28C58, 0x1C14EF83340FBE5E], dtype=np.uint64)
+G2_ONE_RAW = np.array([0x8E83B5D102BC2026, 0xDCEB1935497B0172, 0xFBB8264797811ADF, 0x19573841AF96503B,
+                       0xAFB4737DA84C6140, 0x6043DD5A5802D8C4, 0x09E950FC52A02F86, 0x14FEF0833AEA7B6B,
+                       0x619DFA9D886BE9F6, 0xFE7FD297F59E9B78, 0xFF9E1A62231B7DFE, 0x28FD7EEBAE9E4206,
+                       0x64095B56C71856EE, 0xDC57F922327D3CBB, 0x55F935BE33351076, 0x0DA4A0E693FD6482], dtype=np.uint64)
+
+
+def blank_hash() -> bytes:
+    """powersoftau/src/utils.rs:138-140: BLAKE2b-512 of the empty string, the `hash` field of a fresh challenge."""
+    import hashlib
+
+    return hashlib.blake2b(b"", digest_size=64).digest()
+
+
+def calculate_hash(data) -> bytes:
+    """powersoftau/src/utils.rs:20-27: BLAKE2b-512 over the whole file (`data`: bytes, numpy uint8 or a uint8 tensor).
+    Hashing is host work in the reference too (a sequential compression function; no device counterpart)."""
+    import hashlib
+
+    if hasattr(data, "cpu"):
+        data = data.cpu().numpy()
+    return hashlib.blake2b(np.ascontiguousarray(data, dtype=np.uint8).tobytes(), digest_size=64).digest()
+
+
+def new_accumulator(power: int, device):
+    """BatchedAccumulator::generate_initial (batched_accumulator.rs:1295-1347), the body of `new_constrained`: every element
+    of every vector is the group generator, the hash field is blank_hash().  write_accumulator(acc, compressed=False) of the
+    result is the challenge file of new_constrained.rs:42-77 (COMPRESS_NEW_CHALLENGE = No: `accumulator_size` bytes)."""
+    import torch
+
+    g1 = torch.from_numpy(G1_ONE_RAW.view(np.int64)).to(device)
+    g2 = torch.from_numpy(G2_ONE_RAW.view(np.int64)).to(device)
+    n = 1 << power
+    return {"hash": torch.frombuffer(bytearray(blank_hash()), dtype=torch.uint8).to(device),
+            "tau_g1": g1.repeat(2 * n - 1, 1), "tau_g2": g2.repeat(n, 1), "alpha_g1": g1.repeat(n, 1), "beta_g1": g1.repeat(n, 1),
+            "beta_g2": g2.repeat(1, 1)}
 
 
 def _limbs_i64(x: int):

@@ -24,9 +24,9 @@ void ntt_release_all();
 int ntt_configure();
 // msm.hip
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
-                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup);
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont);
 int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
-                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup);
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont);
 int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
@@ -590,7 +590,8 @@ int plan_density(size_t n_bases, size_t base_offset, size_t n_scalars, const uin
 
 template <int GROUP>
 int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
-                  const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0) {
+                  const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0,
+                  uint32_t flags = 0) {
   t_last_err_index = -1;
   if (!out_xyz || (n_scalars && !d_scalars) || (n_bases && !d_bases)) return ZK_ERR_BAD_ARGS;
   if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
@@ -605,12 +606,17 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
     size_t words = (n + 31) / 32;
     ZK_HIP(hipMalloc(&d_density, words * 8));
     d_prefix = d_density + words;
-    ZK_HIP(hipMemcpyAsync(d_density, density, words * 4, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(d_prefix, P.prefix.data(), words * 4, hipMemcpyHostToDevice, st));
+    hipError_t e = hipMemcpyAsync(d_density, density, words * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_prefix, P.prefix.data(), words * 4, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+      (void)hipFree(d_density);
+      ZK_HIP(e);
+    }
   }
   long long err_index = -1;
-  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup);
-  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup);
+  const bool mont = (flags & MI355ZK_MSM_SCALARS_MONTGOMERY) != 0;
+  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont);
+  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont);
   if (d_density) (void)hipFree(d_density);
   if (rc == ZK_ERR_UNEXPECTED_IDENTITY) {
     // the kernels report the lowest BASE index that was the identity under a non-zero exponent; the exponent that owns it
@@ -756,6 +762,19 @@ int mi355zk_bn254_g2_msm_part_dev(const void* d_bases, size_t n_bases, size_t ba
   if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
   return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
 }
+// flags (MI355ZK_MSM_*) + window groups in one entry point
+int mi355zk_bn254_g1_msm_ex_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                                const uint32_t* density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
+                                void* stream, uint64_t out_xyz[12]) {
+  if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
+  return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+}
+int mi355zk_bn254_g2_msm_ex_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                                const uint32_t* density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
+                                void* stream, uint64_t out_xyz[24]) {
+  if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
+  return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+}
 int mi355zk_bn254_g1_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
   if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   return msm_g1_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
@@ -819,6 +838,24 @@ int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_
   if (geninv) std::memcpy(geninv, &D.geninv, 32);
   if (minv) std::memcpy(minv, &D.minv, 32);
   return ZK_OK;
+}
+
+// EvaluationDomain::z (domain.rs:207-212) and divide_by_z_on_coset (domain.rs:217-234)
+int mi355zk_bn254_fr_domain_z(uint32_t log_n, const uint64_t tau[4], uint64_t out[4]) {
+  if (!tau || !out || log_n > 28) return ZK_ERR_BAD_ARGS;
+  Fr t;
+  std::memcpy(&t, tau, 32);
+  for (uint32_t i = 0; i < log_n; ++i) t = sqr(t);   // tau.pow(&[m]) with m = 2^log_n
+  t = sub(t, Fr::one());
+  std::memcpy(out, &t, 32);
+  return ZK_OK;
+}
+int mi355zk_bn254_fr_divide_by_z_on_coset_dev(void* d_a, uint32_t log_n, void* stream) {
+  if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;
+  Fr z = fr_from_u64(7);                             // E::Fr::multiplicative_generator() (fr.rs:5)
+  for (uint32_t i = 0; i < log_n; ++i) z = sqr(z);
+  z = sub(z, Fr::one());
+  return ntt_scale((Fr*)d_a, log_n, inv(z), nullptr, (hipStream_t)stream);
 }
 
 // EvaluationDomain<Point<G1>>::{fft, ifft} on affine records (group.rs:22-51, domain.rs:154-173; prepare_phase2.rs:68-131)

@@ -36,6 +36,12 @@ __global__ void __launch_bounds__(256) fr_pointwise_kernel(Fr* __restrict__ a, c
   }
 }
 
+// out[i] = into_repr(in[i]): Montgomery form -> canonical integer (one Montgomery reduction; out may alias in)
+__global__ void __launch_bounds__(256) fr_into_repr_kernel(Fr* out, const Fr* in, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    st(out + i, to_canonical(ld(in + i)));
+}
+
 // every lane runs `iters` dependent products x <- x * y on 4 independent chains (ILP like the group law)
 template <class PR>
 __global__ void __launch_bounds__(256) fp_mul_ubench_kernel(Fp<PR> a, Fp<PR> b, uint32_t iters, Fp<PR>* out) {
@@ -199,6 +205,15 @@ int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const u
 
 int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 0); }
 int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 1); }
+int mi355zk_bn254_fr_into_repr_dev(void* d_out, const void* d_in, size_t n, void* stream) {
+  if ((!d_out || !d_in) && n) return ZK_ERR_BAD_ARGS;
+  if (n == 0) return ZK_OK;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(zk::fr_into_repr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (zk::Fr*)d_out, (const zk::Fr*)d_in, (uint64_t)n);
+  ZK_HIP(hipGetLastError());
+  return ZK_OK;
+}
 
 int mi355zk_ubench_fp_mul(int which, uint32_t blocks, uint32_t iters, const uint64_t a[4], const uint64_t b[4], uint64_t out[16], float* ms) {
   if (!a || !b || !out || !ms) return ZK_ERR_BAD_ARGS;

@@ -26,9 +26,7 @@
 // (ec.rs:45-85, 596-629), so parity is defined on the affine normalisation.
 #include <hip/hip_runtime.h>
 
-#include <cstring>  // before rocprim: its texture iterator calls the host memset
-
-#include <rocprim/rocprim.hpp>
+#include <cstring>
 
 #include <cmath>
 #include <cstdio>
@@ -129,33 +127,10 @@ __device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint3
   r0 = (uint32_t)(pv - hi * ((uint64_t)M << sh));
 }
 
-template <class F>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t base_offset,
-                                                        const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
-                                                        MsmGeom G, uint32_t w_lo, uint32_t w_hi, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals) {
-  // only the windows w_lo <= w < w_hi are emitted (slot w - w_lo): a multi-GPU run may give every rank a subset of the
-  // windows of the same geometry; the carry chain of the signed digits still runs from window 0.
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool active = true;
-  uint64_t bi = base_offset + i;
-  if (density != nullptr) {
-    uint32_t wd = density[i >> 5];
-    active = (wd >> (i & 31)) & 1;
-    bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
-  }
-  uint32_t s[9];
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-  uint4 s0 = sp[0], s1 = sp[1];
-  s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
-  uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
-  if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
-    for (uint32_t w = w_lo; w < w_hi; ++w) keys[(uint64_t)(w - w_lo) * n + i] = ((w - w_lo) << G.c) | G.nb;
-    return;
-  }
-  // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is loaded
-  // anyway, in accumulate_run -- testing it here cost a second pass over all bases)
+// Digits of one scalar (canonical limbs s[0..7], s[8] = 0): emit(w, d, neg) for every window w of the geometry, d = |digit|
+// (0 = no bucket), neg = SIGN_BIT for a negative digit.  The carry chain of the signed digits runs from window 0.
+template <class Emit>
+__device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& G, Emit emit) {
   uint32_t carry = 0;
   if (G.rmul != 1) {
     // mixed radix: repeatedly  low = q mod 2^rshift;  q >>= rshift;  (q, r) = divmod(q, rmul);  digit = low + 2^rshift * r
@@ -209,11 +184,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       } else {
         d = q[0] + carry;        // top digit, unsigned: <= nb by the choice of B (make_geom_radix)
       }
-      if (w >= w_lo && w < w_hi) {
-        const uint64_t o = (uint64_t)(w - w_lo) * n + i;
-        keys[o] = ((w - w_lo) << G.c) | (d ? d - 1 : G.nb);
-        vals[o] = (uint32_t)bi | neg;
-      }
+      emit(w, d, neg);
     }
     return;
   }
@@ -229,43 +200,381 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
       neg = (d != 0) ? SIGN_BIT : 0;
       carry = 1;
     }
-    if (w >= w_lo && w < w_hi) {
-      uint64_t o = (uint64_t)(w - w_lo) * n + i;
-      keys[o] = ((w - w_lo) << G.c) | (d ? d - 1 : G.nb);  // sort field = low c bits: bucket, or nb = "no bucket" (sorts last)
-      vals[o] = (uint32_t)bi | neg;
+    emit(w, d, neg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. PARTITION: the (window, bucket) grouping of the n * WL digits, hand-written (no library sort on the path).
+//    Only GROUPING by bucket is needed (bucket membership of multiexp.rs:104-117; the order inside a bucket is irrelevant to
+//    the sum), so instead of a full LSD radix sort the digits take ONE coarse and ONE fine step, both staged through LDS:
+//      pass A  msm_digits_hist_kernel  scalars -> W signed digits, written window-major as 4-byte keys (bucket | sign); the
+//              workgroup keeps an LDS histogram over (window, coarse bin = bucket >> lo_bits) and dumps it once per
+//              super-tile of ST scalars: tile_hist[super-tile][window][bin] (u16).
+//      scan    msm_colsum / msm_binscan / msm_tileoff: column-wise exclusive prefix sums of tile_hist -> for every
+//              (super-tile, window, bin) the exact position of its run inside the bin's region: no atomics, no look-back.
+//      pass B  msm_scatter_kernel  one workgroup per (window, super-tile): keys -> LDS histogram ranks -> the tile's
+//              elements reordered by bin in LDS -> written out as contiguous runs of (key, base index) pairs.
+//      pass C  msm_bucket_kernel   one workgroup per (window, coarse bin) (~2^14 elements, held in registers): LDS histogram
+//              over its 2^lo_bits buckets -> bucket bounds first[] / last[] (bucket starts aligned to 4 entries so that the
+//              accumulation can read its index list with 16-byte loads) -> indices placed through an LDS staging buffer and
+//              written out coalesced.  Bins that outgrow registers / LDS (skewed scalars) take a two-read path.
+//    HBM traffic per element: 4 B (keys) written + read, 8 B (pairs) written + read, 4 B (indices) written = 28 B, against
+//    3 x 16 B for a three-pass pair sort.
+constexpr uint32_t PART_THREADS = 1024;
+constexpr uint32_t PART_MAX_ST = 16384;       // super-tile: scalars per pass-A histogram dump = elements per pass-B workgroup
+constexpr uint32_t PART_MAX_EB = PART_MAX_ST / PART_THREADS;
+constexpr uint32_t PART_LO_MAX = 12;          // at most 4096 buckets per coarse bin
+constexpr uint32_t PART_EC = 32;              // pass C: elements per lane held in registers
+constexpr uint32_t PART_LDS_A = 150 * 1024;   // pass A histogram budget
+constexpr uint32_t PART_LDS_MAX = 160 * 1024 - 512;
+constexpr uint32_t KEY_NONE_MASK = 0x00ffffffu;  // key = bucket (or nb = none) in the low 24 bits | SIGN_BIT
+
+struct PartGeom {
+  uint32_t lo_bits;   // fine bits: buckets per coarse bin = 2^lo_bits
+  uint32_t nbin;      // coarse bins per window
+  uint32_t st;        // super-tile size (multiple of PART_THREADS)
+  uint32_t n_st;      // super-tiles
+  uint32_t n_chunk;   // row chunks of the column scans
+  uint32_t rows_per_chunk;
+};
+
+// exclusive prefix sums over len <= 4 * PART_THREADS values: value(idx) -> out(idx, exclusive prefix); returns the total.
+// `scratch`: 17 words of LDS.  Every thread of the 1024-thread workgroup must call it.
+template <class In, class Out>
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t len, uint32_t* scratch, In value, Out out) {
+  constexpr uint32_t PER = 4;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t idx = tid * PER + k;
+    v[k] = idx < len ? value(idx) : 0u;
+    sum += v[k];
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();  // scratch may still be read from a previous call
+  if (lane == 63) scratch[wv] = inc;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < PART_THREADS / 64; ++w) {
+      const uint32_t t = scratch[w];
+      scratch[w] = run;
+      run += t;
+    }
+    scratch[16] = run;
+  }
+  __syncthreads();
+  uint32_t run = scratch[wv] + inc - sum;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t idx = tid * PER + k;
+    if (idx < len) out(idx, run);
+    run += v[k];
+  }
+  return scratch[16];
+}
+
+// pass A.  density == nullptr: FullDensity (source.rs:80-99).  Otherwise bit i of `density` selects exponent i
+// (source.rs:101-118).  scalars_mont != 0: the exponents are Fr elements in Montgomery form (what the prover holds before
+// scalars_into_representations, prover.rs:89-129): the conversion into_repr() is one Montgomery reduction, fused here.
+__global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n,
+                                                                       const uint32_t* __restrict__ density, MsmGeom G, uint32_t w_lo,
+                                                                       uint32_t w_hi, int scalars_mont, PartGeom P,
+                                                                       uint32_t* __restrict__ keys, uint16_t* __restrict__ tile_hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* lh = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t WL = w_hi - w_lo, ncell = WL * P.nbin;
+  for (uint32_t st = blockIdx.x; st < P.n_st; st += gridDim.x) {
+    for (uint32_t t = threadIdx.x; t < ncell; t += PART_THREADS) lh[t] = 0;
+    __syncthreads();
+    const uint64_t i_end = (uint64_t)(st + 1) * P.st < n ? (uint64_t)(st + 1) * P.st : n;
+    for (uint64_t i = (uint64_t)st * P.st + threadIdx.x; i < i_end; i += PART_THREADS) {
+      bool active = true;
+      if (density != nullptr) active = (density[i >> 5] >> (i & 31)) & 1;
+      uint32_t s[9];
+      const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+      const uint4 s0 = sp[0], s1 = sp[1];
+      s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
+      if (scalars_mont) {
+        Fr f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) f.l[l] = s[l];
+        f = to_canonical(f);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) s[l] = f.l[l];
+      }
+      const uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
+      if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
+        for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * n + i] = G.nb;
+        continue;
+      }
+      // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is
+      // loaded anyway, in accumulate_run)
+      msm_scalar_digits(s, G, [&](uint32_t w, uint32_t d, uint32_t neg) {
+        if (w >= w_lo && w < w_hi) {
+          const uint32_t wl = w - w_lo;
+          keys[(uint64_t)wl * n + i] = d ? ((d - 1) | neg) : G.nb;
+          if (d) atomicAdd(&lh[wl * P.nbin + ((d - 1) >> P.lo_bits)], 1u);
+        }
+      });
+    }
+    __syncthreads();
+    uint16_t* row = tile_hist + (uint64_t)st * ncell;
+    for (uint32_t t = threadIdx.x; t < ncell; t += PART_THREADS) row[t] = (uint16_t)lh[t];  // <= ST <= 16384
+    __syncthreads();
+  }
+}
+
+// column sums of tile_hist over one chunk of rows: csum[chunk][col]
+__global__ void __launch_bounds__(256) msm_colsum_kernel(const uint16_t* __restrict__ tile_hist, PartGeom P, uint32_t ncell,
+                                                        uint32_t* __restrict__ csum) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+  if (col >= ncell) return;
+  const uint32_t r0 = chunk * P.rows_per_chunk, r1 = r0 + P.rows_per_chunk < P.n_st ? r0 + P.rows_per_chunk : P.n_st;
+  uint32_t s = 0;
+  for (uint32_t r = r0; r < r1; ++r) s += tile_hist[(uint64_t)r * ncell + col];
+  csum[(uint64_t)chunk * ncell + col] = s;
+}
+
+// one workgroup: bin_start[col] = elements before (window, bin) `col` in the pair array, out_start[col] = first slot of
+// the bin's region in the index array (every bucket start is padded to a multiple of 4 entries: + up to 3 per bucket),
+// and csum[chunk][col] is replaced by the position at which the chunk's first row starts inside the bin.
+__global__ void __launch_bounds__(PART_THREADS) msm_binscan_kernel(uint32_t* __restrict__ csum, PartGeom P, uint32_t ncell, uint32_t nb,
+                                                                   uint32_t* __restrict__ bin_start, uint32_t* __restrict__ out_start) {
+  __shared__ uint32_t part[PART_THREADS], part_out[PART_THREADS];
+  const uint32_t per = (ncell + PART_THREADS - 1) / PART_THREADS;
+  const uint32_t c0 = threadIdx.x * per, c1 = c0 + per < ncell ? c0 + per : ncell;
+  uint32_t sum = 0, sum_out = 0;
+  for (uint32_t col = c0; col < c1; ++col) {
+    uint32_t tot = 0;
+    for (uint32_t ch = 0; ch < P.n_chunk; ++ch) tot += csum[(uint64_t)ch * ncell + col];
+    const uint32_t bin = col % P.nbin;
+    const uint32_t nf = (bin + 1) << P.lo_bits <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
+    sum += tot;
+    sum_out += (tot + 3u * nf + 3u) & ~3u;
+  }
+  part[threadIdx.x] = sum;
+  part_out[threadIdx.x] = sum_out;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0, run_out = 0;
+    for (uint32_t t = 0; t < PART_THREADS; ++t) {
+      uint32_t v = part[t], vo = part_out[t];
+      part[t] = run;
+      part_out[t] = run_out;
+      run += v;
+      run_out += vo;
+    }
+    bin_start[ncell] = run;
+    out_start[ncell] = run_out;
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x], run_out = part_out[threadIdx.x];
+  for (uint32_t col = c0; col < c1; ++col) {
+    bin_start[col] = run;
+    out_start[col] = run_out;
+    uint32_t tot = 0;
+    for (uint32_t ch = 0; ch < P.n_chunk; ++ch) {
+      const uint32_t v = csum[(uint64_t)ch * ncell + col];
+      csum[(uint64_t)ch * ncell + col] = run + tot;
+      tot += v;
+    }
+    const uint32_t bin = col % P.nbin;
+    const uint32_t nf = (bin + 1) << P.lo_bits <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
+    run += tot;
+    run_out += (tot + 3u * nf + 3u) & ~3u;
+  }
+}
+
+// tile_off[row][col] = position in the pair array at which super-tile `row` writes its run of (window, bin) `col`
+__global__ void __launch_bounds__(256) msm_tileoff_kernel(const uint16_t* __restrict__ tile_hist, const uint32_t* __restrict__ cbase, PartGeom P,
+                                                         uint32_t ncell, uint32_t* __restrict__ tile_off) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+  if (col >= ncell) return;
+  const uint32_t r0 = chunk * P.rows_per_chunk, r1 = r0 + P.rows_per_chunk < P.n_st ? r0 + P.rows_per_chunk : P.n_st;
+  uint32_t run = cbase[(uint64_t)chunk * ncell + col];
+  for (uint32_t r = r0; r < r1; ++r) {
+    tile_off[(uint64_t)r * ncell + col] = run;
+    run += tile_hist[(uint64_t)r * ncell + col];
+  }
+}
+
+// pass B.  One workgroup per (window wl, super-tile st): the tile's keys are ranked inside their coarse bin by LDS atomics,
+// reordered by bin in LDS and written out as one contiguous run per bin at tile_off[st][wl][bin].  The pair carries the
+// key (bucket | sign) and the BASE index of the exponent: base_offset + i under FullDensity, base_offset + rank(i) for a
+// density map (source.rs:101-118: rank(i) = dprefix[i/32] + popc(density[i/32] & ((1 << i%32) - 1))).
+__global__ void __launch_bounds__(PART_THREADS) msm_scatter_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint64_t base_offset,
+                                                                   const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
+                                                                   uint32_t nb, uint32_t WL, PartGeom P, const uint32_t* __restrict__ tile_off,
+                                                                   uint2* __restrict__ pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* loff = reinterpret_cast<uint32_t*>(smem);             // nbin: counts, then exclusive offsets inside the tile
+  uint32_t* scratch = loff + ((P.nbin + 3u) & ~3u);               // 32 words
+  uint2* staging = reinterpret_cast<uint2*>(scratch + 32);        // st pairs
+  const uint32_t st = blockIdx.x % P.n_st, wl = blockIdx.x / P.n_st;
+  const uint64_t i0 = (uint64_t)st * P.st;
+  const uint32_t cnt = (uint32_t)(n - i0 < P.st ? n - i0 : P.st);
+  for (uint32_t t = threadIdx.x; t < P.nbin; t += PART_THREADS) loff[t] = 0;
+  __syncthreads();
+  uint32_t key[PART_MAX_EB], rank[PART_MAX_EB];
+  const uint32_t* kp = keys + (uint64_t)wl * n + i0;
+#pragma unroll
+  for (uint32_t k = 0; k < PART_MAX_EB; ++k) {
+    const uint32_t idx = k * PART_THREADS + threadIdx.x;
+    key[k] = nb;
+    rank[k] = 0;
+    if (idx < cnt) {
+      key[k] = kp[idx];
+      const uint32_t b = key[k] & KEY_NONE_MASK;
+      if (b < nb) rank[k] = atomicAdd(&loff[b >> P.lo_bits], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t total = block_scan_1024(P.nbin, scratch, [&](uint32_t x) { return loff[x]; }, [&](uint32_t x, uint32_t ex) { loff[x] = ex; });
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < PART_MAX_EB; ++k) {
+    const uint32_t idx = k * PART_THREADS + threadIdx.x;
+    const uint32_t b = key[k] & KEY_NONE_MASK;
+    if (idx < cnt && b < nb) {
+      const uint64_t i = i0 + idx;
+      uint64_t bi = base_offset + i;
+      if (density != nullptr) {
+        const uint32_t wd = density[i >> 5];
+        bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
+      }
+      staging[loff[b >> P.lo_bits] + rank[k]] = make_uint2(key[k], (uint32_t)bi);
+    }
+  }
+  __syncthreads();
+  const uint32_t* toff = tile_off + ((uint64_t)st * WL + wl) * P.nbin;
+  for (uint32_t p = threadIdx.x; p < total; p += PART_THREADS) {
+    const uint2 e = staging[p];
+    const uint32_t bin = (e.x & KEY_NONE_MASK) >> P.lo_bits;
+    pairs[(uint64_t)toff[bin] + (p - loff[bin])] = e;
+  }
+}
+
+// pass C.  One workgroup per (window wl, coarse bin): its pairs [bin_start[col], bin_start[col + 1]) are grouped by bucket.
+//   first[id] / last[id] (id = wl * nb + bucket) delimit the bucket's index list inside `vals`; every list starts at a
+//   multiple of 4 entries (16-byte loads in the accumulation; the padding slots are never consumed).
+//   vals entry = base index | SIGN_BIT for a negative digit.
+__global__ void __launch_bounds__(PART_THREADS) msm_bucket_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ bin_start,
+                                                                  const uint32_t* __restrict__ out_start, uint32_t nb, PartGeom P,
+                                                                  uint32_t stage_cap, uint32_t* __restrict__ first, uint32_t* __restrict__ last,
+                                                                  uint32_t* __restrict__ vals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t nfmax = 1u << P.lo_bits;
+  const uint32_t nfl = nfmax < 4 ? 4 : nfmax;            // (keeps `staging` 16-byte aligned)
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);   // nfmax
+  uint32_t* start = hist + nfl;                          // nfmax
+  uint32_t* scratch = start + nfl;                       // 32
+  uint32_t* staging = scratch + 32;                      // stage_cap
+  const uint32_t col = blockIdx.x, wl = col / P.nbin, bin = col % P.nbin;
+  const uint32_t beg = bin_start[col], cnt = bin_start[col + 1] - beg;
+  const uint32_t ob = out_start[col];
+  const uint32_t nf = (bin + 1) << P.lo_bits <= nb ? nfmax : nb - (bin << P.lo_bits);
+  const uint32_t fmask = nfmax - 1u;
+  for (uint32_t t = threadIdx.x; t < nfmax; t += PART_THREADS) hist[t] = 0;
+  __syncthreads();
+  const bool in_regs = cnt <= PART_EC * PART_THREADS;
+  uint32_t val[PART_EC], fr[PART_EC];  // fr = fine bucket | rank << PART_LO_MAX
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t k = 0; k < PART_EC; ++k) {
+      const uint32_t idx = k * PART_THREADS + threadIdx.x;
+      val[k] = 0;
+      fr[k] = 0;
+      if (idx < cnt) {
+        const uint2 e = pairs[(uint64_t)beg + idx];
+        const uint32_t f = e.x & fmask;
+        val[k] = e.y | (e.x & SIGN_BIT);
+        fr[k] = f | (atomicAdd(&hist[f], 1u) << PART_LO_MAX);
+      }
+    }
+  } else {
+    for (uint32_t idx = threadIdx.x; idx < cnt; idx += PART_THREADS) atomicAdd(&hist[pairs[(uint64_t)beg + idx].x & fmask], 1u);
+  }
+  __syncthreads();
+  const uint32_t padded = block_scan_1024(nf, scratch, [&](uint32_t x) { return (hist[x] + 3u) & ~3u; },
+                                          [&](uint32_t x, uint32_t ex) { start[x] = ex; });
+  __syncthreads();
+  const uint32_t id0 = wl * nb + (bin << P.lo_bits);
+  for (uint32_t t = threadIdx.x; t < nf; t += PART_THREADS) {
+    first[id0 + t] = ob + start[t];
+    last[id0 + t] = ob + start[t] + hist[t];
+  }
+  if (in_regs && padded <= stage_cap) {
+#pragma unroll
+    for (uint32_t k = 0; k < PART_EC; ++k) {
+      const uint32_t idx = k * PART_THREADS + threadIdx.x;
+      if (idx < cnt) staging[start[fr[k] & ((1u << PART_LO_MAX) - 1u)] + (fr[k] >> PART_LO_MAX)] = val[k];
+    }
+    __syncthreads();
+    // 16-byte stores; `ob` and `padded` are multiples of 4
+    uint4* dst = reinterpret_cast<uint4*>(vals + ob);
+    const uint4* src = reinterpret_cast<const uint4*>(staging);
+    for (uint32_t q = threadIdx.x; q < padded / 4; q += PART_THREADS) dst[q] = src[q];
+  } else if (in_regs) {
+#pragma unroll
+    for (uint32_t k = 0; k < PART_EC; ++k) {
+      const uint32_t idx = k * PART_THREADS + threadIdx.x;
+      if (idx < cnt) vals[(uint64_t)ob + start[fr[k] & ((1u << PART_LO_MAX) - 1u)] + (fr[k] >> PART_LO_MAX)] = val[k];
+    }
+  } else {
+    // second read: `hist` becomes the running cursor of every bucket
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nfmax; t += PART_THREADS) hist[t] = 0;
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < cnt; idx += PART_THREADS) {
+      const uint2 e = pairs[(uint64_t)beg + idx];
+      const uint32_t f = e.x & fmask;
+      vals[(uint64_t)ob + start[f] + atomicAdd(&hist[f], 1u)] = e.y | (e.x & SIGN_BIT);
     }
   }
 }
 
-// 2. the pairs are sorted (stable LSD radix sort) on the LOW c BITS of the key only: the digits kernel writes
-//    window-major, so equal sort fields keep their window order and every (window, bucket) run is contiguous --
-//    the window number never has to take part in the sort (2 passes instead of 3 for c <= 16).
-// 3. bucket boundaries in the sorted pair list; bucket id = window * nb + bucket
-__global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, uint64_t m, uint32_t c, uint32_t nb,
-                                                        uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
-  // four consecutive keys per lane (one 16-byte load) plus the two neighbours: a streaming pass over the keys
-  const uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (j0 >= m) return;
-  uint32_t k[6];
-  if (j0 + 4 <= m) {
-    const uint4 v = *reinterpret_cast<const uint4*>(keys + j0);
-    k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
-  } else {
-    for (int t = 0; t < 4; ++t) k[1 + t] = j0 + t < m ? keys[j0 + t] : 0xffffffffu;
+// partition geometry for n scalars, WL windows of nb bucket slots each
+inline PartGeom choose_part(uint64_t n, uint32_t WL, uint32_t nb) {
+  static const char* env_lo = std::getenv("MI355ZK_PART_LO");
+  static const char* env_st = std::getenv("MI355ZK_PART_ST");
+  PartGeom P{};
+  uint32_t lo_cap = 0;
+  while ((1u << lo_cap) < nb && lo_cap < PART_LO_MAX) ++lo_cap;  // one bin holds everything, or 2^PART_LO_MAX buckets
+  auto nbin_of = [&](uint32_t lo) { return (uint32_t)(((uint64_t)nb + (1ull << lo) - 1) >> lo); };
+  // as fine as the pass-A histogram (WL * nbin words of LDS) allows, but no finer than ~8192 elements per bin need
+  auto fits = [&](uint32_t lo) { return (uint64_t)WL * nbin_of(lo) * 4 <= PART_LDS_A && nbin_of(lo) <= 4 * PART_THREADS; };
+  uint32_t lo = lo_cap;
+  const uint64_t pop_target = 12288;
+  while (lo > 0 && (uint64_t)n * (1ull << lo) / nb > pop_target && fits(lo - 1)) --lo;
+  while (!fits(lo) && lo < PART_LO_MAX) ++lo;
+  if (env_lo) {
+    const int v = std::atoi(env_lo);
+    if (v >= 0 && v <= (int)lo_cap && fits((uint32_t)v)) lo = (uint32_t)v;
   }
-  k[0] = j0 ? keys[j0 - 1] : ~k[1];
-  k[5] = j0 + 4 < m ? keys[j0 + 4] : ~k[4];
-  const uint32_t mask = (1u << c) - 1u;
-#pragma unroll
-  for (int t = 1; t <= 4; ++t) {
-    const uint64_t j = j0 + (uint64_t)(t - 1);
-    if (j >= m) break;
-    const uint32_t field = k[t] & mask;
-    if (field >= nb) continue;
-    const uint32_t id = (k[t] >> c) * nb + field;
-    if (k[t - 1] != k[t]) first[id] = (uint32_t)j;
-    if (j + 1 == m || k[t + 1] != k[t]) last[id] = (uint32_t)j + 1;
+  P.lo_bits = lo;
+  P.nbin = nbin_of(lo);
+  uint32_t st = PART_MAX_ST;
+  while (st > PART_THREADS && n / st < 512) st >>= 1;
+  if (env_st) {
+    const int v = std::atoi(env_st);
+    if (v >= (int)PART_THREADS && v <= (int)PART_MAX_ST && v % (int)PART_THREADS == 0) st = (uint32_t)v;
   }
+  // pass B holds the tile (8 B per element) and nbin words in LDS
+  while (st > PART_THREADS && (uint64_t)st * 8 + (uint64_t)P.nbin * 4 + 256 > PART_LDS_MAX) st -= PART_THREADS;
+  if ((uint64_t)st * 8 + (uint64_t)P.nbin * 4 + 256 > PART_LDS_MAX) st = 0;  // cannot happen: nbin <= 4096
+  P.st = st;
+  P.n_st = (uint32_t)((n + st - 1) / st);
+  P.rows_per_chunk = P.n_st > 64 ? (P.n_st + 63) / 64 : 1;
+  P.n_chunk = (P.n_st + P.rows_per_chunk - 1) / P.rows_per_chunk;
+  return P;
 }
 
 // 3b. buckets ordered by size (descending) so that the 64 lanes of a wave own buckets of (nearly) equal length --
@@ -719,11 +1028,32 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
   return G;
 }
 
+// the partition kernels use up to the whole 160 KiB of LDS (dynamic): raise the limit once per device
+std::mutex g_part_cfg_mu;
+std::map<int, int> g_part_cfg;
+int part_configure(int dev) {
+  std::lock_guard<std::mutex> lk(g_part_cfg_mu);
+  auto it = g_part_cfg.find(dev);
+  if (it != g_part_cfg.end()) return it->second;
+  int rc = ZK_OK;
+  const void* fns[3] = {reinterpret_cast<const void*>(msm_digits_hist_kernel), reinterpret_cast<const void*>(msm_scatter_kernel),
+                        reinterpret_cast<const void*>(msm_bucket_kernel)};
+  for (const void* fn : fns) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(partition kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
+      rc = ZK_ERR_DEVICE;
+    }
+  }
+  g_part_cfg[dev] = rc;
+  return rc;
+}
+
 template <class F>
 int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n,
                const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out,
                bool dense = false, const Affine<F>* d_bases2 = nullptr, Jacobian<F>* out2 = nullptr, uint32_t wgroups = 1,
-               uint32_t wgroup = 0) {
+               uint32_t wgroup = 0, bool scalars_mont = false) {
   // wgroups > 1: only window group `wgroup` of `wgroups` equal groups is evaluated -- the partial  sum_{w in group} B^w T_w
   // of this point set; the partials of all groups (and of all point ranges) add up to the multiexp (shard.py).
   // dense == true: powersoftau's dense_multiexp contract (infinity bases add nothing, no Source errors);
@@ -762,16 +1092,20 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t final_bits = 1;
   while ((1u << final_bits) <= final_cnt - 1 + final_off) ++final_bits;
 
-  size_t sort_tmp_bytes = 0;
-  ZK_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint32_t*)nullptr, (size_t)m, 0, G.c, st));
+  const PartGeom P = choose_part(n, WL, G.nb);
+  if (P.st == 0) return ZK_ERR_BAD_ARGS;
+  const uint32_t ncell = WL * P.nbin;
+  // index lists: every bucket start is padded to a multiple of 4 entries (<= 3 per bucket), every bin region to 4
+  const uint64_t vals_cap = m + 3ull * n_buckets + 4ull * ncell + 4;
+  if (vals_cap > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;
 
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
-  size_t o_keys_a = take(m * 4), o_keys_b = take(m * 4), o_vals_a = take(m * 4), o_vals_b = take(m * 4);
-  // first, last and the size histogram are contiguous: one memset clears them
+  // the window-major keys of pass A are dead once pass B has run; pass C writes the index lists over them
+  size_t o_keys = take((size_t)vals_cap * 4), o_pairs = take((size_t)m * 8);
+  size_t o_tile_hist = take((size_t)P.n_st * ncell * 2), o_tile_off = take((size_t)P.n_st * ncell * 4);
+  size_t o_csum = take((size_t)P.n_chunk * ncell * 4), o_bin_start = take((size_t)(ncell + 1) * 4), o_out_start = take((size_t)(ncell + 1) * 4);
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
-  size_t o_zero_end = off;
   size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
   // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
   const uint64_t mean_len = n / G.nb + 1;
@@ -791,17 +1125,22 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   const uint64_t tree_tmp = (uint64_t)n_out * ((tree_cnt + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE);
   size_t o_sumtmp = take((size_t)WL * tree_tmp * 2 * sizeof(XYZZ<F>));
   size_t o_err = take(8);
-  size_t o_sort = take(sort_tmp_bytes);
 
+  int rc = part_configure(dev);
+  if (rc) return rc;
   std::unique_lock<std::mutex> lk(g_ws_mu);
   void* base = nullptr;
-  int rc = ws_reserve(dev, off, &base);
+  rc = ws_reserve(dev, off, &base);
   if (rc) return rc;
   char* ws = (char*)base;
-  uint32_t* keys_a = (uint32_t*)(ws + o_keys_a);
-  uint32_t* keys_b = (uint32_t*)(ws + o_keys_b);
-  uint32_t* vals_a = (uint32_t*)(ws + o_vals_a);
-  uint32_t* vals_b = (uint32_t*)(ws + o_vals_b);
+  uint32_t* keys = (uint32_t*)(ws + o_keys);
+  uint32_t* vals_b = keys;  // (aliases the keys: see above)
+  uint2* pairs = (uint2*)(ws + o_pairs);
+  uint16_t* tile_hist = (uint16_t*)(ws + o_tile_hist);
+  uint32_t* tile_off = (uint32_t*)(ws + o_tile_off);
+  uint32_t* csum = (uint32_t*)(ws + o_csum);
+  uint32_t* bin_start = (uint32_t*)(ws + o_bin_start);
+  uint32_t* out_start = (uint32_t*)(ws + o_out_start);
   uint32_t* first = (uint32_t*)(ws + o_first);
   uint32_t* last = (uint32_t*)(ws + o_last);
   uint32_t* size_hist = (uint32_t*)(ws + o_hist);
@@ -817,35 +1156,66 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   unsigned long long* d_err = (unsigned long long*)(ws + o_err);
 
   ZK_HIP(hipMemsetAsync(d_err, 0xff, 8, st));
-  ZK_HIP(hipMemsetAsync(first, 0, o_zero_end - o_first, st));
+  ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
 
   static const bool debug = std::getenv("MI355ZK_DEBUG") != nullptr;
   auto checkpoint = [&](const char* what) -> int {
     if (!debug) return 0;
     ZK_HIP(hipStreamSynchronize(st));
-    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u levels=%u: %s done\n", (int)(sizeof(F) / sizeof(Fq)),
-                 (unsigned long long)n, G.c, WL, n_buckets, n_levels, what);
+    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u levels=%u part(lo=%u nbin=%u st=%u): %s done\n",
+                 (int)(sizeof(F) / sizeof(Fq)), (unsigned long long)n, G.c, WL, n_buckets, n_levels, P.lo_bits, P.nbin, P.st, what);
     return 0;
   };
-  static const int slot_digits = prof_slot("msm_digits"), slot_sort = prof_slot("msm_sort"),
-                   slot_acc = prof_slot("msm_accumulate"), slot_heavy = prof_slot("msm_accumulate_heavy"),
-                   slot_red = prof_slot("msm_reduce");
+  static const int slot_digits = prof_slot("msm_digits"), slot_scan = prof_slot("msm_part_scan"), slot_scatter = prof_slot("msm_scatter"),
+                   slot_bucket = prof_slot("msm_bucket"), slot_sort = prof_slot("msm_sort"), slot_acc = prof_slot("msm_accumulate"),
+                   slot_heavy = prof_slot("msm_accumulate_heavy"), slot_red = prof_slot("msm_reduce");
 
+  // "msm_sort" spans the whole partition after the digits (scan + scatter + bucket + size order), as it did for the library sort
   prof_begin(slot_digits, st);
-  hipLaunchKernelGGL(msm_digits_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, base_offset,
-                     d_density, d_dprefix, G, w_lo, w_hi, keys_a, vals_a);
+  {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t grid = P.n_st < (uint32_t)cus ? P.n_st : (uint32_t)cus;  // one 1024-lane workgroup per CU (LDS histogram)
+    hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(grid), dim3(PART_THREADS), (size_t)ncell * 4, st, d_scalars, n, d_density, G, w_lo, w_hi,
+                       scalars_mont ? 1 : 0, P, keys, tile_hist);
+  }
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
   if (checkpoint("digits")) return ZK_ERR_DEVICE;
 
   prof_begin(slot_sort, st);
-  ZK_HIP(rocprim::radix_sort_pairs((void*)(ws + o_sort), sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, G.c, st));
-  hipLaunchKernelGGL(msm_bounds_kernel, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, st, keys_b, m, G.c, G.nb, first, last);
+  prof_begin(slot_scan, st);
+  hipLaunchKernelGGL(msm_colsum_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, P, ncell, csum);
+  hipLaunchKernelGGL(msm_binscan_kernel, dim3(1), dim3(PART_THREADS), 0, st, csum, P, ncell, G.nb, bin_start, out_start);
+  hipLaunchKernelGGL(msm_tileoff_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, csum, P, ncell, tile_off);
   ZK_HIP(hipGetLastError());
+  prof_end(slot_scan, st);
+  prof_begin(slot_scatter, st);
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)(((P.nbin + 3u) & ~3u) + 32) * 4 + (size_t)P.st * 8, st, keys, n,
+                     base_offset, d_density, d_dprefix, G.nb, WL, P, tile_off, pairs);
+  ZK_HIP(hipGetLastError());
+  prof_end(slot_scatter, st);
+  if (checkpoint("scatter")) return ZK_ERR_DEVICE;
+  prof_begin(slot_bucket, st);
+  {
+    const uint32_t nfl = (1u << P.lo_bits) < 4 ? 4 : (1u << P.lo_bits);
+    const size_t fixed = (size_t)(2 * nfl + 32) * 4;
+    // staging for the expected bin population with slack, at most what the CU has
+    uint64_t want = (uint64_t)(n / P.nbin) * 5 / 4 + 3ull * nfl + 4096;
+    const uint64_t cap_max = (PART_LDS_MAX - fixed) / 4;
+    if (want > cap_max) want = cap_max;
+    if (want > (uint64_t)PART_EC * PART_THREADS + 3ull * nfl) want = (uint64_t)PART_EC * PART_THREADS + 3ull * nfl;
+    const uint32_t stage_cap = (uint32_t)want & ~3u;
+    hipLaunchKernelGGL(msm_bucket_kernel, dim3(ncell), dim3(PART_THREADS), fixed + (size_t)stage_cap * 4, st, pairs, bin_start, out_start, G.nb, P,
+                       stage_cap, first, last, vals_b);
+  }
+  ZK_HIP(hipGetLastError());
+  prof_end(slot_bucket, st);
+  if (checkpoint("bucket")) return ZK_ERR_DEVICE;
   msm_order_by_size(first, last, n_buckets, size_hist, order, sizes_b, st);
   ZK_HIP(hipGetLastError());
   prof_end(slot_sort, st);
-  if (checkpoint("sort+bounds")) return ZK_ERR_DEVICE;
+  if (checkpoint("partition")) return ZK_ERR_DEVICE;
 
   auto run_set = [&](const Affine<F>* bases_set, Jacobian<F>* result, bool last_set) -> int {
     {

@@ -13,6 +13,7 @@ SO_PATH = os.path.join(_HERE, "libmi355zk.so")
 
 OK, ERR_UNEXPECTED_IDENTITY, ERR_UNEXPECTED_EOF, ERR_BAD_ARGS, ERR_DEVICE = 0, 1, 2, 3, -1
 OP_FFT, OP_IFFT, OP_COSET_FFT, OP_ICOSET_FFT = 0, 1, 2, 3
+MSM_SCALARS_MONTGOMERY = 1
 
 _vp, _sz, _i, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
 _u64p, _u32p, _u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
@@ -28,6 +29,8 @@ SIGNATURES = {
     "mi355zk_bn254_g2_msm_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g1_msm_part_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _vp, _vp]),
     "mi355zk_bn254_g2_msm_part_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _vp, _vp]),
+    "mi355zk_bn254_g1_msm_ex_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _u32, _vp, _vp]),
+    "mi355zk_bn254_g2_msm_ex_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _u32, _vp, _vp]),
     "mi355zk_bn254_g1_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g2_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g1_merge_pairs_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
@@ -46,6 +49,9 @@ SIGNATURES = {
     "mi355zk_bn254_fr_domain_constants": (_i, [_u32, _vp, _vp, _vp, _vp]),
     "mi355zk_bn254_fr_mul_assign_dev": (_i, [_vp, _vp, _sz, _vp]),
     "mi355zk_bn254_fr_sub_assign_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_fr_into_repr_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_fr_divide_by_z_on_coset_dev": (_i, [_vp, _u32, _vp]),
+    "mi355zk_bn254_fr_domain_z": (_i, [_u32, _vp, _vp]),
     "mi355zk_ubench_fp_mul": (_i, [_i, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_float)]),
     "mi355zk_selftest_u_mul": (_i, [_i, _vp, _vp, _vp]),
     "mi355zk_selftest_u_sub": (_i, [_i, _i, _i, _vp, _vp, _vp]),

@@ -229,3 +229,114 @@ def test_eval_qap_polynomials_like_mpc_parameters_new(zk, worker):
         e = rowsum(O.G1, radix["alpha_coeffs_g1"], bt, v, e)
         e = rowsum(O.G1, radix["coeffs_g1"], ct, v, e)
         assert np.array_equal(_host(ext)[v], O.G1.to_affine(e))
+
+
+@pytest.mark.parametrize("power", [10, 12])
+def test_config1_new_constrained_challenge_hash(zk, worker, power):
+    """BASELINE config 1, `new`: ceremony.new_accumulator (generate_initial, batched_accumulator.rs:1295-1347) serialised by the
+    HIP encoders in the layout of batched_accumulator.rs:87-178 must hash (BLAKE2b-512, utils.rs:20-27) to the value the
+    reference's layout fixes (tests/test_challenge_hash.py holds the same constants for the oracle's encoder)."""
+    import torch
+
+    from test_challenge_hash import CHALLENGE
+
+    acc = zk.ceremony.new_accumulator(power, torch.device("cuda", 0))
+    blob = zk.ceremony.write_accumulator(acc, compressed=False)
+    size, digest = CHALLENGE[power]
+    assert blob.numel() == size
+    assert zk.ceremony.calculate_hash(blob).hex() == digest
+    back = zk.ceremony.read_accumulator(blob, power, compressed=False)    # what compute_constrained reads
+    assert all(torch.equal(back[k], acc[k]) for k in acc)
+
+
+def test_config1_compute_constrained_power12(zk, worker):
+    """BASELINE config 1, `compute` at REQUIRED_POWER = 12 (8191 TauG1 + 4096 x (TauG2, AlphaG1, BetaG1) + BetaG2) with a fixed
+    key injected instead of OsRng (compute_constrained.rs:41-80): challenge file -> read_accumulator -> contribute_accumulator
+    (batched_accumulator.rs:1119-1292) -> compressed response body.  EVERY element of every vector is checked against the closed
+    form the relations of verify_transform (batched_accumulator.rs:182-272) imply -- tau_g1[i] = tau^i G, tau_g2[i] = tau^i G2,
+    alpha_g1[i] = alpha tau^i G, beta_g1[i] = beta tau^i G, beta_g2 = beta G2 -- computed by the oracle's mul_assign; the
+    response round-trips through the compressed codec and carries the challenge's hash (:1284-1290 writes it first)."""
+    import torch
+
+    power = 12
+    n, n1 = 1 << power, (2 << power) - 1
+    r = M.R_ORDER
+    dev = torch.device("cuda", 0)
+    challenge = zk.ceremony.write_accumulator(zk.ceremony.new_accumulator(power, dev), compressed=False)
+    challenge_hash = zk.ceremony.calculate_hash(challenge)
+    acc = zk.ceremony.read_accumulator(challenge, power, compressed=False)
+    tau = 0x1F0E2D3C4B5A69788796A5B4C3D2E1F00112233445566778899AABBCCDDEEFF % r
+    alpha = 0x2B7E151628AED2A6ABF7158809CF4F3C762E7160F38B4DA56A784D9045190CFE % r
+    beta = 0x243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89 % r
+    out = zk.ceremony.contribute_accumulator(acc, tau, alpha, beta)
+    out["hash"] = torch.frombuffer(bytearray(challenge_hash), dtype=torch.uint8).to(dev)
+    tp = [1] * n1
+    for i in range(1, n1):
+        tp[i] = tp[i - 1] * tau % r
+    limbs = lambda ks: np.array([M.to_limbs(k % r) for k in ks], dtype=np.uint64)  # noqa: E731
+    assert np.array_equal(_host(out["tau_g1"]), O.G1.mul_many_affine(inputs.G1_GEN_RAW, limbs(tp)))
+    assert np.array_equal(_host(out["tau_g2"]), O.G2.mul_many_affine(inputs.G2_GEN_RAW, limbs(tp[:n])))
+    assert np.array_equal(_host(out["alpha_g1"]), O.G1.mul_many_affine(inputs.G1_GEN_RAW, limbs([alpha * t for t in tp[:n]])))
+    assert np.array_equal(_host(out["beta_g1"]), O.G1.mul_many_affine(inputs.G1_GEN_RAW, limbs([beta * t for t in tp[:n]])))
+    assert np.array_equal(_host(out["beta_g2"]), O.G2.mul_many_affine(inputs.G2_GEN_RAW, limbs([beta])))
+    response = zk.ceremony.write_accumulator(out, compressed=True)
+    _, body = zk.ceremony.accumulator_layout(power, compressed=True)
+    assert response.numel() == body == 787_296 - (3 * 128 + 6 * 64)       # contribution_size - public_key_size, parameters.rs:97-107
+    assert bytes(response[:64].cpu().numpy()) == challenge_hash
+    back = zk.ceremony.read_accumulator(response, power, compressed=True)
+    assert all(torch.equal(back[k], out[k]) for k in ("tau_g1", "tau_g2", "alpha_g1", "beta_g1", "beta_g2"))
+    # the oracle's encoder agrees byte for byte on a sample of the response
+    off_tau2 = [o for name, _, _, o in zk.ceremony.accumulator_layout(power, True)[0] if name == "tau_g2"][0]
+    sample = response[off_tau2:off_tau2 + 64 * 64].cpu().numpy()
+    assert np.array_equal(sample, O.encode_points(2, _host(out["tau_g2"])[:64], True).reshape(-1))
+
+
+@pytest.mark.parametrize("group,log_n", [(1, 20), (2, 16)])
+def test_config5_contribute_at_size(zk, worker, group, log_n):
+    """BASELINE config 5: the device work of MPCParameters::contribute (phase2/src/parameters.rs:414-522) at |L| = 2^20,
+    |H| = 2^20 - 1 G1 points (and the same kernel family over G2 at 2^16): every point times delta^-1 by `batch_exp`, affine out.
+    Checks: (1) >= 1024 random indices of L' and H' against the oracle's mul_assign + into_affine, bit exact;
+    (2) the statement verify_contribution checks with a pairing (merge_pairs + same_ratio against (delta_g2_after, delta_g2_before),
+    parameters.rs:1038-1075 / utils.rs:59-105), here with the known delta:  sum rho_i L[i] == delta * sum rho_i L'[i];
+    (3) an infinity record passes through as infinity."""
+    import ctypes as C
+
+    import torch
+
+    import bench
+
+    G = O.G1 if group == 1 else O.G2
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW)
+    dev = torch.device("cuda", 0)
+    L = zk.lib.load()
+    r = M.R_ORDER
+
+    def synth(n, seed):
+        k = bench.gen_scalars(n, seed, dev)
+        p = torch.empty((n, 8 * group), dtype=torch.int64, device=dev)
+        fn = L.mi355zk_bn254_g1_batch_mul_dev if group == 1 else L.mi355zk_bn254_g2_batch_mul_dev
+        assert fn(C.c_void_p(p.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+        return p
+
+    n_l, n_h = 1 << log_n, (1 << log_n) - 1
+    l_before, h_before = synth(n_l, 2001), synth(n_h, 2002)
+    l_before[12345 % n_l] = 0                                              # an infinity entry stays infinity
+    delta = 0x0123456789ABCDEF0FEDCBA9876543210123456789ABCDEF02468ACE13579B % r
+    delta_inv = _limbs(pow(delta, -1, r))
+    d_inv = _dev(delta_inv.reshape(1, 4))
+    l_after = zk.ceremony.batch_exp(l_before, d_inv, same_scalar=True)
+    h_after = zk.ceremony.batch_exp(h_before, d_inv, same_scalar=True)
+    rng = np.random.default_rng(2003)
+    for before, after, n in ((l_before, l_after, n_l), (h_before, h_after, n_h)):
+        idx = np.unique(np.concatenate([[0, 1, n - 2, n - 1, 12345 % n], rng.integers(0, n, size=1100)]))
+        t_idx = torch.from_numpy(idx).to(dev)
+        hb, ha = _host(before[t_idx]), _host(after[t_idx])
+        assert len(idx) >= 1024
+        for j in range(len(idx)):
+            want = G.to_affine(G.mul(G.from_affine(hb[j]), delta_inv)) if hb[j].any() else np.zeros(8 * group, np.uint64)
+            assert np.array_equal(ha[j], want), int(idx[j])
+    assert not _host(l_after[12345 % n_l]).any()
+    for before, after, n, seed in ((l_before, l_after, n_l, 2004), (h_before, h_after, n_h, 2005)):
+        rho = bench.gen_scalars(n, seed, dev)
+        s, sx = zk.ceremony.merge_pairs(before, after, rho)
+        assert np.array_equal(G.to_affine(s), G.to_affine(G.mul(sx, _limbs(delta))))

@@ -129,12 +129,16 @@ def test_skewed_scalars_one_heavy_bucket(zk, worker):
 
 
 def test_deterministic_run_twice(zk, worker):
+    """The group element is reproducible; its Jacobian representative need not be (the order inside a bucket comes from LDS
+    atomics in the partition kernels, and include/mi355zk.h allows any representative: projective equality is by value,
+    ec.rs:45-85)."""
     n = 50000
     bases = inputs.bases_progression_cpu(1, n, seed=51)
     scalars = inputs.random_scalars(n, seed=52)
     a = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
     b = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
-    assert np.array_equal(a, b)
+    assert np.array_equal(O.G1.to_affine(a), O.G1.to_affine(b))
+    assert O.G1.eq(a, b)
 
 
 def _dev_inputs(zk, log_n, seed):
@@ -453,3 +457,125 @@ def test_window_group_partials_add_up(zk, worker, group, log_n):
         dm = zk.DensityTracker.from_bools(bits)
         parts = [zk.multiexp(worker, (bases, 3), dm, scalars, window_group=(4, w)).wait() for w in range(4)]
         assert rc == 0 and np.array_equal(G.to_affine(zk.shard.join_partials(np.stack(parts))), G.to_affine(want_d))
+
+
+def _to_int(a):
+    return sum(a[:, i].astype(object) << (64 * i) for i in range(4))
+
+
+def test_config2_density_tracker_at_2e20(zk, worker):
+    """BASELINE config 2's DensityTracker variant at its stated size: 2^20 exponents, ~50 % density, a non-zero source
+    offset, compacted bases k_j*G resident in HBM, a prover-like sprinkle of 0 / 1 scalars.
+      - closed form at the full size: sum over the selected i of s_i * k_rank(i) (source.rs:101-118 defines rank)
+      - the 2^14-exponent prefix (same map, same bases) against the CPU oracle, bit exact
+      - additivity: MSM(s) == MSM(a) + MSM(s - a) under the same map."""
+    import torch
+
+    import bench
+    import bn254_model as M
+
+    log_n, off = 20, 7
+    n = 1 << log_n
+    rng = np.random.default_rng(2101)
+    bits = rng.random(n) < 0.5
+    used = int(bits.sum())
+    dev = torch.device("cuda", 0)
+    k = bench.gen_scalars(used + off, 2102, dev)
+    bases = torch.empty((used + off, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    assert zk.lib.load().mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()),
+                                                       used + off, None) == 0
+    hs = inputs.random_scalars(n, seed=2103)
+    kind = rng.integers(0, 10, size=n)
+    hs[kind == 0] = 0
+    hs[kind == 1] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    scalars = torch.from_numpy(hs.view(np.int64)).to(dev)
+    dm = zk.DensityTracker.from_bools(bits)
+    total = zk.multiexp(worker, (bases, off), dm, scalars).wait()
+    hk = _to_int(k.cpu().numpy().view(np.uint64))[off:]
+    sel = _to_int(hs)[bits]
+    dot = int(sum(int(a) * int(b) for a, b in zip(sel, hk)) % M.R_ORDER)
+    want = O.G1.mul(O.G1.from_affine(inputs.G1_GEN_RAW), M.to_limbs(dot))
+    assert np.array_equal(O.G1.to_affine(total), O.G1.to_affine(want))
+    m = 1 << 14
+    hb = bases.cpu().numpy().view(np.uint64)
+    rc, ref = O.G1.multiexp(hb, hs[:m], density=GU.density_words(bits[:m]), density_bits=m, base_offset=off, threads=8)
+    got = zk.multiexp(worker, (bases, off), zk.DensityTracker.from_bools(bits[:m]), scalars[:m]).wait()
+    assert rc == 0 and np.array_equal(O.G1.to_affine(got), O.G1.to_affine(ref))
+    a = bench.gen_scalars(n, 2104, dev)
+    b = scalars.clone()
+    assert zk.lib.load().mi355zk_bn254_fr_sub_assign_dev(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, None) == 0
+    torch.cuda.synchronize()
+    pa = zk.multiexp(worker, (bases, off), dm, a).wait()
+    pb = zk.multiexp(worker, (bases, off), dm, b).wait()
+    assert np.array_equal(O.G1.to_affine(zk.shard.join_partials(np.stack([pa, pb]))), O.G1.to_affine(total))
+    # one base too few: UnexpectedEof at the exponent that owns the missing base (source.rs:46-48)
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (bases[:used + off - 1], off), dm, scalars).wait()
+    assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == int(np.nonzero(bits)[0][-1])
+
+
+def test_g2_msm_at_2e20_closed_form(zk, worker):
+    """2^20-point G2 multiexp (prover.rs:297-298's B_G2 at BASELINE config 5's size), bases k_i*G2 resident in HBM:
+    closed form (sum s_i k_i) * G2, additivity over point ranges through the source offset, and the 2^12 prefix against the oracle."""
+    import torch
+
+    import bench
+    import bn254_model as M
+
+    log_n = 20
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    scalars = bench.gen_scalars(n, 2201, dev)
+    k = bench.gen_scalars(n, 2202, dev)
+    bases = torch.empty((n, 16), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G2_GEN_RAW)
+    assert zk.lib.load().mi355zk_bn254_g2_batch_mul_dev(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+    total = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    hs, hk = scalars.cpu().numpy().view(np.uint64), k.cpu().numpy().view(np.uint64)
+    dot = int(sum(int(a) * int(b) for a, b in zip(_to_int(hs), _to_int(hk))) % M.R_ORDER)
+    want = O.G2.mul(O.G2.from_affine(inputs.G2_GEN_RAW), M.to_limbs(dot))
+    assert np.array_equal(O.G2.to_affine(total), O.G2.to_affine(want))
+    h = n // 2 + 12345
+    lo = zk.multiexp(worker, (bases[:h], 0), zk.FullDensity(), scalars[:h]).wait()
+    hi = zk.multiexp(worker, (bases, h), zk.FullDensity(), scalars[h:]).wait()
+    assert np.array_equal(O.G2.to_affine(zk.shard.join_partials(np.stack([lo, hi]))), O.G2.to_affine(total))
+    m = 1 << 12
+    rc, ref = O.G2.multiexp(bases[:m].cpu().numpy().view(np.uint64), hs[:m], threads=8)
+    got = zk.multiexp(worker, (bases[:m], 0), zk.FullDensity(), scalars[:m]).wait()
+    assert rc == 0 and np.array_equal(O.G2.to_affine(got), O.G2.to_affine(ref))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_montgomery_scalars_fused_into_repr(zk, worker, group):
+    """the prover holds Montgomery-form Fr (`Vec<Scalar<E>>`) and converts with into_repr() before every
+    multiexp (prover.rs:89-129).  MI355ZK_MSM_SCALARS_MONTGOMERY fuses that pass into the digit extraction: same result as
+    the canonical call and as the oracle; mi355zk_bn254_fr_into_repr_dev is the standalone pass.  Includes 0, 1, r - 1 and a
+    density map."""
+    import torch
+
+    import bn254_model as M
+
+    G = O.G1 if group == 1 else O.G2
+    n = 5000 if group == 1 else 700
+    bases = inputs.bases_progression_cpu(group, n, seed=2300 + group)
+    canon = inputs.random_scalars(n, seed=2301)
+    canon[0] = 0
+    canon[1] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    canon[2] = np.array(M.to_limbs(M.R_ORDER - 1), dtype=np.uint64)
+    r2 = np.array(M.to_limbs(pow(2, 512, M.R_ORDER)), dtype=np.uint64)
+    mont = O.fe_mul_many(O.FR, canon, np.tile(r2, (n, 1))).reshape(n, 4)       # from_repr: c * R mod r
+    d_bases = torch.from_numpy(bases.view(np.int64)).cuda()
+    d_mont = torch.from_numpy(mont.view(np.int64)).cuda()
+    rng = np.random.default_rng(2302)
+    bits = rng.random(n) < 0.6
+    for dm, dens in ((zk.FullDensity(), None), (zk.DensityTracker.from_bools(bits), bits)):
+        rc, want = G.multiexp(bases, canon, density=None if dens is None else GU.density_words(dens), density_bits=None if dens is None else n,
+                              threads=8)
+        assert rc == 0
+        got = zk.multiexp(worker, (d_bases, 0), dm, d_mont, scalars_montgomery=True).wait()
+        assert np.array_equal(G.to_affine(got), G.to_affine(want))
+    out = torch.empty_like(d_mont)
+    assert zk.lib.load().mi355zk_bn254_fr_into_repr_dev(C.c_void_p(out.data_ptr()), C.c_void_p(d_mont.data_ptr()), n, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), canon)

@@ -74,3 +74,34 @@ def test_device_resident_roundtrips(zk, worker, log_n):
     if log_n == 20:
         want = O.fr_domain_op(host, log_n, "fft").reshape(-1, 4)
         assert np.array_equal(f_a.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("op", ["ifft", "coset_fft"])
+def test_2e24_three_pass_uneven_split_matches_oracle(zk, worker, op):
+    """2^24 elements (512 MiB): three passes with an uneven digit split, the fused scalings on the first / last pass; all
+    2^24 x 32 bytes against the oracle (its parallel_fft shape, asserted equal to serial_fft by domain.rs:465-496)."""
+    log_n = 24
+    a = inputs.random_fr_mont(1 << log_n, seed=400)
+    want = O.fr_domain_op(a, log_n, op, log_cpus=3).reshape(-1, 4)
+    dom = zk.EvaluationDomain.from_coeffs(a)
+    getattr(dom, op)(worker)
+    assert np.array_equal(dom.into_coeffs(), want)
+
+
+def test_divide_by_z_on_coset_and_z(zk, worker):
+    """domain.rs:207-234: z(tau) = tau^m - 1; divide_by_z_on_coset multiplies every coefficient by z(g)^-1, g = 7."""
+    import torch
+
+    import bn254_model as M
+
+    log_n = 12
+    a = inputs.random_fr_mont(1 << log_n, seed=500)
+    dom = zk.EvaluationDomain(torch.from_numpy(a.view(np.int64)).cuda(), log_n)
+    r = M.R_ORDER
+    tau = 0x123456789ABCDEF0123 % r
+    mont = lambda v: np.array(M.to_limbs(v * M.MONT_R % r), dtype=np.uint64)  # noqa: E731
+    assert np.array_equal(dom.z(mont(tau)), mont((pow(tau, 1 << log_n, r) - 1) % r))
+    dom.divide_by_z_on_coset(worker)
+    zinv = mont(pow((pow(7, 1 << log_n, r) - 1) % r, -1, r))
+    want = O.fe_mul_many(O.FR, a, np.tile(zinv, (1 << log_n, 1))).reshape(-1, 4)
+    assert np.array_equal(dom.coeffs.cpu().numpy().view(np.uint64), want)

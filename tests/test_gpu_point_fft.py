@@ -77,3 +77,15 @@ def test_g2_point_fft_roundtrip(zk, worker):
     lag = _run(zk, pts, log_n, 1, group=2)
     assert not np.array_equal(lag, pts)
     assert np.array_equal(_run(zk, lag, log_n, 0, group=2), pts)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_point_ifft_matches_oracle_at_2e12(zk, worker, group):
+    """prepare_phase2's Lagrange conversion at 2^12 points (the REQUIRED_POWER of BASELINE config 1), G1 and G2, every record
+    against the oracle's Point<G> FFT + batch_normalization; an infinity coefficient included."""
+    log_n = 12
+    pts = inputs.bases_progression_cpu(group, 1 << log_n, seed=90 + group)
+    pts[1234] = 0
+    want = O.point_domain_op(group, pts, log_n, "ifft")
+    got = _run(zk, pts, log_n, 1, group=group)
+    assert np.array_equal(got, want)
