@@ -226,7 +226,7 @@ constexpr uint32_t PART_MAX_ST = 16384;       // super-tile: scalars per pass-A 
 constexpr uint32_t PART_MAX_EB = PART_MAX_ST / PART_THREADS;
 constexpr uint32_t PART_LO_MAX = 12;          // at most 4096 buckets per coarse bin
 constexpr uint32_t PART_EC = 32;              // pass C: elements per lane held in registers
-constexpr uint32_t PART_LDS_A = 150 * 1024;   // pass A histogram budget
+constexpr uint32_t PART_LDS_A = 76 * 1024;    // pass A histogram budget (16-bit counters; two workgroups per CU)
 constexpr uint32_t PART_LDS_MAX = 160 * 1024 - 512;
 constexpr uint32_t KEY_NONE_MASK = 0x00ffffffu;  // key = bucket (or nb = none) in the low 24 bits | SIGN_BIT
 
@@ -286,13 +286,15 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t len, uint32_t* scra
 // scalars_into_representations, prover.rs:89-129): the conversion into_repr() is one Montgomery reduction, fused here.
 __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n,
                                                                        const uint32_t* __restrict__ density, MsmGeom G, uint32_t w_lo,
-                                                                       uint32_t w_hi, int scalars_mont, PartGeom P,
+                                                                       uint32_t w_hi, int scalars_mont, PartGeom P, uint64_t kstride,
                                                                        uint32_t* __restrict__ keys, uint16_t* __restrict__ tile_hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // counters are 16 bits wide (a super-tile has at most 16384 scalars), two per LDS word: half the LDS, two workgroups per CU,
+  // and the dump below is a plain copy (little endian: even cell = low half)
   uint32_t* lh = reinterpret_cast<uint32_t*>(smem);
-  const uint32_t WL = w_hi - w_lo, ncell = WL * P.nbin;
+  const uint32_t WL = w_hi - w_lo, ncell = WL * P.nbin, nword = (ncell + 1) / 2;
   for (uint32_t st = blockIdx.x; st < P.n_st; st += gridDim.x) {
-    for (uint32_t t = threadIdx.x; t < ncell; t += PART_THREADS) lh[t] = 0;
+    for (uint32_t t = threadIdx.x; t < nword; t += PART_THREADS) lh[t] = 0;
     __syncthreads();
     const uint64_t i_end = (uint64_t)(st + 1) * P.st < n ? (uint64_t)(st + 1) * P.st : n;
     for (uint64_t i = (uint64_t)st * P.st + threadIdx.x; i < i_end; i += PART_THREADS) {
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
       }
       const uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
       if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
-        for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * n + i] = G.nb;
+        for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * kstride + i] = G.nb;
         continue;
       }
       // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is
@@ -320,14 +322,18 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
       msm_scalar_digits(s, G, [&](uint32_t w, uint32_t d, uint32_t neg) {
         if (w >= w_lo && w < w_hi) {
           const uint32_t wl = w - w_lo;
-          keys[(uint64_t)wl * n + i] = d ? ((d - 1) | neg) : G.nb;
-          if (d) atomicAdd(&lh[wl * P.nbin + ((d - 1) >> P.lo_bits)], 1u);
+          keys[(uint64_t)wl * kstride + i] = d ? ((d - 1) | neg) : G.nb;
+          if (d) {
+            const uint32_t cell = wl * P.nbin + ((d - 1) >> P.lo_bits);
+            atomicAdd(&lh[cell >> 1], 1u << (16u * (cell & 1u)));
+          }
         }
       });
     }
     __syncthreads();
-    uint16_t* row = tile_hist + (uint64_t)st * ncell;
-    for (uint32_t t = threadIdx.x; t < ncell; t += PART_THREADS) row[t] = (uint16_t)lh[t];  // <= ST <= 16384
+    // rows are padded to an even cell count (ncell_pad) so that every row starts on a word
+    uint32_t* row = reinterpret_cast<uint32_t*>(tile_hist) + (uint64_t)st * nword;
+    for (uint32_t t = threadIdx.x; t < nword; t += PART_THREADS) row[t] = lh[t];
     __syncthreads();
   }
 }
@@ -337,28 +343,45 @@ __global__ void __launch_bounds__(256) msm_colsum_kernel(const uint16_t* __restr
                                                         uint32_t* __restrict__ csum) {
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
   if (col >= ncell) return;
+  const uint32_t stride = (ncell + 1u) & ~1u;
   const uint32_t r0 = chunk * P.rows_per_chunk, r1 = r0 + P.rows_per_chunk < P.n_st ? r0 + P.rows_per_chunk : P.n_st;
   uint32_t s = 0;
-  for (uint32_t r = r0; r < r1; ++r) s += tile_hist[(uint64_t)r * ncell + col];
+#pragma unroll 8
+  for (uint32_t r = r0; r < r1; ++r) s += tile_hist[(uint64_t)r * stride + col];
   csum[(uint64_t)chunk * ncell + col] = s;
 }
 
-// one workgroup: bin_start[col] = elements before (window, bin) `col` in the pair array, out_start[col] = first slot of
-// the bin's region in the index array (every bucket start is padded to a multiple of 4 entries: + up to 3 per bucket),
-// and csum[chunk][col] is replaced by the position at which the chunk's first row starts inside the bin.
-__global__ void __launch_bounds__(PART_THREADS) msm_binscan_kernel(uint32_t* __restrict__ csum, PartGeom P, uint32_t ncell, uint32_t nb,
+// per column: csum[chunk][col] -> exclusive prefix over the chunks, total[col] = the column sum (coalesced across columns)
+__global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__ csum, PartGeom P, uint32_t ncell, uint32_t* __restrict__ total) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncell) return;
+  uint32_t run = 0;
+  for (uint32_t ch = 0; ch < P.n_chunk; ++ch) {
+    const uint32_t v = csum[(uint64_t)ch * ncell + col];
+    csum[(uint64_t)ch * ncell + col] = run;
+    run += v;
+  }
+  total[col] = run;
+}
+
+// one workgroup: bin_start[col] = elements before (window, bin) `col` in the pair array (exclusive scan of total[]),
+// out_start[col] = first slot of the bin's region in the index array (every bucket start is padded to a multiple of 4
+// entries: + up to 3 per bucket).
+__global__ void __launch_bounds__(PART_THREADS) msm_binscan_kernel(const uint32_t* __restrict__ total, PartGeom P, uint32_t ncell, uint32_t nb,
                                                                    uint32_t* __restrict__ bin_start, uint32_t* __restrict__ out_start) {
   __shared__ uint32_t part[PART_THREADS], part_out[PART_THREADS];
   const uint32_t per = (ncell + PART_THREADS - 1) / PART_THREADS;
   const uint32_t c0 = threadIdx.x * per, c1 = c0 + per < ncell ? c0 + per : ncell;
+  auto padded = [&](uint32_t col, uint32_t tot) {
+    const uint32_t bin = col % P.nbin;
+    const uint32_t nf = ((bin + 1) << P.lo_bits) <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
+    return (tot + 3u * nf + 3u) & ~3u;
+  };
   uint32_t sum = 0, sum_out = 0;
   for (uint32_t col = c0; col < c1; ++col) {
-    uint32_t tot = 0;
-    for (uint32_t ch = 0; ch < P.n_chunk; ++ch) tot += csum[(uint64_t)ch * ncell + col];
-    const uint32_t bin = col % P.nbin;
-    const uint32_t nf = (bin + 1) << P.lo_bits <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
+    const uint32_t tot = total[col];
     sum += tot;
-    sum_out += (tot + 3u * nf + 3u) & ~3u;
+    sum_out += padded(col, tot);
   }
   part[threadIdx.x] = sum;
   part_out[threadIdx.x] = sum_out;
@@ -366,7 +389,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_binscan_kernel(uint32_t* __r
   if (threadIdx.x == 0) {
     uint32_t run = 0, run_out = 0;
     for (uint32_t t = 0; t < PART_THREADS; ++t) {
-      uint32_t v = part[t], vo = part_out[t];
+      const uint32_t v = part[t], vo = part_out[t];
       part[t] = run;
       part_out[t] = run_out;
       run += v;
@@ -378,31 +401,27 @@ __global__ void __launch_bounds__(PART_THREADS) msm_binscan_kernel(uint32_t* __r
   __syncthreads();
   uint32_t run = part[threadIdx.x], run_out = part_out[threadIdx.x];
   for (uint32_t col = c0; col < c1; ++col) {
+    const uint32_t tot = total[col];
     bin_start[col] = run;
     out_start[col] = run_out;
-    uint32_t tot = 0;
-    for (uint32_t ch = 0; ch < P.n_chunk; ++ch) {
-      const uint32_t v = csum[(uint64_t)ch * ncell + col];
-      csum[(uint64_t)ch * ncell + col] = run + tot;
-      tot += v;
-    }
-    const uint32_t bin = col % P.nbin;
-    const uint32_t nf = (bin + 1) << P.lo_bits <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
     run += tot;
-    run_out += (tot + 3u * nf + 3u) & ~3u;
+    run_out += padded(col, tot);
   }
 }
 
 // tile_off[row][col] = position in the pair array at which super-tile `row` writes its run of (window, bin) `col`
-__global__ void __launch_bounds__(256) msm_tileoff_kernel(const uint16_t* __restrict__ tile_hist, const uint32_t* __restrict__ cbase, PartGeom P,
-                                                         uint32_t ncell, uint32_t* __restrict__ tile_off) {
+__global__ void __launch_bounds__(256) msm_tileoff_kernel(const uint16_t* __restrict__ tile_hist, const uint32_t* __restrict__ cbase,
+                                                         const uint32_t* __restrict__ bin_start, PartGeom P, uint32_t ncell,
+                                                         uint32_t* __restrict__ tile_off) {
   const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
   if (col >= ncell) return;
+  const uint32_t stride = (ncell + 1u) & ~1u;
   const uint32_t r0 = chunk * P.rows_per_chunk, r1 = r0 + P.rows_per_chunk < P.n_st ? r0 + P.rows_per_chunk : P.n_st;
-  uint32_t run = cbase[(uint64_t)chunk * ncell + col];
+  uint32_t run = bin_start[col] + cbase[(uint64_t)chunk * ncell + col];
+#pragma unroll 8
   for (uint32_t r = r0; r < r1; ++r) {
     tile_off[(uint64_t)r * ncell + col] = run;
-    run += tile_hist[(uint64_t)r * ncell + col];
+    run += tile_hist[(uint64_t)r * stride + col];
   }
 }
 
@@ -410,55 +429,90 @@ __global__ void __launch_bounds__(256) msm_tileoff_kernel(const uint16_t* __rest
 // reordered by bin in LDS and written out as one contiguous run per bin at tile_off[st][wl][bin].  The pair carries the
 // key (bucket | sign) and the BASE index of the exponent: base_offset + i under FullDensity, base_offset + rank(i) for a
 // density map (source.rs:101-118: rank(i) = dprefix[i/32] + popc(density[i/32] & ((1 << i%32) - 1))).
-__global__ void __launch_bounds__(PART_THREADS) msm_scatter_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint64_t base_offset,
+__global__ void __launch_bounds__(PART_THREADS) msm_scatter_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint64_t kstride, uint64_t base_offset,
                                                                    const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
-                                                                   uint32_t nb, uint32_t WL, PartGeom P, const uint32_t* __restrict__ tile_off,
-                                                                   uint2* __restrict__ pairs) {
+                                                                   uint32_t nb, uint32_t WL, PartGeom P, uint32_t xcds,
+                                                                   const uint32_t* __restrict__ tile_off, uint2* __restrict__ pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t nbin4 = (P.nbin + 3u) & ~3u;
   uint32_t* loff = reinterpret_cast<uint32_t*>(smem);             // nbin: counts, then exclusive offsets inside the tile
-  uint32_t* scratch = loff + ((P.nbin + 3u) & ~3u);               // 32 words
+  uint32_t* delta = loff + nbin4;                                 // nbin: tile_off[bin] - loff[bin] (mod 2^32)
+  uint32_t* scratch = delta + nbin4;                              // 32 words
   uint2* staging = reinterpret_cast<uint2*>(scratch + 32);        // st pairs
-  const uint32_t st = blockIdx.x % P.n_st, wl = blockIdx.x / P.n_st;
+  // Workgroups are dealt to the XCDs round-robin by block id; runs of one bin written by CONSECUTIVE super-tiles are adjacent
+  // in memory, so consecutive super-tiles are given to the same XCD (block id b -> XCD b % xcds takes a contiguous range of
+  // super-tiles) and their partial lines merge in that XCD's L2 instead of leaving it one by one.
+  uint32_t st, wl;
+  {
+    const uint32_t per = P.n_st / xcds;  // super-tiles per XCD in the remapped part
+    const uint32_t body = per * xcds;    // the first `body` super-tiles are remapped, the remainder keeps the plain order
+    const uint32_t b = blockIdx.x;
+    if (per != 0 && b < body * WL) {
+      const uint32_t x = b % xcds, j = b / xcds;
+      st = x * per + j % per;
+      wl = j / per;
+    } else {
+      const uint32_t r = b - body * WL, rem = P.n_st - body;
+      st = body + r % rem;
+      wl = r / rem;
+    }
+  }
   const uint64_t i0 = (uint64_t)st * P.st;
   const uint32_t cnt = (uint32_t)(n - i0 < P.st ? n - i0 : P.st);
   for (uint32_t t = threadIdx.x; t < P.nbin; t += PART_THREADS) loff[t] = 0;
   __syncthreads();
+  // lane t holds keys 4 * (k * 1024 + t) .. + 3: one 16-byte load (the key planes are kstride = 4 * ceil(n / 4) apart, tiles are
+  // multiples of 1024: every tile starts on 16 bytes)
   uint32_t key[PART_MAX_EB], rank[PART_MAX_EB];
-  const uint32_t* kp = keys + (uint64_t)wl * n + i0;
+  const uint32_t* kp = keys + (uint64_t)wl * kstride + i0;
+  const bool wide = true;
 #pragma unroll
-  for (uint32_t k = 0; k < PART_MAX_EB; ++k) {
-    const uint32_t idx = k * PART_THREADS + threadIdx.x;
-    key[k] = nb;
-    rank[k] = 0;
-    if (idx < cnt) {
-      key[k] = kp[idx];
-      const uint32_t b = key[k] & KEY_NONE_MASK;
-      if (b < nb) rank[k] = atomicAdd(&loff[b >> P.lo_bits], 1u);
+  for (uint32_t k4 = 0; k4 < PART_MAX_EB / 4; ++k4) {
+    const uint32_t idx = 4u * (k4 * PART_THREADS + threadIdx.x);
+    uint32_t v[4] = {nb, nb, nb, nb};
+    if (wide && idx + 4 <= cnt) {
+      const uint4 q = *reinterpret_cast<const uint4*>(kp + idx);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e)
+        if (idx + e < cnt) v[e] = kp[idx + e];
     }
-  }
-  __syncthreads();
-  const uint32_t total = block_scan_1024(P.nbin, scratch, [&](uint32_t x) { return loff[x]; }, [&](uint32_t x, uint32_t ex) { loff[x] = ex; });
-  __syncthreads();
 #pragma unroll
-  for (uint32_t k = 0; k < PART_MAX_EB; ++k) {
-    const uint32_t idx = k * PART_THREADS + threadIdx.x;
-    const uint32_t b = key[k] & KEY_NONE_MASK;
-    if (idx < cnt && b < nb) {
-      const uint64_t i = i0 + idx;
-      uint64_t bi = base_offset + i;
-      if (density != nullptr) {
-        const uint32_t wd = density[i >> 5];
-        bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
-      }
-      staging[loff[b >> P.lo_bits] + rank[k]] = make_uint2(key[k], (uint32_t)bi);
+    for (uint32_t e = 0; e < 4; ++e) {
+      key[4 * k4 + e] = v[e];
+      rank[4 * k4 + e] = 0;
+      const uint32_t b = v[e] & KEY_NONE_MASK;
+      if (b < nb) rank[4 * k4 + e] = atomicAdd(&loff[b >> P.lo_bits], 1u);
     }
   }
   __syncthreads();
   const uint32_t* toff = tile_off + ((uint64_t)st * WL + wl) * P.nbin;
+  const uint32_t total = block_scan_1024(P.nbin, scratch, [&](uint32_t x) { return loff[x]; },
+                                         [&](uint32_t x, uint32_t ex) { loff[x] = ex; delta[x] = toff[x] - ex; });
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k4 = 0; k4 < PART_MAX_EB / 4; ++k4) {
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      const uint32_t k = 4 * k4 + e;
+      const uint32_t idx = 4u * (k4 * PART_THREADS + threadIdx.x) + e;
+      const uint32_t b = key[k] & KEY_NONE_MASK;
+      if (idx < cnt && b < nb) {
+        const uint64_t i = i0 + idx;
+        uint64_t bi = base_offset + i;
+        if (density != nullptr) {
+          const uint32_t wd = density[i >> 5];
+          bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
+        }
+        staging[loff[b >> P.lo_bits] + rank[k]] = make_uint2(key[k], (uint32_t)bi);
+      }
+    }
+  }
+  __syncthreads();
   for (uint32_t p = threadIdx.x; p < total; p += PART_THREADS) {
     const uint2 e = staging[p];
-    const uint32_t bin = (e.x & KEY_NONE_MASK) >> P.lo_bits;
-    pairs[(uint64_t)toff[bin] + (p - loff[bin])] = e;
+    pairs[(uint64_t)(p + delta[(e.x & KEY_NONE_MASK) >> P.lo_bits])] = e;
   }
 }
 
@@ -550,7 +604,8 @@ inline PartGeom choose_part(uint64_t n, uint32_t WL, uint32_t nb) {
   while ((1u << lo_cap) < nb && lo_cap < PART_LO_MAX) ++lo_cap;  // one bin holds everything, or 2^PART_LO_MAX buckets
   auto nbin_of = [&](uint32_t lo) { return (uint32_t)(((uint64_t)nb + (1ull << lo) - 1) >> lo); };
   // as fine as the pass-A histogram (WL * nbin words of LDS) allows, but no finer than ~8192 elements per bin need
-  auto fits = [&](uint32_t lo) { return (uint64_t)WL * nbin_of(lo) * 4 <= PART_LDS_A && nbin_of(lo) <= 4 * PART_THREADS; };
+  // pass A keeps WL * nbin 16-bit counters in LDS (two workgroups per CU); pass B scans nbin words with 1024 lanes x 4
+  auto fits = [&](uint32_t lo) { return (uint64_t)WL * nbin_of(lo) * 2 <= PART_LDS_A && nbin_of(lo) <= 4 * PART_THREADS; };
   uint32_t lo = lo_cap;
   const uint64_t pop_target = 12288;
   while (lo > 0 && (uint64_t)n * (1ull << lo) / nb > pop_target && fits(lo - 1)) --lo;
@@ -568,8 +623,8 @@ inline PartGeom choose_part(uint64_t n, uint32_t WL, uint32_t nb) {
     if (v >= (int)PART_THREADS && v <= (int)PART_MAX_ST && v % (int)PART_THREADS == 0) st = (uint32_t)v;
   }
   // pass B holds the tile (8 B per element) and nbin words in LDS
-  while (st > PART_THREADS && (uint64_t)st * 8 + (uint64_t)P.nbin * 4 + 256 > PART_LDS_MAX) st -= PART_THREADS;
-  if ((uint64_t)st * 8 + (uint64_t)P.nbin * 4 + 256 > PART_LDS_MAX) st = 0;  // cannot happen: nbin <= 4096
+  while (st > PART_THREADS && (uint64_t)st * 8 + (uint64_t)P.nbin * 8 + 256 > PART_LDS_MAX) st -= PART_THREADS;
+  if ((uint64_t)st * 8 + (uint64_t)P.nbin * 8 + 256 > PART_LDS_MAX) st = 0;  // cannot happen: nbin <= 4096
   P.st = st;
   P.n_st = (uint32_t)((n + st - 1) / st);
   P.rows_per_chunk = P.n_st > 64 ? (P.n_st + 63) / 64 : 1;
@@ -1093,6 +1148,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   while ((1u << final_bits) <= final_cnt - 1 + final_off) ++final_bits;
 
   const PartGeom P = choose_part(n, WL, G.nb);
+  const uint64_t kstride = (n + 3) & ~3ull;  // distance between the key planes of two windows
   if (P.st == 0) return ZK_ERR_BAD_ARGS;
   const uint32_t ncell = WL * P.nbin;
   // index lists: every bucket start is padded to a multiple of 4 entries (<= 3 per bucket), every bin region to 4
@@ -1103,8 +1159,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   // the window-major keys of pass A are dead once pass B has run; pass C writes the index lists over them
   size_t o_keys = take((size_t)vals_cap * 4), o_pairs = take((size_t)m * 8);
-  size_t o_tile_hist = take((size_t)P.n_st * ncell * 2), o_tile_off = take((size_t)P.n_st * ncell * 4);
-  size_t o_csum = take((size_t)P.n_chunk * ncell * 4), o_bin_start = take((size_t)(ncell + 1) * 4), o_out_start = take((size_t)(ncell + 1) * 4);
+  size_t o_tile_hist = take((size_t)P.n_st * ((ncell + 1) & ~1u) * 2), o_tile_off = take((size_t)P.n_st * ncell * 4);
+  size_t o_csum = take((size_t)P.n_chunk * ncell * 4), o_total = take((size_t)ncell * 4);
+  size_t o_bin_start = take((size_t)(ncell + 1) * 4), o_out_start = take((size_t)(ncell + 1) * 4);
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
   size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
   // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
@@ -1139,6 +1196,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint16_t* tile_hist = (uint16_t*)(ws + o_tile_hist);
   uint32_t* tile_off = (uint32_t*)(ws + o_tile_off);
   uint32_t* csum = (uint32_t*)(ws + o_csum);
+  uint32_t* col_total = (uint32_t*)(ws + o_total);
   uint32_t* bin_start = (uint32_t*)(ws + o_bin_start);
   uint32_t* out_start = (uint32_t*)(ws + o_out_start);
   uint32_t* first = (uint32_t*)(ws + o_first);
@@ -1175,9 +1233,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t grid = P.n_st < (uint32_t)cus ? P.n_st : (uint32_t)cus;  // one 1024-lane workgroup per CU (LDS histogram)
-    hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(grid), dim3(PART_THREADS), (size_t)ncell * 4, st, d_scalars, n, d_density, G, w_lo, w_hi,
-                       scalars_mont ? 1 : 0, P, keys, tile_hist);
+    const uint32_t grid = P.n_st < 2u * (uint32_t)cus ? P.n_st : 2u * (uint32_t)cus;  // two 1024-lane workgroups per CU (LDS histograms)
+    hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_scalars, n, d_density, G, w_lo,
+                       w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist);
   }
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
@@ -1186,13 +1244,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   prof_begin(slot_sort, st);
   prof_begin(slot_scan, st);
   hipLaunchKernelGGL(msm_colsum_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, P, ncell, csum);
-  hipLaunchKernelGGL(msm_binscan_kernel, dim3(1), dim3(PART_THREADS), 0, st, csum, P, ncell, G.nb, bin_start, out_start);
-  hipLaunchKernelGGL(msm_tileoff_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, csum, P, ncell, tile_off);
+  hipLaunchKernelGGL(msm_colscan_kernel, dim3((ncell + 255) / 256), dim3(256), 0, st, csum, P, ncell, col_total);
+  hipLaunchKernelGGL(msm_binscan_kernel, dim3(1), dim3(PART_THREADS), 0, st, col_total, P, ncell, G.nb, bin_start, out_start);
+  hipLaunchKernelGGL(msm_tileoff_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, csum, bin_start, P, ncell, tile_off);
   ZK_HIP(hipGetLastError());
   prof_end(slot_scan, st);
   prof_begin(slot_scatter, st);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)(((P.nbin + 3u) & ~3u) + 32) * 4 + (size_t)P.st * 8, st, keys, n,
-                     base_offset, d_density, d_dprefix, G.nb, WL, P, tile_off, pairs);
+  {
+    static const char* env_x = std::getenv("MI355ZK_PART_XCDS");  // 1 disables the XCD-aware tile order
+    const uint32_t xcds = env_x && std::atoi(env_x) >= 1 ? (uint32_t)std::atoi(env_x) : 8u;
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)(2 * ((P.nbin + 3u) & ~3u) + 32) * 4 + (size_t)P.st * 8, st,
+                       keys, n, kstride, base_offset, d_density, d_dprefix, G.nb, WL, P, xcds, tile_off, pairs);
+  }
   ZK_HIP(hipGetLastError());
   prof_end(slot_scatter, st);
   if (checkpoint("scatter")) return ZK_ERR_DEVICE;
