@@ -713,7 +713,11 @@ inline void msm_order_by_size(const uint32_t* first, const uint32_t* last, uint3
 
 constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take the segment-parallel path (the rest of a pathological input runs one lane per bucket)
 
-template <class F>
+// A4: the index list starts on a multiple of 4 entries, is walked with stride 1 and its padding slots are readable (the
+// lists the partition writes): a lane reads its indices FOUR AT A TIME with one 16-byte load, one group ahead.  Read one by
+// one, a lane touches each 128-byte line of its list 32 times, ~10^4 instructions apart, and by then the line has usually
+// left the caches (64 lanes x 16 waves x 32 CUs share an L2 that 52 GB of bases stream through): 8 touches instead of 32.
+template <class F, bool A4 = false>
 __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
                                                   uint32_t stride, bool skip_zero, unsigned long long* __restrict__ err_base) {
   // the all-zero record is the point at infinity (no curve point has y == 0).  skip_zero (dense mode, powersoftau's
@@ -725,14 +729,32 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
     // The gather of point k+1 is issued, as four back-to-back 16-byte loads, before the ~2200 ALU instructions of
     // addition k: the four loads of a record then hit the same 128-byte line while it is still in cache (left to the
     // scheduler they drift apart to their uses and the line is fetched more than once: +22 % HBM traffic).
-    uint32_t v = vals[j];
+    uint4 q = make_uint4(0, 0, 0, 0), qn = q;  // A4: this group of four indices (rotated so that q.x is the current one), the next group
+    uint32_t v;
+    if constexpr (A4) {
+      q = *reinterpret_cast<const uint4*>(vals + j);
+      qn = q;
+      if (j + 4 < e) qn = *reinterpret_cast<const uint4*>(vals + j + 4);
+      v = q.x;
+    } else {
+      v = vals[j];
+    }
     Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
     for (;;) {
       const uint32_t jn = j + stride;
       const bool more = jn < e;
       uint32_t vn = 0;
       Affine<F> pn = p;
-      if (more) {
+      if constexpr (A4) {
+        if ((jn & 3u) == 0) {  // uniform over the wave: every lane started on a multiple of 4
+          q = qn;
+          if (jn + 4 < e) qn = *reinterpret_cast<const uint4*>(vals + jn + 4);
+        } else {
+          q.x = q.y; q.y = q.z; q.z = q.w;
+        }
+        vn = q.x;
+        if (more) pn = load_affine(bases + (vn & ~SIGN_BIT));
+      } else if (more) {
         vn = vals[jn];
         pn = load_affine(bases + (vn & ~SIGN_BIT));
       }
@@ -863,7 +885,7 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __
 
 // 4b. one lane per bucket, buckets taken in size order.  Both groups run on U-form arithmetic (curveu.hpp:
 //     29-bit lazy limbs, one v_mad_u64_u32 per partial product, no carry flags).
-template <class F>
+template <class F, bool A4>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                             const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
@@ -873,7 +895,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
   if (i < hb && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
-  store_vec(buckets + b, accumulate_run<F>(bases, vals, j, e, 1, skip_zero != 0, err_base));
+  store_vec(buckets + b, accumulate_run<F, A4>(bases, vals, j, e, 1, skip_zero != 0, err_base));
 }
 
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
@@ -1294,8 +1316,13 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       ZK_HIP(hipGetLastError());
       prof_end(slot_heavy, st);
       prof_begin(slot_acc, st);
-      hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order, heavy,
-                         hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+      static const bool a4 = std::getenv("MI355ZK_ACC_NARROW") == nullptr;  // (the 4-byte index walk, kept for the traffic comparison in profiles/)
+      if (a4)
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order,
+                           heavy, hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+      else
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order,
+                           heavy, hb, n_buckets, buckets, dense ? 1 : 0, d_err);
       ZK_HIP(hipGetLastError());
     }
     prof_end(slot_acc, st);
@@ -1479,7 +1506,7 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
                      vals, first, last, order, item_off, hb, seg_sums, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, hb,
                      buckets);
-  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
+  hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
                      n_rows, buckets, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_to_affine_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, buckets, d_out, n_rows);
   ZK_HIP(hipGetLastError());
