@@ -56,6 +56,17 @@ def gen_scalars(n: int, seed: int, device) -> torch.Tensor:
     return (lo | (hi << 32)).contiguous()
 
 
+def kernel_sources_sha() -> str:
+    """hash of the sources the dominant kernel is compiled from: ties a committed PMC figure to the code it was measured on"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("msm_impl.hpp", "curveu.hpp", "fieldu.hpp", "msm_g1.hip"):
+        with open(os.path.join(ROOT, "phase2-bn254_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +75,9 @@ def main() -> int:
     ap.add_argument("--log-n", type=int, default=26)
     ap.add_argument("--cpu-sample-log-n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bases", choices=["random", "tau"], default="random",
+                    help="random: P_i = k_i*G with independent k_i;  tau: the tau-table structure P_i = tau^i*G of the real workload (SURVEY 8d)")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra timing that includes the scalars' host-to-device copy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,23 +128,30 @@ def main() -> int:
     bases = torch.empty((n_local, 8), dtype=torch.int64, device=dev)
     gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
     t_gen = time.time()
+    R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    TAU = 0x2545F4914F6CDD1D9E3779B97F4A7C15F39CC0605CEDC8341082276BF3A27251 % R_ORDER
     for s in range(shards_local):
         gs = first_shard + s
         scalars[s * shard:(s + 1) * shard] = gen_scalars(shard, 1_000_003 * gs + 17, dev)
-        k = gen_scalars(shard, 2_000_003 * gs + 29, dev)
+        if args.bases == "tau":   # P_i = tau^i * G for the GLOBAL index i (identical input for every N)
+            k = zk.ceremony.scalar_powers(TAU, shard, dev, coeff=pow(TAU, gs * shard, R_ORDER))
+        else:
+            k = gen_scalars(shard, 2_000_003 * gs + 29, dev)
         rc = L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases[s * shard:(s + 1) * shard].data_ptr()), gen.ctypes.data_as(C.c_void_p),
                                               C.c_void_p(k.data_ptr()), shard, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
         torch.cuda.synchronize()
         del k
     t_gen = time.time() - t_gen
+    lo_global = pgroup * n_local  # global index of this rank's first exponent
 
-    def step() -> np.ndarray:
-        part = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars, window_group=(wgroups, wgroup)).wait()  # (12,) u64 Jacobian partial
+    def step(sc=None) -> np.ndarray:
+        fut = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars if sc is None else sc, window_group=(wgroups, wgroup))
         if world == 1:
-            return part
-        # the path's one exchange step: all-gather of the 96-byte partials, then local EC adds
-        return zk.shard.allgather_join(part, device=dev if backend == "nccl" else None)
+            return fut.wait()  # (12,) u64 Jacobian
+        # the path's one exchange step: all-gather of the 96-byte partials (+ rc and error index, so that a failing rank
+        # cannot leave the others in the collective), then local EC adds
+        return zk.shard.exchange(fut, 12, index_offset=lo_global, device=dev if backend == "nccl" else None)
 
     for _ in range(args.warmup):
         step()
@@ -168,6 +189,17 @@ def main() -> int:
     # (over ALL windows of the local points: the partial over a window group is not linear in the exponents, the carries of
     # the signed digits cross windows)
     whole = result if world == 1 else zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    sharded_ok = True
+    if world > 1:
+        # the TIMED, sharded `result` itself (window-group partials -> all-gather -> join) against the unsharded evaluation:
+        # one rank of every point range contributes `whole` (all windows of its points), the others the identity
+        contrib = np.ascontiguousarray(whole) if wgroup == 0 else np.zeros(12, dtype=np.uint64)
+        ref_total = zk.shard.allgather_join(contrib, device=dev if backend == "nccl" else None)
+        ra, rb = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        L.mi355zk_bn254_g1_to_affine(ra.ctypes.data_as(C.c_void_p), np.ascontiguousarray(ref_total).ctypes.data_as(C.c_void_p))
+        L.mi355zk_bn254_g1_to_affine(rb.ctypes.data_as(C.c_void_p), np.ascontiguousarray(result).ctypes.data_as(C.c_void_p))
+        sharded_ok = bool(np.array_equal(ra, rb))
+        assert sharded_ok, "the sharded result differs from the unsharded evaluation"
     part_a = zk.multiexp(worker, (bases, 0), zk.FullDensity(), sa).wait()
     part_b = zk.multiexp(worker, (bases, 0), zk.FullDensity(), sb).wait()
     del sa, sb
@@ -185,16 +217,44 @@ def main() -> int:
         L.mi355zk_prof_get(name.encode(), C.byref(ms), C.byref(cnt))
         kern[name] = (ms.value / cnt.value) if cnt.value else None
 
-    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc pass (counters cannot be
-    # read from inside this process); the committed figure is reported when it was taken on this workload.
+    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc pass (counters cannot be read from inside
+    # this process): the committed figure is reported only when it was taken on this workload AND on these kernel sources
+    # (profiles/latest_pmc.json records their hash) -- otherwise null, never a stale number.
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
             pmc = json.load(f)
-        if pmc.get("workload_log_n") == log_n and pmc.get("n_gpus") == world:
+        if pmc.get("workload_log_n") == log_n and pmc.get("n_gpus") == world and pmc.get("kernel_sources_sha") == kernel_sources_sha():
             traffic = pmc["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
+
+    # ---- the same step with the scalars' host-to-device copy inside the timed region (SURVEY 8d defines the metric with "H2D of
+    # scalars included"; `value` keeps inputs resident as the bench contract asks): pinned host buffer -> HBM -> multiexp
+    h2d = None
+    if not args.no_h2d_leg:
+        host_sc = torch.empty(scalars.shape, dtype=scalars.dtype, pin_memory=True)
+        host_sc.copy_(scalars)
+        stage = torch.empty_like(scalars)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        reps = min(3, args.steps)
+        for _ in range(reps):
+            stage.copy_(host_sc, non_blocking=True)
+            r2 = step(stage)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = (time.perf_counter() - t1) / reps
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        h2d = {"value_incl_scalar_h2d": round(n_total / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
+               "note": "scalars copied from a pinned host buffer on every step (not overlapped), bases resident"}
+        del host_sc, stage
 
     out = None
     if rank == 0:
@@ -223,7 +283,8 @@ def main() -> int:
             "dtype": "u32x8 (256-bit Montgomery limbs)",
             "data": "synthetic (bases k_i*G generated on device, scalars uniform < r)",
             "config": {"workload": "2^%d-point BN254 G1 Pippenger MSM, FullDensity, bases+scalars resident in HBM" % log_n,
-                       "points_per_gpu": n_local, "window_bits": c_bits, "windows": nw.value,
+                       "bases": "k_i*G, independent k_i" if args.bases == "random" else "tau^i*G (tau-table structure)",
+                       "points_per_gpu": n_local, "bases_bytes_per_gpu": n_local * 64, "window_bits": c_bits, "windows": nw.value,
                        "parallelism": "%d point range(s) x %d window group(s), all-gather of 96-B partials" % (pgroups, wgroups)},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6) if achieved else None,
@@ -237,6 +298,8 @@ def main() -> int:
                                                "MSM is integer-ALU bound (SURVEY 8d), the multiplier instructions alone are this fraction of the measured v_mad_u64_u32 peak"}},
             "result_affine_x_limb0": hex(int(aff[0])),
             "full_size_linearity_check": additive_ok,
+            "sharded_result_matches_unsharded": sharded_ok if world > 1 else None,
+            "incl_scalar_h2d": h2d,
             "input_gen_s": round(t_gen, 2),
         }
 
@@ -258,7 +321,8 @@ def main() -> int:
         # parity of the GPU path on the same sample (affine-normalised, bit exact)
         got = zk.multiexp(worker, (bases[:ns], 0), zk.FullDensity(), scalars[:ns]).wait()
         ok = bool(np.array_equal(O.G1.to_affine(got), O.G1.to_affine(ref)))
-        out["cpu_baseline"] = {"value": round(ns / dt / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": round(ns / dt / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "threads": threads, "host_cores": cores,
+                               "kind": "port",
                                "sample": "first 2^%d points of the same input, oracle restatement of bellman_ce multiexp "
                                          "(c=%d, one thread per window, %d windows), %.2f s" % (int(np.log2(ns)), c_ref, windows, dt),
                                "gpu_matches_oracle_on_sample": ok}

@@ -62,12 +62,58 @@ def join_partials(partials: np.ndarray) -> np.ndarray:
     return acc
 
 
+_RC = {"UnexpectedIdentity": 1, "IoError(UnexpectedEof)": 2}
+
+
+def exchange(fut, limbs: int, index_offset: int = 0, device=None, group=None) -> np.ndarray:
+    """The exchange step WITH the error path: `fut` is this rank's ready future (bellman.multiexp(...)) of a `limbs`-word
+    Jacobian partial (12 for G1, 24 for G2).  Every rank contributes (partial, rc, GLOBAL exponent index = local index +
+    index_offset); after the all-gather every rank either returns the same total or raises the SAME SynthesisError -- the one
+    at the lowest exponent index, Eof before identity at one index, which is what the unsharded call reports
+    (oracle/tmpl_multiexp.h).  Without this a failing rank would raise before the collective and leave the others blocked in it,
+    and a window-group partial alone is not a complete identity check (a base is only looked at by the groups whose windows hold
+    a non-zero digit of its exponent: the minimum over the groups is)."""
+    import torch
+    import torch.distributed as dist
+
+    from .bellman import SynthesisError
+
+    rec = np.zeros(limbs + 2, dtype=np.uint64)
+    local_exc = None
+    try:
+        rec[:limbs] = np.ascontiguousarray(fut.wait(), dtype=np.uint64)
+    except SynthesisError as e:
+        rec[limbs] = _RC[e.kind]
+        rec[limbs + 1] = np.uint64(max(e.index, 0) + index_offset)
+    except Exception as e:  # noqa: BLE001  (device failure / bad arguments: every rank must still reach the collective)
+        rec[limbs] = 3
+        local_exc = e
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        allr = rec.reshape(1, -1)
+    else:
+        mine = torch.from_numpy(rec.view(np.int64))
+        if device is not None:
+            mine = mine.to(device)
+        gathered = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        allr = gathered.cpu().numpy().view(np.uint64).reshape(world, -1)
+    rcs = allr[:, limbs].astype(np.int64)
+    if (rcs == 3).any():
+        raise local_exc if local_exc is not None else RuntimeError("mi355zk: a peer rank failed inside its multiexp")
+    bad = [(int(allr[r, limbs + 1]), 0 if rcs[r] == 2 else 1) for r in range(world) if rcs[r] != 0]
+    if bad:
+        idx, kind = min(bad)
+        raise SynthesisError(SynthesisError.IO_UNEXPECTED_EOF if kind == 0 else SynthesisError.UNEXPECTED_IDENTITY, idx)
+    return join_partials(allr[:, :limbs])
+
+
 def allgather_join(partial: np.ndarray, device=None, group=None) -> np.ndarray:
     """The exchange step: every rank contributes its Jacobian partial, every rank gets the total."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return np.ascontiguousarray(partial, dtype=np.uint64)
     mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64))

@@ -45,6 +45,24 @@ def _worker(rank, world, port, group, n, with_density, q):
     assert rc == 0 and rc_full == 0
     total = zk.shard.allgather_join(part)
     ok = bool(np.array_equal(G.to_affine(total), G.to_affine(full)))
+    # the same through the exchange step with the error path; then rank 1 alone fails: BOTH ranks must raise the same error,
+    # carrying the GLOBAL exponent index (and nobody may be left waiting in the collective)
+    total2 = zk.shard.exchange(zk.bellman._Ready(part), 12 * group, index_offset=lo)
+    ok = ok and bool(np.array_equal(G.to_affine(total2), G.to_affine(full)))
+    fut = zk.bellman._Ready(part) if rank == 0 else zk.bellman._Ready(error=zk.SynthesisError(zk.SynthesisError.UNEXPECTED_IDENTITY, 5))
+    try:
+        zk.shard.exchange(fut, 12 * group, index_offset=lo)
+        ok = False
+    except zk.SynthesisError as e:
+        ok = ok and e.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.index == zk.shard.shard_range(n, world, 1)[0] + 5
+    # Eof on rank 0 at a LOWER global index than an identity on rank 1: Eof wins everywhere
+    fut = (zk.bellman._Ready(error=zk.SynthesisError(zk.SynthesisError.IO_UNEXPECTED_EOF, 2)) if rank == 0
+           else zk.bellman._Ready(error=zk.SynthesisError(zk.SynthesisError.UNEXPECTED_IDENTITY, 0)))
+    try:
+        zk.shard.exchange(fut, 12 * group, index_offset=lo)
+        ok = False
+    except zk.SynthesisError as e:
+        ok = ok and e.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.index == 2
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
