@@ -29,7 +29,8 @@
  *   0  ok
  *   1  UnexpectedIdentity: a selected base with a non-zero exponent is infinity   (source.rs:50-52)
  *   2  UnexpectedEof:      the bases ran out                                      (source.rs:46-48,62-64)
- *   3  bad arguments (NULL pointer, log_n > 28 = PolynomialDegreeTooLarge domain.rs:66-79, sizes >= 2^31)
+ *   3  bad arguments (NULL pointer, log_n > 28 = PolynomialDegreeTooLarge domain.rs:66-79, sizes >= 2^31, an exponent
+ *      >= 2^254, i.e. not a canonical FrRepr: mi355zk_last_error_index() names it)
  *  <0  device failure (details on stderr).  There is NO CPU fallback inside the library.
  * When both error kinds are present the one at the lowest exponent index is reported (the reference's
  * answer depends on thread scheduling there; see oracle/tmpl_multiexp.h).
@@ -179,12 +180,13 @@ int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const u
  * batch_normalization) as one CSR-matrix x point-vector product:
  *   out[r] = sum_{t = row_ptr[r]}^{row_ptr[r+1]-1} coeff[t] * bases[col[t]],  r < n_rows,  affine out (all-zero = infinity).
  * row_ptr: u32[n_rows + 1] (row_ptr[n_rows] == nnz), col: u32[nnz], coeff: nnz canonical FrRepr; all device pointers.
+ * The index arrays are validated on the device (col[t] < n_bases, row_ptr monotone from 0 to nnz): 3 = bad arguments otherwise.
  * `ext` of the reference (three products added) is one call on the concatenated term lists / bases.
  * Synchronises `stream` before returning. */
-int mi355zk_bn254_g1_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, const uint32_t *d_row_ptr, const uint32_t *d_col,
-                                       const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
-int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, const uint32_t *d_row_ptr, const uint32_t *d_col,
-                                       const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
+int mi355zk_bn254_g1_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, size_t n_bases, const uint32_t *d_row_ptr,
+                                       const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
+int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, size_t n_bases, const uint32_t *d_row_ptr,
+                                       const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
 
 /* ---- point codecs: the reference's wire encodings <-> raw affine records.
  * Replaces EncodedPoint::{into_affine, into_affine_unchecked, from_affine} for G1Uncompressed (64 B), G1Compressed

@@ -100,8 +100,16 @@ def eval_qap(bases, row_ptr, col, coeff):
 
     g = _group(bases)
     n_rows = row_ptr.shape[0] - 1
+    for name, t in (("row_ptr", row_ptr), ("col", col)):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous int32 tensor")   # (an int64 tensor would be read as pairs of int32)
+    if not (bases.is_contiguous() and coeff.is_contiguous()) or coeff.shape[0] != col.shape[0]:
+        raise ValueError("bases / coeff must be contiguous, one coefficient per term")
     out = torch.zeros((n_rows, 8 * g), dtype=bases.dtype, device=bases.device)
-    _check(_fn("sparse_matvec_dev", g)(_p(out), _p(bases), _p(row_ptr), _p(col), _p(coeff), n_rows, col.shape[0], _stream_ptr()), "eval_qap")
+    rc = _fn("sparse_matvec_dev", g)(_p(out), _p(bases), bases.shape[0], _p(row_ptr), _p(col), _p(coeff), n_rows, col.shape[0], _stream_ptr())
+    if rc == _lib.ERR_BAD_ARGS:
+        raise ValueError("eval_qap: a column index is out of range or row_ptr is not a CSR offset array")
+    _check(rc, "eval_qap")
     return out
 
 

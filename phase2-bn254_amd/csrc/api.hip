@@ -419,12 +419,18 @@ void exp_scratch_release_all() {
   g_exp_scratch.clear();
 }
 
+// The scratch (Z coordinates, window tables) is per (device, stream) and the two kernels of one call must reach the stream
+// back to back: several host threads may share a stream (the default one above all), and A.exp, B.exp, A.normalize would
+// let A normalise with B's Z.  Held while ENQUEUEING only; the stream orders the kernels.
+static std::mutex g_exp_launch_mu;
+
 template <class F>
 int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_scalars, int same_scalar, size_t n, void* stream,
               const uint32_t* d_base_index = nullptr) {
   if (!d_out || !d_bases || !d_scalars) return n ? ZK_ERR_BAD_ARGS : ZK_OK;
   if (n == 0) return ZK_OK;
   hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> launch_lk(g_exp_launch_mu);
   if constexpr (std::is_same<F, Fq>::value) {
     const bool windowed = !same_scalar;                     // per-point scalars: fixed windows (see batch_exp_win_kernel)
     const size_t chunk = n < ((size_t)1 << 18) ? n : ((size_t)1 << 18);
@@ -637,6 +643,7 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
     t_last_err_index = rank;
     return rc;
   }
+  if (rc == ZK_ERR_BAD_ARGS) t_last_err_index = err_index;  // a non-canonical exponent (>= 2^254): its index
   if (rc != ZK_OK) return rc;
   if (P.eof_index >= 0) { t_last_err_index = P.eof_index; return ZK_ERR_UNEXPECTED_EOF; }
   return ZK_OK;
@@ -694,13 +701,45 @@ int ntt_host(uint64_t* a, uint32_t log_n, int op, const uint64_t* omega) {
 using namespace zk;
 
 // out[r] = sum_{t in [row_ptr[r], row_ptr[r+1])} coeff[t] * bases[col[t]], affine (QAP evaluation, parameters.rs:225-294)
+// CSR sanity on the device: flag |= 1 if some col[t] >= n_bases, |= 2 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[n_rows] = nnz
+__global__ void __launch_bounds__(256) csr_check_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, uint64_t n_rows,
+                                                       uint64_t nnz, uint64_t n_bases, uint32_t* __restrict__ flag) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t bad = 0;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += stride)
+    if (col[t] >= n_bases) bad |= 1u;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rows; r += stride) {
+    const uint32_t v = row_ptr[r];
+    if ((r == 0 && v != 0) || (r == n_rows && v != nnz) || (r < n_rows && v > row_ptr[r + 1])) bad |= 2u;
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
 template <class F>
-static int sparse_matvec(void* d_out, const void* d_bases, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeffs, size_t n_rows,
-                         size_t nnz, void* stream, int group) {
+static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeffs,
+                         size_t n_rows, size_t nnz, void* stream, int group) {
   if (!d_out || !d_row_ptr || (nnz && (!d_bases || !d_col || !d_coeffs)) || n_rows >= (1ull << 31) || nnz >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   if (n_rows == 0) return ZK_OK;
   Affine<F>* d_terms = nullptr;
-  ZK_HIP(hipMalloc(&d_terms, (nnz ? nnz : 1) * sizeof(Affine<F>)));
+  ZK_HIP(hipMalloc(&d_terms, (nnz ? nnz : 1) * sizeof(Affine<F>) + 256));
+  {
+    // the ABI cannot trust the index arrays: an out-of-range column would be an out-of-bounds gather in batch_exp
+    uint32_t* d_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_terms) + (nnz ? nnz : 1) * sizeof(Affine<F>));
+    uint32_t h_flag = 0;
+    hipError_t e = hipMemsetAsync(d_flag, 0, 4, (hipStream_t)stream);
+    if (e == hipSuccess) {
+      const uint64_t work = nnz > n_rows + 1 ? nnz : n_rows + 1;
+      hipLaunchKernelGGL(csr_check_kernel, dim3((unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,
+                         d_row_ptr, d_col, (uint64_t)n_rows, (uint64_t)nnz, (uint64_t)n_bases, d_flag);
+      e = hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess || h_flag) {
+      (void)hipFree(d_terms);
+      if (e != hipSuccess) ZK_HIP(e);
+      return ZK_ERR_BAD_ARGS;
+    }
+  }
   int rc = batch_exp<F>(d_terms, d_bases, 0, d_coeffs, 0, nnz, stream, d_col);
   if (rc == ZK_OK)
     rc = group == 1 ? segsum_g1_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out)
@@ -899,13 +938,13 @@ int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affin
 int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[16], const void* d_scalars, size_t n, void* stream) {
   return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
 }
-int mi355zk_bn254_g1_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, const uint32_t* d_row_ptr, const uint32_t* d_col,
-                                       const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
-  return sparse_matvec<Fq>(d_out_affine, d_bases_affine, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1);
+int mi355zk_bn254_g1_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
+                                       const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
+  return sparse_matvec<Fq>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1);
 }
-int mi355zk_bn254_g2_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, const uint32_t* d_row_ptr, const uint32_t* d_col,
-                                       const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
-  return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
+int mi355zk_bn254_g2_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
+                                       const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
+  return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
 }
 
 int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {

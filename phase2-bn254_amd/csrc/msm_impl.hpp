@@ -287,7 +287,8 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t len, uint32_t* scra
 __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n,
                                                                        const uint32_t* __restrict__ density, MsmGeom G, uint32_t w_lo,
                                                                        uint32_t w_hi, int scalars_mont, PartGeom P, uint64_t kstride,
-                                                                       uint32_t* __restrict__ keys, uint16_t* __restrict__ tile_hist) {
+                                                                       uint32_t* __restrict__ keys, uint16_t* __restrict__ tile_hist,
+                                                                       unsigned long long* __restrict__ err_scalar) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // counters are 16 bits wide (a super-tile has at most 16384 scalars), two per LDS word: half the LDS, two workgroups per CU,
   // and the dump below is a plain copy (little endian: even cell = low half)
@@ -313,6 +314,12 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
         for (int l = 0; l < 8; ++l) s[l] = f.l[l];
       }
       const uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
+      if (active && (s[7] >> 30)) {
+        // not a canonical FrRepr (r < 2^254): its top digit would overflow the bucket field of the key.  Reported as bad
+        // arguments (the lowest such exponent index), the exponent is skipped.
+        atomicMin(err_scalar, (unsigned long long)i);
+        active = false;
+      }
       if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
         for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * kstride + i] = G.nb;
         continue;
@@ -1203,7 +1210,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   const uint32_t tree_cnt = n_levels ? lvl_chunks[0] : final_cnt;
   const uint64_t tree_tmp = (uint64_t)n_out * ((tree_cnt + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE);
   size_t o_sumtmp = take((size_t)WL * tree_tmp * 2 * sizeof(XYZZ<F>));
-  size_t o_err = take(8);
+  size_t o_err = take(16);  // [0] lowest identity base index, [1] lowest index of a non-canonical exponent
 
   int rc = part_configure(dev);
   if (rc) return rc;
@@ -1235,7 +1242,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   XYZZ<F>* sumtmp = (XYZZ<F>*)(ws + o_sumtmp);
   unsigned long long* d_err = (unsigned long long*)(ws + o_err);
 
-  ZK_HIP(hipMemsetAsync(d_err, 0xff, 8, st));
+  ZK_HIP(hipMemsetAsync(d_err, 0xff, 16, st));
   ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
 
   static const bool debug = std::getenv("MI355ZK_DEBUG") != nullptr;
@@ -1257,7 +1264,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t grid = P.n_st < 2u * (uint32_t)cus ? P.n_st : 2u * (uint32_t)cus;  // two 1024-lane workgroups per CU (LDS histograms)
     hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_scalars, n, d_density, G, w_lo,
-                       w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist);
+                       w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist, d_err + 1);
   }
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
@@ -1380,13 +1387,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     if (checkpoint("reduce")) return (int)ZK_ERR_DEVICE;
 
     std::vector<XYZZ<F>> h_wsums((size_t)WL * n_out);
-    unsigned long long h_err = 0;
+    unsigned long long h_errs[2] = {0, 0};
     ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)WL * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(h_errs, d_err, 16, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    const unsigned long long h_err = h_errs[0];
     // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
     // flight, prover.rs:250-298) start while this thread joins its partial sums
     if (last_set) lk.unlock();
+    if (h_errs[1] != ~0ull) {
+      *err_index_out = (long long)h_errs[1];
+      return ZK_ERR_BAD_ARGS;
+    }
     if (h_err != ~0ull) {
       *err_index_out = (long long)h_err;
       return ZK_ERR_UNEXPECTED_IDENTITY;

@@ -239,17 +239,40 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
   key.log_n = log_n;
   for (int i = 0; i < 8; ++i) key.w[i] = w.l[i];
   std::lock_guard<std::mutex> lk(g_mu);
+  // The cache is keyed on arbitrary roots (best_fft takes a caller-supplied omega): bounded, so that a caller cycling through
+  // roots cannot grow device memory without limit.  Dropping everything is safe once the device is idle.
+  if (g_tables.find(key) == g_tables.end() && g_tables.size() >= 64) {
+    ZK_HIP(hipDeviceSynchronize());
+    for (auto& kv : g_tables) {
+      (void)hipFree(kv.second.A);
+      (void)hipFree(kv.second.B);
+      for (auto* r : kv.second.roots) (void)hipFree(r);
+    }
+    g_tables.clear();
+  }
   PowTables& T = g_tables[key];
   bool built = false;
+  // on any failure the entry is removed again: a half-built entry (A set, B or a roots table missing) would be taken for
+  // complete by the next call
+  auto fail = [&](hipError_t e, const char* what) {
+    std::fprintf(stderr, "[mi355zk] NTT table build failed (%s): %s\n", what, hipGetErrorString(e));
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(T.A);
+    (void)hipFree(T.B);
+    for (auto* r : T.roots) (void)hipFree(r);
+    g_tables.erase(key);
+    return (int)ZK_ERR_DEVICE;
+  };
+  hipError_t e = hipSuccess;
   if (T.A == nullptr) {
     built = true;
     T.h = (log_n + 1) / 2;
     uint64_t nB = 1ull << T.h, nA = 1ull << (log_n - T.h);
-    ZK_HIP(hipMalloc(&T.A, nA * sizeof(UTab)));
-    ZK_HIP(hipMalloc(&T.B, nB * sizeof(UTab)));
+    if ((e = hipMalloc(&T.A, nA * sizeof(UTab))) != hipSuccess) return fail(e, "A");
+    if ((e = hipMalloc(&T.B, nB * sizeof(UTab))) != hipSuccess) return fail(e, "B");
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, st, T.A, w, nB, nA);
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, st, T.B, w, 1ull, nB);
-    ZK_HIP(hipGetLastError());
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
   }
   if (want_roots) {
     for (int p = 0; p < nb; ++p) {
@@ -257,12 +280,12 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
       if (b == 0 || T.roots[b] != nullptr) continue;
       built = true;
       uint64_t cnt = 1ull << (b - 1);
-      ZK_HIP(hipMalloc(&T.roots[b], cnt * sizeof(UTab)));
+      if ((e = hipMalloc(&T.roots[b], cnt * sizeof(UTab))) != hipSuccess) return fail(e, "roots");
       hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.roots[b], w, 1ull << (log_n - b), cnt);
-      ZK_HIP(hipGetLastError());
+      if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
     }
   }
-  if (built) ZK_HIP(hipStreamSynchronize(st));  // one-time: tables may be used from other streams later
+  if (built && (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");  // one-time: tables may be used from other streams later
   *out = &T;
   return 0;
 }
@@ -276,24 +299,30 @@ struct ScratchBuf {
 std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
 std::mutex g_run_mu;
 
-std::once_flag g_cfg_once;
-int g_cfg_rc = 0;
+std::mutex g_cfg_mu;
+std::map<int, int> g_cfg;  // device -> rc of its one-time kernel configuration
 
 }  // namespace
 
 // the tile kernel stages up to 4 x 1025 x 36 B = 144 KiB in dynamic LDS (gfx950: 160 KiB per CU)
 int ntt_configure() {
-  std::call_once(g_cfg_once, [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(ntt_pass_kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
-      g_cfg_rc = ZK_ERR_DEVICE;
-    }
-  });
-  return g_cfg_rc;
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_cfg_mu);  // the attribute is per device: once for every device this process drives
+  auto it = g_cfg.find(dev);
+  if (it != g_cfg.end()) return it->second;
+  int rc = ZK_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(ntt_pass_kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
+    rc = ZK_ERR_DEVICE;
+  }
+  g_cfg[dev] = rc;
+  return rc;
 }
 
 void ntt_release_all() {
+  std::lock_guard<std::mutex> lk2(g_run_mu);  // (same order as the run path: g_run_mu, then g_mu)
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_tables) {
     (void)hipSetDevice(kv.first.dev);
@@ -302,7 +331,6 @@ void ntt_release_all() {
     for (auto* r : kv.second.roots) (void)hipFree(r);
   }
   g_tables.clear();
-  std::lock_guard<std::mutex> lk2(g_run_mu);
   for (auto& kv : g_scratch) {
     (void)hipSetDevice(kv.first.first);
     (void)hipFree(kv.second.p);
@@ -331,6 +359,9 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
 
   int rc = ntt_configure();
   if (rc) return rc;
+  // held from the table lookup to the last launch: the table cache may be dropped (when full) only while nobody is between
+  // "got a table pointer" and "enqueued the kernels that read it"
+  std::lock_guard<std::mutex> run_lk(g_run_mu);
   PowTables* T = nullptr;
   rc = build_pow_tables(st, log_n, omega, true, b, R, &T);
   if (rc) return rc;
@@ -341,7 +372,6 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   const FrU post_cu = to_u261(post_c ? *post_c : Fr::one());
   static const int slot_pass = prof_slot("ntt_pass");
 
-  std::lock_guard<std::mutex> run_lk(g_run_mu);
   Fr* scratch = nullptr;
   if (R > 1) {
     int dev = 0;
@@ -441,6 +471,7 @@ int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st)
   const UTab* A = nullptr;
   const UTab* B = nullptr;
   uint32_t h = 0;
+  std::lock_guard<std::mutex> run_lk(g_run_mu);
   if (g != nullptr && log_n > 0) {
     PowTables* T = nullptr;
     int rc = build_pow_tables(st, log_n, *g, false, nullptr, 0, &T);

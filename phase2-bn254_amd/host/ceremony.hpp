@@ -57,7 +57,7 @@ template <> struct Abi<G1Affine> {
   static int batch_exp(void* o, const void* b, const void* s, size_t n, int same) { return mi355zk_bn254_g1_batch_exp_dev(o, b, s, n, same, nullptr); }
   static int dense(const void* b, const void* s, size_t n, uint64_t* out) { return mi355zk_bn254_g1_dense_multiexp_dev(b, s, n, nullptr, out); }
   static int merge(const void* a, const void* b, const void* r, size_t n, uint64_t* s, uint64_t* sx) { return mi355zk_bn254_g1_merge_pairs_dev(a, b, r, n, nullptr, s, sx); }
-  static int matvec(void* o, const void* b, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz) { return mi355zk_bn254_g1_sparse_matvec_dev(o, b, rp, c, k, rows, nnz, nullptr); }
+  static int matvec(void* o, const void* b, size_t nb, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz) { return mi355zk_bn254_g1_sparse_matvec_dev(o, b, nb, rp, c, k, rows, nnz, nullptr); }
   static int fft(void* p, uint32_t log_n, int inv) { return mi355zk_bn254_g1_point_fft_dev(p, log_n, inv, nullptr); }
   static int decode(void* o, const void* in, size_t n, int c, int chk, long long* idx) { return mi355zk_bn254_g1_decode_dev(o, in, n, c, chk, nullptr, idx); }
   static int encode(void* o, const void* in, size_t n, int c) { return mi355zk_bn254_g1_encode_dev(o, in, n, c, nullptr); }
@@ -67,7 +67,7 @@ template <> struct Abi<G2Affine> {
   static int batch_exp(void* o, const void* b, const void* s, size_t n, int same) { return mi355zk_bn254_g2_batch_exp_dev(o, b, s, n, same, nullptr); }
   static int dense(const void* b, const void* s, size_t n, uint64_t* out) { return mi355zk_bn254_g2_dense_multiexp_dev(b, s, n, nullptr, out); }
   static int merge(const void* a, const void* b, const void* r, size_t n, uint64_t* s, uint64_t* sx) { return mi355zk_bn254_g2_merge_pairs_dev(a, b, r, n, nullptr, s, sx); }
-  static int matvec(void* o, const void* b, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz) { return mi355zk_bn254_g2_sparse_matvec_dev(o, b, rp, c, k, rows, nnz, nullptr); }
+  static int matvec(void* o, const void* b, size_t nb, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz) { return mi355zk_bn254_g2_sparse_matvec_dev(o, b, nb, rp, c, k, rows, nnz, nullptr); }
   static int fft(void* p, uint32_t log_n, int inv) { return mi355zk_bn254_g2_point_fft_dev(p, log_n, inv, nullptr); }
   static int decode(void* o, const void* in, size_t n, int c, int chk, long long* idx) { return mi355zk_bn254_g2_decode_dev(o, in, n, c, chk, nullptr, idx); }
   static int encode(void* o, const void* in, size_t n, int c) { return mi355zk_bn254_g2_encode_dev(o, in, n, c, nullptr); }
@@ -125,7 +125,7 @@ std::vector<G> eval_qap(const std::vector<G>& bases, const std::vector<uint32_t>
   const size_t rows = row_ptr.size() - 1;
   detail::DeviceArray b(bases.data(), bases.size() * sizeof(G)), rp(row_ptr.data(), row_ptr.size() * 4), c(col.data(), col.size() * 4),
       k(coeff.data(), coeff.size() * 32), o(nullptr, rows * sizeof(G));
-  detail::check(detail::Abi<G>::matvec(o.get(), b.get(), (const uint32_t*)rp.get(), (const uint32_t*)c.get(), k.get(), rows, col.size()));
+  detail::check(detail::Abi<G>::matvec(o.get(), b.get(), bases.size(), (const uint32_t*)rp.get(), (const uint32_t*)c.get(), k.get(), rows, col.size()));
   std::vector<G> out(rows);
   o.download(out.data());
   return out;

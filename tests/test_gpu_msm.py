@@ -113,6 +113,18 @@ def test_identity_error_index_under_a_density_map(zk, worker, group):
     assert rc_o == 1
 
 
+def test_non_canonical_exponent_is_bad_arguments(zk, worker):
+    """An exponent >= 2^254 is not a FrRepr the reference could hand over (into_repr() < r); its top digit would overflow the
+    bucket field.  The library reports bad arguments and the exponent's index instead of corrupting another window."""
+    n = 3000
+    bases = inputs.bases_progression_cpu(1, n, seed=61)
+    scalars = inputs.random_scalars(n, seed=62)
+    scalars[1234, 3] |= np.uint64(1 << 62)
+    with pytest.raises(ValueError):
+        zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
+    assert zk.lib.load().mi355zk_last_error_index() == 1234
+
+
 def test_empty_input_is_identity(zk, worker):
     got = zk.multiexp(worker, (np.zeros((0, 8), np.uint64), 0), zk.FullDensity(), np.zeros((0, 4), np.uint64)).wait()
     assert not got[8:12].any()  # Z == 0
@@ -347,8 +359,15 @@ def test_sparse_matvec_qap_evaluation(zk, worker, group):
     d_bases, d_rp, d_col, d_cf = d(bases), d(row_ptr), d(col), d(coeff)
     d_out = torch.zeros((len(row_len), 8 * group), dtype=torch.int64, device="cuda")
     fn = zk.lib.load().mi355zk_bn254_g1_sparse_matvec_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_sparse_matvec_dev
-    assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_col.data_ptr()),
+    assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), nb, C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_col.data_ptr()),
               C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 0
+    # the index arrays are validated: one column beyond the bases, or a non-monotone row_ptr, is "bad arguments" (3), not a wild gather
+    assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), int(col.max()), C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_col.data_ptr()),
+              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 3
+    bad_rp = row_ptr.copy()
+    bad_rp[2], bad_rp[3] = bad_rp[3], bad_rp[2] - 1
+    assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), nb, C.c_void_p(d(bad_rp).data_ptr()), C.c_void_p(d_col.data_ptr()),
+              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 3
     got = d_out.cpu().numpy().view(np.uint64)
     for r in range(len(row_len)):
         acc = G.from_affine(np.zeros(G.aff, np.uint64))

@@ -43,7 +43,7 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     rp32 = rp.to(torch.int32); col = torch.randint(0, n, (nnz,), device=dev, generator=g_, dtype=torch.int32)
     cf = bench.gen_scalars(nnz, 61 + g, dev)
     smv = L.mi355zk_bn254_g1_sparse_matvec_dev if g == 1 else L.mi355zk_bn254_g2_sparse_matvec_dev
-    sargs = (C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(rp32.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(cf.data_ptr()), n, nnz, None)
+    sargs = (C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), n, C.c_void_p(rp32.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(cf.data_ptr()), n, nnz, None)
     assert smv(*sargs) == 0
     t = time.perf_counter()
     for _ in range(a.iters): assert smv(*sargs) == 0
