@@ -1,7 +1,8 @@
 """bench.py's N > 1 control flow on ONE GPU: N gloo ranks share the device (BENCH_BACKEND=gloo), every rank takes its
 (point range x window group) cell, the 96-byte partials go through the exchange step (shard.exchange: all-gather + error
 record + join).  The input is generated in seed-per-shard blocks, so the result must be the SAME group element for every N;
-bench.py itself checks the timed sharded result against the unsharded evaluation and full-size linearity."""
+bench.py itself checks the timed sharded result against the unsharded evaluation and full-size linearity.
+(2^21 points: the input is generated in 2^20-point shards, and N = 8 splits the points into two ranges.)"""
 import json
 import os
 import socket
@@ -21,7 +22,7 @@ def _free_port():
 
 
 def _run(n_ranks, bases):
-    args = ["bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--log-n", "20", "--no-cpu-baseline", "--no-h2d-leg", "--bases", bases]
+    args = ["bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--log-n", "21", "--no-cpu-baseline", "--no-h2d-leg", "--bases", bases]
     env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if n_ranks == 1:
         cmd = [sys.executable] + args
@@ -42,4 +43,4 @@ def test_bench_result_is_identical_for_every_rank_count(bases):
         got = _run(n, bases)
         assert got["n_gpus"] == n and got["full_size_linearity_check"] and got["sharded_result_matches_unsharded"]
         assert got["result_affine_x_limb0"] == ref["result_affine_x_limb0"], (n, bases)
-        assert got["config"]["bases_bytes_per_gpu"] * (n // min(n, 4)) == (1 << 20) * 64
+        assert got["config"]["bases_bytes_per_gpu"] * (n // min(n, 4)) == (1 << 21) * 64
