@@ -150,6 +150,13 @@ int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9
   }
   return ZK_OK;
 }
+// out_std = u_to_std_lt32p(in_u): canonical reduction of an N-form value < 32p without a product (the NTT's closing step)
+int mi355zk_selftest_u_reduce32(int which, const uint32_t in_u[9], uint64_t out_std[4]) {
+  if (!in_u || !out_std) return ZK_ERR_BAD_ARGS;
+  if (which == 0) { zk::FqU u; std::memcpy(&u, in_u, 36); zk::Fq x = zk::u_to_std_lt32p(u); std::memcpy(out_std, &x, 32); }
+  else { zk::FrU u; std::memcpy(&u, in_u, 36); zk::Fr x = zk::u_to_std_lt32p(u); std::memcpy(out_std, &x, 32); }
+  return ZK_OK;
+}
 // bucket accumulation of n signed affine G1 points on the HOST: mode 0 = saturated-limb XYZZ (curve.hpp),
 // mode 1 = U-form XYZZ (curveu.hpp).  out = memory-format XYZZ (X, Y, ZZ, ZZZ; 16 u64).
 int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const uint8_t* negate, size_t n, uint64_t out_xyzz[16]) {

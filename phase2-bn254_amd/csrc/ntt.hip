@@ -140,25 +140,43 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   }
   __syncthreads();
 
-  // DIT stages.  Entering stage s every element is < (4 + 2s) p with limbs < ((s & 3) + 1) * 2^29.
+  // DIT stages.  Entering stage s every element has limbs < ((s & 3) + 1) * 2^29 and is < (4 + 2s) p, or < 16p + 2(s - 3)p when
+  // the twiddle-one products of stages 1 and 2 are skipped (see j_slow).
   const uint32_t half = elems >> 1;
   for (uint32_t s = 0; s < P.log_np; ++s) {
     const uint32_t m = 1u << s;
     const bool carry_now = (s & 3) == 3;
+    // Stages 1 and 2 (when a row has at least 64 blocks of 2m): the butterflies of a row are dealt to the lanes with the
+    // twiddle index j SLOWEST (lane = j * blocks + block), so j is uniform over a wave and the waves with j == 0 -- twiddle
+    // one: 1/2 and 1/4 of the butterflies of these stages -- skip the product.  Later stages: j fastest (unit-stride LDS).
+    // Bounds: a skipped product leaves t as large as u, so values DOUBLE on that path: V_1 < 4p, V_2 < 8p, V_3 < 16p, and
+    // with + 2p for each of the stages 3..9: < 30p at the end (u_to_std_lt32p / the closing product allow < 32p); the
+    // subtraction constant follows (u_sub<4,1> / <8,1>).  Stage 3 is not skipped: it would take the bound past 32p.
+    const bool j_slow = (s == 1 || s == 2) && (np >> (s + 1)) >= 64;
     for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
       uint32_t g = b >> (P.log_np - 1);
       uint32_t bf = b & ((np >> 1) - 1);
-      uint32_t j = bf & (m - 1);
-      uint32_t x0 = ((bf >> s) << (s + 1)) + j;
+      uint32_t j, x0;
+      if (j_slow) {
+        const uint32_t blocks_log = P.log_np - 1 - s;                     // blocks of 2m per row
+        j = bf >> blocks_log;
+        x0 = ((bf & ((1u << blocks_log) - 1u)) << (s + 1)) + j;
+      } else {
+        j = bf & (m - 1);
+        x0 = ((bf >> s) << (s + 1)) + j;
+      }
       uint32_t i0 = g * pitch + swz(x0);
       uint32_t i1 = g * pitch + swz(x0 + m);
       FrU u = lds_load(lds, plane, i0);
       FrU t = lds_load(lds, plane, i1);
-      if (s != 0) t = u_mul(t, tab_load(roots + ((uint64_t)j << (P.log_np - 1 - s))));  // limbs < 4*2^29 times N: ok; < 2p, N
-      else t = u_carry(t);                                                // stage 0: w = 1; inputs are N already (no-op carry keeps the form explicit)
+      // (t < 24p with limbs < 4*2^29 either way: the skipped product only leaves t as large as u may be)
+      if (s != 0 && !(j_slow && j == 0)) t = u_mul(t, tab_load(roots + ((uint64_t)j << (P.log_np - 1 - s))));  // limbs < 4*2^29 times N: ok; < 2p, N
+      else t = u_carry(t);                                                // w = 1 (stage 0; j == 0): no product
       FrU sum = u_add(u, t);                                              // limbs grow by 2^29, value by 2p
       if (carry_now) sum = u_carry(sum);
-      FrU dif = u_sub<2, 1>(u, t);                                        // t < 2p N; u limbs < 4*2^29 < 2^32 - 2^30 - 16: ok.  N out
+      FrU dif;                                                            // t N; u limbs < 4*2^29 < 2^32 - 2^30 - 16: ok.  N out
+      if (j_slow && j == 0) dif = s == 1 ? u_sub<4, 1>(u, t) : u_sub<8, 1>(u, t);   // t < 4p (stage 1), < 8p (stage 2)
+      else dif = u_sub<2, 1>(u, t);                                       // t < 2p
       lds_store(lds, plane, i0, sum);
       lds_store(lds, plane, i1, dif);
     }
@@ -168,7 +186,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   // store: one more product brings the value below 2p (inter-pass twiddle, or the post scale / one on the last pass)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
     uint32_t g = e % P.g, k = e / P.g;
-    FrU v = lds_load(lds, plane, g * pitch + swz(k));                     // < 24p, limbs < 4*2^29
+    FrU v = lds_load(lds, plane, g * pitch + swz(k));                     // < 30p, limbs < 4*2^29
     const uint64_t go = out_base + k * P.out_xs + g * P.out_gs;
     FrU w;
     if (P.tw_mul != 0) {
@@ -177,10 +195,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     } else if (P.post == 2) {                                             // minv * ginv^k (icoset_fft, domain.rs:197-203)
       w = u_mul(tab_load(postA + (go >> P.post_h)), tab_load(postB + (go & ((1ull << P.post_h) - 1))));
       w = u_mul(w, post_c);
+    } else if (P.post == 3) {                                             // plain fft / coset_fft: nothing to multiply by --
+      gstore(out + go, u_to_std_lt32p(u_carry(v)));                       // reduce the < 24p value directly
+      continue;
     } else {
-      w = post_c;                                                         // one (fft / coset_fft) or minv (ifft, domain.rs:163-173)
+      w = post_c;                                                         // minv (ifft, domain.rs:163-173)
     }
-    gstore(out + go, u_to_std_lt2p(u_mul(v, w)));                          // 24 * 2 * 0.006 + 1 < 2p
+    gstore(out + go, u_to_std_lt2p(u_mul(v, w)));                          // 30 * 2 * 0.006 + 1 < 2p
   }
 }
 
@@ -447,7 +468,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       tiles = (N1 / G) * mid;
     }
     if (p == 0 && Tpre) { P.pre = 1; P.pre_h = Tpre->h; }
-    if (p == R - 1) { P.post = Tpost ? 2 : 1; P.post_h = Tpost ? Tpost->h : 0; }
+    if (p == R - 1) { P.post = Tpost ? 2 : (post_c ? 1 : 3); P.post_h = Tpost ? Tpost->h : 0; }
     uint32_t pitch = np >= 32 ? (uint32_t)np + 1 : (uint32_t)np;
     size_t lds_bytes = (size_t)P.g * pitch * 36;
     uint32_t threads = (uint32_t)((P.g * np) / 2);

@@ -104,6 +104,21 @@ def test_u_pack_roundtrip_and_canonical_reduce(lib, which, p):
         assert M.from_limbs(out) == v % p
 
 
+@pytest.mark.parametrize("which,p", MODS)
+def test_u_reduce_below_32p_without_a_product(lib, which, p):
+    """u_to_std_lt32p: the NTT's closing reduction (values < 30p after ten butterfly stages) by a quotient estimate from the top
+    limb, a limbwise v - q p and two conditional subtractions; every multiple of p up to 32p and its neighbours, and random values."""
+    cases = [0, 1, 32 * p - 1]
+    for k in range(1, 32):
+        cases += [k * p - 1, k * p, k * p + 1]
+    cases += [rnd.randrange(32 * p) for _ in range(3000)]
+    for v in cases:
+        u = _u32(limbs29(v))
+        out = np.zeros(4, np.uint64)
+        assert lib.mi355zk_selftest_u_reduce32(which, u.ctypes.data, out.ctypes.data) == 0
+        assert M.from_limbs(out) == v % p, v // p
+
+
 def _xyzz_to_affine(x):
     X, Y, ZZ, ZZZ = (M.from_mont(M.from_limbs(x[4 * i:4 * i + 4]), M.Q) for i in range(4))
     if ZZ == 0:
