@@ -232,28 +232,47 @@ def main() -> int:
     # ---- the same step with the scalars' host-to-device copy inside the timed region (SURVEY 8d defines the metric with "H2D of
     # scalars included"; `value` keeps inputs resident as the bench contract asks): pinned host buffer -> HBM -> multiexp
     h2d = None
-    if not args.no_h2d_leg:
+    if not args.no_h2d_leg and world == 1:
+        # the library's host-buffer entry point: the base vector is cached on the device after the first call (the CRS is reused
+        # by every proof), the scalars are streamed from (pageable) host memory in chunks overlapped with the kernels
+        hb = bases.cpu().numpy().view(np.uint64)
+        hs = scalars.cpu().numpy().view(np.uint64)
+        t1 = time.perf_counter()
+        r_first = zk.multiexp(worker, (hb, 0), zk.FullDensity(), hs).wait()
+        dt_first = time.perf_counter() - t1
+        reps = min(3, args.steps)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            r2 = zk.multiexp(worker, (hb, 0), zk.FullDensity(), hs).wait()
+        dt = (time.perf_counter() - t1) / reps
+        a1, a2 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        L.mi355zk_bn254_g1_to_affine(a1.ctypes.data_as(C.c_void_p), np.ascontiguousarray(r2).ctypes.data_as(C.c_void_p))
+        L.mi355zk_bn254_g1_to_affine(a2.ctypes.data_as(C.c_void_p), np.ascontiguousarray(result).ctypes.data_as(C.c_void_p))
+        h2d = {"value_incl_scalar_h2d": round(n_total / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
+               "first_call_incl_bases_h2d_ms": round(dt_first * 1e3, 3), "same_result": bool(np.array_equal(a1, a2)),
+               "note": "mi355zk_bn254_g1_msm (host buffers): bases cached on the device after the first call, scalars streamed from "
+                       "pageable host memory in chunks overlapped with the kernels; first call = bases + scalars over PCIe"}
+        L.mi355zk_bases_cache_invalidate(None)
+        del hb, hs, r_first
+    elif not args.no_h2d_leg:
         host_sc = torch.empty(scalars.shape, dtype=scalars.dtype, pin_memory=True)
         host_sc.copy_(scalars)
         stage = torch.empty_like(scalars)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         t1 = time.perf_counter()
         reps = min(3, args.steps)
         for _ in range(reps):
             stage.copy_(host_sc, non_blocking=True)
-            r2 = step(stage)
+            step(stage)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         dt = (time.perf_counter() - t1) / reps
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
         h2d = {"value_incl_scalar_h2d": round(n_total / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
-               "note": "scalars copied from a pinned host buffer on every step (not overlapped), bases resident"}
+               "note": "every rank copies its scalars from a pinned host buffer on every step (not overlapped), bases resident"}
         del host_sc, stage
 
     out = None

@@ -75,6 +75,12 @@ int mi355zk_bn254_g1_msm(const uint8_t *bases, size_t n_bases, size_t base_offse
                          const uint64_t *scalars, size_t n_scalars,
                          const uint32_t *density, size_t density_bits,
                          uint64_t out_xyz[12]);
+/* Host-buffer calls keep the uploaded BASE vector cached on the device, keyed by (pointer, length, group, a fingerprint of
+ * sampled records): the CRS is an immutable `Arc<Vec<G>>` reused by every proof (groth16/mod.rs:216-238), so only the scalars
+ * cross PCIe after the first call; large calls are streamed (chunked upload overlapped with the kernels).  A caller that
+ * REWRITES a base vector in place must say so: mi355zk_bases_cache_invalidate(ptr) (NULL: every cached vector).  The cache is
+ * LRU-bounded by env MI355ZK_BASES_CACHE_GB (default 64, 0 = off). */
+void mi355zk_bases_cache_invalidate(const void *host_bases);
 /* Same for G = G2Affine (prover.rs:297-298). */
 int mi355zk_bn254_g2_msm(const uint8_t *bases, size_t n_bases, size_t base_offset,
                          const uint64_t *scalars, size_t n_scalars,

@@ -3,9 +3,12 @@
 // bellman/src/domain.rs:52-99, and the kernel-timing hooks used by bench.py.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <string>
 #include <type_traits>
@@ -649,26 +652,335 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
   return ZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Host-buffer entry points (SURVEY 8b "Ownership"): the caller's bases and scalars live in (pageable) host memory.
+//   * BASES CACHE: the CRS / tau-table is reused across calls (`Arc<Vec<G>>` inside groth16::Parameters, groth16/mod.rs:216-238),
+//     so an uploaded base vector stays on the device, keyed by (host pointer, length, group, fingerprint of sampled records);
+//     LRU-bounded (env MI355ZK_BASES_CACHE_GB, default 64; 0 disables).
+//   * STREAMED UPLOAD: a large call is cut into chunks of ~2^24 exponents; a copy thread uploads chunk i + 1 (its scalars into
+//     one of two staging buffers, its bases -- when they are not cached yet -- straight into the cache entry) on a copy stream
+//     while the calling thread runs the multiexp of chunk i on a compute stream; the Jacobian partials are added on the host.
+//     PCIe and the kernels overlap; the first call is bound by the link (96 B per exponent), later calls by the kernels.
+
+struct BasesEntry {
+  const void* host = nullptr;
+  size_t n = 0;
+  int group = 0, dev = 0;
+  uint64_t fp = 0;
+  void* d = nullptr;
+  size_t bytes = 0;
+  uint64_t tick = 0;
+  bool ready = false;      // fully uploaded
+  std::mutex fill_mu;      // held by the call that uploads it
+};
+std::mutex g_bc_mu;
+std::vector<std::shared_ptr<BasesEntry>> g_bc;
+uint64_t g_bc_tick = 0;
+
+uint64_t fnv1a(uint64_t h, const uint8_t* p, size_t n) {
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+// first / last 4 KiB and 4096 records spread over the array: cheap (~0.3 MB hashed), and a different CRS at the same address
+// is caught; a few records rewritten IN PLACE are not -- the contract (include/mi355zk.h) is the reference's: the vector behind
+// an `Arc<Vec<G>>` is immutable, and mi355zk_bases_cache_invalidate() exists for callers that do rewrite it
+uint64_t bases_fingerprint(const uint8_t* p, size_t bytes, size_t rec) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  const size_t edge = bytes < 4096 ? bytes : 4096;
+  h = fnv1a(h, p, edge);
+  h = fnv1a(h, p + bytes - edge, edge);
+  const size_t nrec = bytes / rec;
+  for (size_t k = 1; k <= 4096 && nrec > 0; ++k) h = fnv1a(h, p + (nrec * k / 4097) * rec, rec);
+  return h;
+}
+size_t bases_cache_cap() {
+  static const char* env = std::getenv("MI355ZK_BASES_CACHE_GB");
+  const double gb = env ? std::atof(env) : 64.0;
+  return gb <= 0 ? 0 : (size_t)(gb * 1073741824.0);
+}
+// returns the entry (locked for filling when *fill == true: the caller uploads and then sets ready) or nullptr (cache off / no room)
+std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, size_t bytes, int dev, bool* fill) {
+  *fill = false;
+  const size_t cap = bases_cache_cap();
+  if (cap == 0 || bytes > cap) return nullptr;
+  const uint64_t fp = bases_fingerprint((const uint8_t*)host, bytes, group == 1 ? 64 : 128);
+  std::shared_ptr<BasesEntry> hit;
+  {
+    std::lock_guard<std::mutex> lk(g_bc_mu);
+    for (auto& e : g_bc)
+      if (e->host == host && e->n == n && e->group == group && e->dev == dev && e->fp == fp) { hit = e; break; }
+    if (hit) hit->tick = ++g_bc_tick;
+  }
+  if (hit) {
+    std::lock_guard<std::mutex> wait_fill(hit->fill_mu);  // another thread may still be uploading it
+    if (hit->ready) return hit;
+    return nullptr;                                       // its upload failed: go uncached
+  }
+  auto e = std::make_shared<BasesEntry>();
+  e->host = host; e->n = n; e->group = group; e->dev = dev; e->fp = fp; e->bytes = bytes;
+  {
+    std::lock_guard<std::mutex> lk(g_bc_mu);
+    size_t used = 0;
+    for (auto& x : g_bc) used += x->bytes;
+    while (used + bytes > cap && !g_bc.empty()) {           // evict least recently used entries nobody is filling
+      size_t victim = g_bc.size();
+      for (size_t i = 0; i < g_bc.size(); ++i)
+        if (g_bc[i]->ready && g_bc[i].use_count() == 1 && (victim == g_bc.size() || g_bc[i]->tick < g_bc[victim]->tick)) victim = i;
+      if (victim == g_bc.size()) break;
+      (void)hipFree(g_bc[victim]->d);
+      used -= g_bc[victim]->bytes;
+      g_bc.erase(g_bc.begin() + (long)victim);
+    }
+    if (used + bytes > cap) return nullptr;
+    if (hipMalloc(&e->d, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    e->tick = ++g_bc_tick;
+    e->fill_mu.lock();
+    g_bc.push_back(e);
+  }
+  *fill = true;
+  return e;
+}
+void bases_drop(const std::shared_ptr<BasesEntry>& e) {  // a failed upload
+  std::lock_guard<std::mutex> lk(g_bc_mu);
+  for (size_t i = 0; i < g_bc.size(); ++i)
+    if (g_bc[i] == e) { g_bc.erase(g_bc.begin() + (long)i); break; }
+  (void)hipFree(e->d);
+  e->d = nullptr;
+}
+
+// per (thread, device): two staging buffers for scalar chunks, a bases buffer for uncached calls, the two streams
+struct HostStage {
+  int dev = -1;
+  void* sc[2] = {nullptr, nullptr};
+  size_t sc_bytes = 0;
+  void* bases = nullptr;
+  size_t bases_bytes = 0;
+  hipStream_t copy = nullptr, compute = nullptr;
+};
+std::mutex g_stage_mu;
+std::vector<HostStage*> g_stages;  // every thread's stage, for mi355zk_shutdown
+HostStage* host_stage(int dev) {
+  thread_local HostStage* mine = nullptr;
+  if (mine == nullptr || mine->dev != dev) {
+    mine = new HostStage();
+    mine->dev = dev;
+    if (hipStreamCreateWithFlags(&mine->copy, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&mine->compute, hipStreamNonBlocking) != hipSuccess)
+      return nullptr;
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    g_stages.push_back(mine);
+  }
+  return mine;
+}
+int stage_reserve(void** p, size_t* have, size_t want) {
+  if (*have >= want) return ZK_OK;
+  if (*p) ZK_HIP(hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  ZK_HIP(hipMalloc(p, want));
+  *have = want;
+  return ZK_OK;
+}
+
+// forget the device copies of the base vector at `host` (nullptr: of every vector); entries in use stay until their call ends
+void bases_cache_invalidate(const void* host) {
+  std::lock_guard<std::mutex> lk(g_bc_mu);
+  for (size_t i = 0; i < g_bc.size();) {
+    if ((host == nullptr || g_bc[i]->host == host) && g_bc[i]->ready && g_bc[i].use_count() == 1) {
+      (void)hipSetDevice(g_bc[i]->dev);
+      (void)hipFree(g_bc[i]->d);
+      g_bc.erase(g_bc.begin() + (long)i);
+    } else {
+      if (host == nullptr || g_bc[i]->host == host) g_bc[i]->fp ^= 0x9e3779b97f4a7c15ull;  // in use: never matched again
+      ++i;
+    }
+  }
+}
+
+void host_entry_release_all() {
+  {
+    std::lock_guard<std::mutex> lk(g_bc_mu);
+    for (auto& e : g_bc) { (void)hipSetDevice(e->dev); (void)hipFree(e->d); }
+    g_bc.clear();
+  }
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  for (HostStage* s : g_stages) {
+    (void)hipSetDevice(s->dev);
+    (void)hipFree(s->sc[0]); (void)hipFree(s->sc[1]); (void)hipFree(s->bases);
+    s->sc[0] = s->sc[1] = s->bases = nullptr;
+    s->sc_bytes = s->bases_bytes = 0;
+  }
+}
+
+constexpr uint64_t HOST_CHUNK = 1ull << 24;      // exponents per chunk of a streamed call
+constexpr uint64_t HOST_CHUNK_MIN = 1ull << 22;  // below 2 chunks of this size the call is not cut
+
 template <int GROUP>
 int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
                    const uint32_t* density, size_t density_bits, uint64_t* out_xyz) {
+  t_last_err_index = -1;
   if (!out_xyz || (n_scalars && !scalars) || (n_bases && !bases)) return ZK_ERR_BAD_ARGS;
-  const size_t bsz = GROUP == 1 ? 64 : 128;
-  void* d_bases = nullptr;
-  void* d_scalars = nullptr;
-  if (n_bases) {
-    ZK_HIP(hipMalloc(&d_bases, n_bases * bsz));
-    ZK_HIP(hipMemcpy(d_bases, bases, n_bases * bsz, hipMemcpyHostToDevice));
+  if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  constexpr size_t bsz = GROUP == 1 ? 64 : 128;
+  constexpr size_t jac_words = GROUP == 1 ? 12 : 24;
+  using Jac = typename std::conditional<GROUP == 1, G1Jacobian, G2Jacobian>::type;
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  HostStage* S = host_stage(dev);
+  if (S == nullptr) return ZK_ERR_DEVICE;
+
+  // the exponents this call evaluates and the bases they consume (source.rs:36-118)
+  DensityPlan P;
+  int rc = plan_density(n_bases, base_offset, n_scalars, density, density_bits, &P);
+  if (rc) return rc;
+  const uint64_t n = P.eof_index >= 0 ? (uint64_t)P.eof_index : P.n;   // exponents before the first Eof
+  auto rank_of = [&](uint64_t i) -> uint64_t {                          // bases consumed by exponents [0, i)
+    if (density == nullptr) return i;
+    if (i == 0) return 0;
+    const uint64_t w = i >> 5;
+    uint64_t r = w < P.prefix.size() ? P.prefix[w] : 0;
+    if (w >= P.prefix.size()) {  // i == n on a word boundary past the last planned word
+      const uint64_t lw = P.prefix.size() - 1;
+      uint32_t v = density[lw];
+      if ((lw + 1) * 32 > P.n) v &= (P.n & 31) ? ((1u << (P.n & 31)) - 1u) : 0xffffffffu;
+      return P.prefix[lw] + (uint32_t)__builtin_popcount(v);
+    }
+    if (i & 31) r += (uint32_t)__builtin_popcount(density[w] & ((1u << (i & 31)) - 1u));
+    return r;
+  };
+
+  // ---- bases: cached, being cached by this call, or (cache off / full) a per-thread buffer
+  bool fill = false;
+  std::shared_ptr<BasesEntry> entry = n_bases ? bases_lookup(bases, n_bases, GROUP, n_bases * bsz, dev, &fill) : nullptr;
+  void* d_bases = entry ? entry->d : nullptr;
+  bool upload_bases = fill;
+  if (!entry && n_bases) {
+    rc = stage_reserve(&S->bases, &S->bases_bytes, n_bases * bsz);
+    if (rc) return rc;
+    d_bases = S->bases;
+    upload_bases = true;
   }
-  if (n_scalars) {
-    hipError_t e = hipMalloc(&d_scalars, n_scalars * 32);
-    if (e == hipSuccess) e = hipMemcpy(d_scalars, scalars, n_scalars * 32, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d_bases); (void)hipFree(d_scalars); ZK_HIP(e); }
+  struct FillGuard {  // whatever happens, the entry is either ready or gone when this call returns
+    std::shared_ptr<BasesEntry> e;
+    bool fill, ok = false;
+    ~FillGuard() {
+      if (!fill) return;
+      e->ready = ok;
+      e->fill_mu.unlock();
+      if (!ok) bases_drop(e);
+    }
+  } guard{entry, fill};
+
+  // ---- chunks (multiples of 32 exponents, so that density words are not shared between chunks)
+  uint64_t n_chunks = n >= 2 * HOST_CHUNK_MIN ? (n + HOST_CHUNK - 1) / HOST_CHUNK : 1;
+  if (n >= 2 * HOST_CHUNK_MIN && n_chunks < 2) n_chunks = 2;
+  uint64_t per = n_chunks ? ((n + n_chunks - 1) / n_chunks + 31) & ~31ull : 0;
+  if (per == 0) per = 32;
+  n_chunks = n ? (n + per - 1) / per : 0;
+  const size_t sc_bytes = (size_t)(n < per ? n : per) * 32;
+  if (n) {
+    for (int k = 0; k < 2; ++k) {
+      size_t have = S->sc_bytes;
+      rc = stage_reserve(&S->sc[k], &have, sc_bytes);
+      if (rc) { S->sc_bytes = 0; return rc; }
+    }
+    if (S->sc_bytes < sc_bytes) S->sc_bytes = sc_bytes;
   }
-  int rc = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, nullptr, out_xyz);
-  (void)hipFree(d_bases);
-  (void)hipFree(d_scalars);
-  return rc;
+
+  // the copy thread: for chunk c, scalars -> staging[c & 1] and (when uploading) the bases the chunk consumes; afterwards the
+  // bases outside the consumed range, so that a cache entry is complete.  `freed` counts chunks whose staging may be reused.
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t copied = 0, freed = 0;
+  bool copy_failed = false, abort_copy = false;
+  const uint64_t b_lo = base_offset < n_bases ? base_offset : n_bases;
+  auto copy_fn = [&]() {
+    if (hipSetDevice(dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); copy_failed = true; cv.notify_all(); return; }
+    uint64_t b_done = b_lo;  // bases [b_lo, b_done) are on the device
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return abort_copy || c < freed + 2; });
+        if (abort_copy) return;
+      }
+      const uint64_t lo = c * per, hi = lo + per < n ? lo + per : n;
+      hipError_t e = hipMemcpyAsync(S->sc[c & 1], scalars + lo * 4, (hi - lo) * 32, hipMemcpyHostToDevice, S->copy);
+      if (e == hipSuccess && upload_bases) {
+        uint64_t b_hi = base_offset + rank_of(hi);
+        if (b_hi > n_bases) b_hi = n_bases;
+        if (b_hi > b_done) {
+          e = hipMemcpyAsync((char*)d_bases + b_done * bsz, bases + b_done * bsz, (b_hi - b_done) * bsz, hipMemcpyHostToDevice, S->copy);
+          b_done = b_hi;
+        }
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(S->copy);
+      std::lock_guard<std::mutex> lk(mu);
+      if (e != hipSuccess) { copy_failed = true; cv.notify_all(); return; }
+      copied = c + 1;
+      cv.notify_all();
+    }
+    if (upload_bases && entry) {  // the rest of the vector (not needed by this call) completes the cache entry
+      hipError_t e = hipSuccess;
+      if (b_lo > 0) e = hipMemcpyAsync(d_bases, bases, b_lo * bsz, hipMemcpyHostToDevice, S->copy);
+      if (e == hipSuccess && b_done < n_bases)
+        e = hipMemcpyAsync((char*)d_bases + b_done * bsz, bases + b_done * bsz, (n_bases - b_done) * bsz, hipMemcpyHostToDevice, S->copy);
+      if (e == hipSuccess) e = hipStreamSynchronize(S->copy);
+      std::lock_guard<std::mutex> lk(mu);
+      if (e != hipSuccess) copy_failed = true;
+    }
+  };
+
+  Jac total = Jac::zero();
+  int result = ZK_OK;
+  long long err_idx = -1;
+  if (n_chunks > 0) {
+    std::thread copier(copy_fn);
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return copy_failed || copied > c; });
+        if (copy_failed) { result = ZK_ERR_DEVICE; break; }
+      }
+      const uint64_t lo = c * per, hi = lo + per < n ? lo + per : n;
+      uint64_t part[jac_words];
+      // the chunk is a multiexp of its own: same base vector, source offset advanced by the bases the earlier chunks consumed
+      int crc = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset + rank_of(lo), S->sc[c & 1], hi - lo, density ? density + (lo >> 5) : nullptr,
+                                     density ? hi - lo : 0, (void*)S->compute, part);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        freed = c + 1;
+        cv.notify_all();
+      }
+      if (crc != ZK_OK) {
+        result = crc;
+        err_idx = t_last_err_index >= 0 ? t_last_err_index + (long long)lo : -1;
+        break;
+      }
+      Jac pj;
+      std::memcpy(&pj, part, sizeof pj);
+      jac_add(total, pj);
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      abort_copy = result != ZK_OK;
+      cv.notify_all();
+    }
+    copier.join();
+    if (copy_failed && result == ZK_OK) result = ZK_ERR_DEVICE;
+  } else if (upload_bases && entry && n_bases) {
+    // nothing to evaluate, but the entry was created: fill it
+    hipError_t e = hipMemcpyAsync(d_bases, bases, n_bases * bsz, hipMemcpyHostToDevice, S->copy);
+    if (e == hipSuccess) e = hipStreamSynchronize(S->copy);
+    if (e != hipSuccess) result = ZK_ERR_DEVICE;
+  }
+  guard.ok = result != ZK_ERR_DEVICE && !copy_failed && !(fill && abort_copy);  // an aborted streamed upload is incomplete
+  if (result != ZK_OK) {
+    t_last_err_index = err_idx;
+    return result;
+  }
+  std::memcpy(out_xyz, &total, sizeof total);
+  if (P.eof_index >= 0) { t_last_err_index = P.eof_index; return ZK_ERR_UNEXPECTED_EOF; }
+  return ZK_OK;
 }
 
 int ntt_host(uint64_t* a, uint32_t log_n, int op, const uint64_t* omega) {
@@ -766,11 +1078,19 @@ int mi355zk_init(const int* device_ids, int n_devices) {
 void mi355zk_shutdown(void) {
   ntt_release_all();
   exp_scratch_release_all();
+  host_entry_release_all();
   msm_release_g1();
   msm_release_g2();
 }
 
-const char* mi355zk_version(void) { return "mi355zk 0.1 (gfx950)"; }
+const char* mi355zk_version(void) { return "mi355zk 0.2 (gfx950)"; }
+
+void mi355zk_bases_cache_invalidate(const void* host_bases) {
+  int dev = 0;
+  const bool have = hipGetDevice(&dev) == hipSuccess;
+  bases_cache_invalidate(host_bases);
+  if (have) (void)hipSetDevice(dev);
+}
 
 int mi355zk_bn254_g1_msm(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
                          const uint32_t* density, size_t density_bits, uint64_t out_xyz[12]) {

@@ -598,3 +598,56 @@ def test_montgomery_scalars_fused_into_repr(zk, worker, group):
     assert zk.lib.load().mi355zk_bn254_fr_into_repr_dev(C.c_void_p(out.data_ptr()), C.c_void_p(d_mont.data_ptr()), n, None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), canon)
+
+
+def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
+    """The host-buffer entry point (mi355zk_bn254_g1_msm, what a bellman shim calls with `Arc<Vec<G1Affine>>` + `Vec<FrRepr>`):
+    2^23 exponents are cut into chunks whose upload overlaps the previous chunk's kernels, and the base vector stays cached on
+    the device under (pointer, length, fingerprint).  Same group element as the device-resident call -- with a density map and
+    a source offset, on the first (uploading) and the second (cached) call; a changed CRS at the same address is noticed; the
+    Source errors keep their global exponent index across chunks."""
+    import torch
+
+    import bench
+
+    log_n, off = 23, 3
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2401)
+    bits = rng.random(n) < 0.75
+    used = int(bits.sum())
+    k = bench.gen_scalars(used + off, 2402, dev)
+    d_bases = torch.empty((used + off, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    assert zk.lib.load().mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(d_bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()),
+                                                       used + off, None) == 0
+    d_scalars = bench.gen_scalars(n, 2403, dev)
+    dm = zk.DensityTracker.from_bools(bits)
+    want = O.G1.to_affine(zk.multiexp(worker, (d_bases, off), dm, d_scalars).wait())
+    h_bases = d_bases.cpu().numpy().view(np.uint64)
+    h_scalars = d_scalars.cpu().numpy().view(np.uint64)
+    first = zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()       # uploads bases + scalars, chunk by chunk
+    second = zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()      # bases served from the cache
+    assert np.array_equal(O.G1.to_affine(first), want) and np.array_equal(O.G1.to_affine(second), want)
+    # FullDensity over a prefix of the same (cached) vector
+    want_fd = O.G1.to_affine(zk.multiexp(worker, (d_bases, 0), zk.FullDensity(), d_scalars[:used]).wait())
+    assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (h_bases, 0), zk.FullDensity(), h_scalars[:used]).wait()), want_fd)
+    # the CRS changes in place (same pointer, same length): the fingerprint differs, the stale copy is not used
+    h_bases[0] = h_bases[1]
+    d_bases[0] = d_bases[1]
+    want2 = O.G1.to_affine(zk.multiexp(worker, (d_bases, off), dm, d_scalars).wait())
+    assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()), want2)
+    # an identity base owned by an exponent of the SECOND chunk: the error carries the global exponent index
+    sel = np.nonzero(bits)[0]
+    target = int(sel[len(sel) * 3 // 4])
+    h_bases[off + len(sel) * 3 // 4] = 0
+    zk.lib.load().mi355zk_bases_cache_invalidate(h_bases.ctypes.data_as(C.c_void_p))   # a record rewritten in place: the caller says so
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == target
+    # one base short: Eof at the last selected exponent (in the last chunk)
+    h_bases[off + len(sel) * 3 // 4] = h_bases[1]
+    zk.lib.load().mi355zk_bases_cache_invalidate(None)
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (h_bases[:used + off - 1].copy(), off), dm, h_scalars).wait()
+    assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == int(sel[-1])

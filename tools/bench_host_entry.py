@@ -20,10 +20,16 @@ for ln in a.log_n:
     want = zk.multiexp(w, (b, 0), zk.FullDensity(), s).wait()
     hb, hs = b.cpu().numpy().view(np.uint64), s.cpu().numpy().view(np.uint64)
     del b, s, k
-    got = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()
+    zk.multiexp(w, (hb[:1024], 0), zk.FullDensity(), hs[:1024]).wait()   # warm the library (streams, workspace), not the cache of hb
     t = time.perf_counter()
-    for _ in range(a.iters): got = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()
+    got = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()              # FIRST call: bases + scalars cross PCIe, streamed
+    dt_first = time.perf_counter() - t
+    t = time.perf_counter()
+    for _ in range(a.iters): got2 = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()   # bases cached on the device: scalars only
     dt = (time.perf_counter() - t) / a.iters
-    out[f"2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mscalar_mul_per_s": round(n / dt / 1e6, 1), "host_bytes_per_call": 96 * n,
-                      "effective_GBs_incl_compute": round(96 * n / dt / 1e9, 2), "same_result_as_device_resident": bool(np.array_equal(got, want))}
-print(json.dumps({"entry": "mi355zk_bn254_g1_msm (host buffers, pageable)", **out}))
+    aff = lambda p: bytes(np.asarray(__import__("oracle_lib").G1.to_affine(p)))  # noqa: E731
+    out[f"2e{ln}"] = {"first_call_ms": round(dt_first * 1e3, 2), "cached_bases_ms": round(dt * 1e3, 2),
+                      "first_call_Mscalar_mul_per_s": round(n / dt_first / 1e6, 1), "cached_Mscalar_mul_per_s": round(n / dt / 1e6, 1),
+                      "first_call_host_bytes": 96 * n, "first_call_GBs_incl_compute": round(96 * n / dt_first / 1e9, 2),
+                      "same_result_as_device_resident": bool(aff(got) == aff(want) and aff(got2) == aff(want))}
+print(json.dumps({"entry": "mi355zk_bn254_g1_msm (host buffers, pageable; streamed upload + bases cache)", **out}))
