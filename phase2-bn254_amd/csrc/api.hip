@@ -206,10 +206,16 @@ constexpr int EXP_TAB = 8;
 __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restrict__ out, const Affine<Fq>* __restrict__ bases, int same_base,
                                                            const uint32_t* __restrict__ scalars, uint64_t i0, uint64_t n_chunk,
                                                            const uint32_t* __restrict__ base_index, Fq* __restrict__ zbuf,
-                                                           JacTabU<FqParams>* __restrict__ tab) {
+                                                           JacTabU<FqParams>* __restrict__ tab, const uint32_t* __restrict__ term_list,
+                                                           const uint32_t* __restrict__ term_count) {
+  // term_list != nullptr: only the listed elements are worked on (lane t of the launch <-> term_list[i0 + t], up to *term_count)
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunk) return;
-  const uint64_t i = i0 + t;
+  uint64_t i = i0 + t;
+  if (term_list != nullptr) {
+    if (i >= *term_count) return;
+    i = term_list[i];
+  }
   uint32_t s[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = scalars[i * 8 + l];
@@ -268,10 +274,15 @@ template <class F>
 __global__ void __launch_bounds__(256) batch_exp_win_std_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
                                                                const uint32_t* __restrict__ scalars, int same_scalar, uint64_t i0,
                                                                uint64_t n_chunk, const uint32_t* __restrict__ base_index,
-                                                               F* __restrict__ zbuf, Jacobian<F>* __restrict__ tab) {
+                                                               F* __restrict__ zbuf, Jacobian<F>* __restrict__ tab,
+                                                               const uint32_t* __restrict__ term_list, const uint32_t* __restrict__ term_count) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunk) return;
-  const uint64_t i = i0 + t;
+  uint64_t i = i0 + t;
+  if (term_list != nullptr) {
+    if (i >= *term_count) return;
+    i = term_list[i];
+  }
   uint32_t s[8];
   const uint32_t* sp = scalars + (same_scalar ? 0 : i * 8);
 #pragma unroll
@@ -422,6 +433,42 @@ void exp_scratch_release_all() {
   g_exp_scratch.clear();
 }
 
+// QAP coefficients are mostly +-1 (circom R1CS): a term with coefficient 1 / r - 1 / 0 is the base itself / its negative /
+// nothing, no scalar multiplication.  Those terms are written directly (Z = one resp. 0 for the normalisation pass that follows);
+// the indices of the others are appended to `list` and only they run the windowed multiplication, as full waves.
+template <class F>
+__global__ void __launch_bounds__(256) exp_classify_kernel(Affine<F>* __restrict__ out, F* __restrict__ zbuf, const Affine<F>* __restrict__ bases,
+                                                          const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ base_index, uint64_t n,
+                                                          uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  const uint4 s0 = sp[0], s1 = sp[1];
+  s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+  bool hi_zero = true, is_rm1 = true;
+#pragma unroll
+  for (int l = 1; l < 8; ++l) {
+    hi_zero = hi_zero && s[l] == 0;
+    is_rm1 = is_rm1 && s[l] == FrParams::P[l];
+  }
+  is_rm1 = is_rm1 && s[0] == FrParams::P[0] - 1u;
+  const bool is_zero = hi_zero && s[0] == 0, is_one = hi_zero && s[0] == 1;
+  if (!(is_zero || is_one || is_rm1)) {
+    list[atomicAdd(count, 1u)] = (uint32_t)i;
+    return;
+  }
+  Affine<F> p = bases[base_index ? base_index[i] : i];
+  if (is_zero || p.is_zero()) {
+    p = Affine<F>{F::zero(), F::zero()};
+    zbuf[i] = F::zero();
+  } else {
+    if (is_rm1) p.y = neg(p.y);
+    zbuf[i] = F::one();
+  }
+  out[i] = p;
+}
+
 // The scratch (Z coordinates, window tables) is per (device, stream) and the two kernels of one call must reach the stream
 // back to back: several host threads may share a stream (the default one above all), and A.exp, B.exp, A.normalize would
 // let A normalise with B's Z.  Held while ENQUEUEING only; the stream orders the kernels.
@@ -429,7 +476,7 @@ static std::mutex g_exp_launch_mu;
 
 template <class F>
 int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_scalars, int same_scalar, size_t n, void* stream,
-              const uint32_t* d_base_index = nullptr) {
+              const uint32_t* d_base_index = nullptr, bool shortcut_unit_scalars = false) {
   if (!d_out || !d_bases || !d_scalars) return n ? ZK_ERR_BAD_ARGS : ZK_OK;
   if (n == 0) return ZK_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -438,16 +485,25 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
     const bool windowed = !same_scalar;                     // per-point scalars: fixed windows (see batch_exp_win_kernel)
     const size_t chunk = n < ((size_t)1 << 18) ? n : ((size_t)1 << 18);
     const size_t z_bytes = (n * sizeof(Fq) + 255) & ~(size_t)255;
+    const bool shortcut = shortcut_unit_scalars && windowed && !same_base;
+    const size_t list_bytes = shortcut ? ((n + 1) * 4 + 255) & ~(size_t)255 : 0;
     void* p = nullptr;
-    int rc = exp_scratch(z_bytes + (windowed ? (size_t)EXP_TAB * chunk * sizeof(JacTabU<FqParams>) : 0), stream, &p);
+    int rc = exp_scratch(z_bytes + list_bytes + (windowed ? (size_t)EXP_TAB * chunk * sizeof(JacTabU<FqParams>) : 0), stream, &p);
     if (rc) return rc;
     Fq* zbuf = (Fq*)p;
+    uint32_t* list = shortcut ? (uint32_t*)((char*)p + z_bytes) : nullptr;   // [0] = count, then the general terms
+    if (shortcut) {
+      ZK_HIP(hipMemsetAsync(list, 0, 4, st));
+      hipLaunchKernelGGL(exp_classify_kernel<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, zbuf, (const Affine<Fq>*)d_bases,
+                         (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list);
+    }
     if (windowed) {
-      JacTabU<FqParams>* tab = (JacTabU<FqParams>*)((char*)p + z_bytes);
+      JacTabU<FqParams>* tab = (JacTabU<FqParams>*)((char*)p + z_bytes + list_bytes);
       for (size_t i0 = 0; i0 < n; i0 += chunk) {
         const size_t m = n - i0 < chunk ? n - i0 : chunk;
         hipLaunchKernelGGL(batch_exp_win_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
-                           same_base, (const uint32_t*)d_scalars, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab);
+                           same_base, (const uint32_t*)d_scalars, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab,
+                           shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
       }
     } else {
       hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, (const Affine<F>*)d_bases,
@@ -462,16 +518,24 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
   } else {
     const size_t chunk = n < ((size_t)1 << 18) ? n : ((size_t)1 << 18);
     const size_t z_bytes = (n * sizeof(F) + 255) & ~(size_t)255;
+    const bool shortcut = shortcut_unit_scalars && !same_scalar && !same_base;
+    const size_t list_bytes = shortcut ? ((n + 1) * 4 + 255) & ~(size_t)255 : 0;
     void* p = nullptr;
-    int rc = exp_scratch(z_bytes + (size_t)EXP_TAB * chunk * sizeof(Jacobian<F>), stream, &p);
+    int rc = exp_scratch(z_bytes + list_bytes + (size_t)EXP_TAB * chunk * sizeof(Jacobian<F>), stream, &p);
     if (rc) return rc;
     F* zbuf = (F*)p;
-    Jacobian<F>* tab = (Jacobian<F>*)((char*)p + z_bytes);
+    uint32_t* list = shortcut ? (uint32_t*)((char*)p + z_bytes) : nullptr;
+    if (shortcut) {
+      ZK_HIP(hipMemsetAsync(list, 0, 4, st));
+      hipLaunchKernelGGL(exp_classify_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, zbuf, (const Affine<F>*)d_bases,
+                         (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list);
+    }
+    Jacobian<F>* tab = (Jacobian<F>*)((char*)p + z_bytes + list_bytes);
     for (size_t i0 = 0; i0 < n; i0 += chunk) {
       const size_t m = n - i0 < chunk ? n - i0 : chunk;
       hipLaunchKernelGGL(batch_exp_win_std_kernel<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out,
                          (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
-                         zbuf, tab);
+                         zbuf, tab, shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
     }
     ZK_HIP(hipGetLastError());
     constexpr int K = 8;
@@ -1052,7 +1116,7 @@ static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const
       return ZK_ERR_BAD_ARGS;
     }
   }
-  int rc = batch_exp<F>(d_terms, d_bases, 0, d_coeffs, 0, nnz, stream, d_col);
+  int rc = batch_exp<F>(d_terms, d_bases, 0, d_coeffs, 0, nnz, stream, d_col, /*shortcut_unit_scalars=*/true);
   if (rc == ZK_OK)
     rc = group == 1 ? segsum_g1_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out)
                     : segsum_g2_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out);

@@ -97,12 +97,15 @@ __device__ __forceinline__ T load_vec(const T* p) {
 // 1. digits.  density == nullptr: FullDensity (source.rs:80-99): base of exponent i is base_offset+i.
 //    Otherwise bit i of `density` selects exponent i and the bases are compacted (source.rs:101-118):
 //    rank(i) = dprefix[i/32] + popc(density[i/32] & ((1<<i%32)-1)).
-// q = q div M, returns q mod M   (256-bit q on 8 words, M a small constant)
+// q = q div M, returns q mod M   (q on 8 words of which only words 0..top can be non-zero; M a small constant).  `top` is
+// uniform over the launch (it follows from the window number), so the skipped word steps are skipped by scalar branches: the
+// dividend loses ~42 bits with every pair of digits taken off, and the multiword work is what the digit extraction costs.
 template <uint32_t M>
-__device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8]) {
+__device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8], int top) {
   uint32_t rem = 0;
 #pragma unroll
   for (int l = 7; l >= 0; --l) {
+    if (l > top) continue;
     const uint64_t cur = ((uint64_t)rem << 32) | q[l];
     q[l] = (uint32_t)(cur / M);
     rem = (uint32_t)(cur % M);
@@ -111,16 +114,17 @@ __device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8]) {
 }
 
 // two mixed-radix digits at once: (r0 + B r1) = q mod B^2, q = q div B^2, B = M * 2^sh (sh <= 22).  One multiword division by
-// M^2 instead of two by M: the multiword work is what the digit extraction costs.
+// M^2 instead of two by M.
 template <uint32_t M>
-__device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint32_t& r0, uint32_t& r1) {
+__device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint32_t& r0, uint32_t& r1, int top) {
   const uint64_t low = (((uint64_t)q[1] << 32) | q[0]) & ((1ull << (2 * sh)) - 1ull);
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
 #pragma unroll
-    for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
+    for (int l = 0; l < 8; ++l)
+      if (l <= top) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
   }
-  const uint32_t rem = msm_divmod_small<M * M>(q);
+  const uint32_t rem = msm_divmod_small<M * M>(q, top);
   const uint64_t pv = low + ((uint64_t)rem << (2 * sh));  // < B^2 < 2^52
   const uint64_t hi = (pv >> sh) / M;                      // pv div B
   r1 = (uint32_t)hi;
@@ -138,9 +142,12 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
 #pragma unroll
     for (int l = 0; l < 8; ++l) q[l] = s[l];
     const uint32_t sh = G.rshift, B = G.rmul << sh;
+    const int flog_m = G.rmul >= 8 ? 3 : G.rmul >= 4 ? 2 : 1;  // floor(log2 rmul): a digit takes at least sh + flog_m bits off q
+    int nbits = 254;                                           // q < 2^nbits (exponents are < r < 2^254)
     uint32_t pending = 0;
     bool have_pending = false;
     for (uint32_t w = 0; w < G.W; ++w) {
+      const int top = nbits > 0 ? (nbits - 1) >> 5 : 0;
       uint32_t d, neg = 0;
       if (w + 1 < G.W) {
         uint32_t raw;
@@ -149,28 +156,30 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
           have_pending = false;
         } else if (w + 2 < G.W) {  // this window and the next one, neither of them the top window
           switch (G.rmul) {  // division by compile-time constants (multiply-high), not by runtime values
-            case 3: msm_two_digits<3>(q, sh, raw, pending); break;
-            case 5: msm_two_digits<5>(q, sh, raw, pending); break;
-            case 7: msm_two_digits<7>(q, sh, raw, pending); break;
-            case 9: msm_two_digits<9>(q, sh, raw, pending); break;
-            case 11: msm_two_digits<11>(q, sh, raw, pending); break;
-            case 13: msm_two_digits<13>(q, sh, raw, pending); break;
-            default: msm_two_digits<15>(q, sh, raw, pending); break;
+            case 3: msm_two_digits<3>(q, sh, raw, pending, top); break;
+            case 5: msm_two_digits<5>(q, sh, raw, pending, top); break;
+            case 7: msm_two_digits<7>(q, sh, raw, pending, top); break;
+            case 9: msm_two_digits<9>(q, sh, raw, pending, top); break;
+            case 11: msm_two_digits<11>(q, sh, raw, pending, top); break;
+            case 13: msm_two_digits<13>(q, sh, raw, pending, top); break;
+            default: msm_two_digits<15>(q, sh, raw, pending, top); break;
           }
           have_pending = true;
+          nbits -= 2 * (int)(sh + flog_m);
         } else {
           const uint32_t low = q[0] & ((1u << sh) - 1u);
 #pragma unroll
           for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
+          nbits -= (int)(sh + flog_m);
           uint32_t rem = 0;
           switch (G.rmul) {
-            case 3: rem = msm_divmod_small<3>(q); break;
-            case 5: rem = msm_divmod_small<5>(q); break;
-            case 7: rem = msm_divmod_small<7>(q); break;
-            case 9: rem = msm_divmod_small<9>(q); break;
-            case 11: rem = msm_divmod_small<11>(q); break;
-            case 13: rem = msm_divmod_small<13>(q); break;
-            default: rem = msm_divmod_small<15>(q); break;
+            case 3: rem = msm_divmod_small<3>(q, top); break;
+            case 5: rem = msm_divmod_small<5>(q, top); break;
+            case 7: rem = msm_divmod_small<7>(q, top); break;
+            case 9: rem = msm_divmod_small<9>(q, top); break;
+            case 11: rem = msm_divmod_small<11>(q, top); break;
+            case 13: rem = msm_divmod_small<13>(q, top); break;
+            default: rem = msm_divmod_small<15>(q, top); break;
           }
           raw = low + (rem << sh);
         }
@@ -298,12 +307,27 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
     for (uint32_t t = threadIdx.x; t < nword; t += PART_THREADS) lh[t] = 0;
     __syncthreads();
     const uint64_t i_end = (uint64_t)(st + 1) * P.st < n ? (uint64_t)(st + 1) * P.st : n;
+    // the next scalar of the lane is requested before the current one is worked on (~10^3 instructions): the load latency is
+    // then hidden inside the lane itself, not only by the other waves
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+    {
+      const uint64_t i_first = (uint64_t)st * P.st + threadIdx.x;
+      if (i_first < i_end) {
+        const uint4* sp = reinterpret_cast<const uint4*>(scalars + i_first * 8);
+        n0 = sp[0];
+        n1 = sp[1];
+      }
+    }
     for (uint64_t i = (uint64_t)st * P.st + threadIdx.x; i < i_end; i += PART_THREADS) {
       bool active = true;
       if (density != nullptr) active = (density[i >> 5] >> (i & 31)) & 1;
       uint32_t s[9];
-      const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-      const uint4 s0 = sp[0], s1 = sp[1];
+      const uint4 s0 = n0, s1 = n1;
+      if (i + PART_THREADS < i_end) {
+        const uint4* sp = reinterpret_cast<const uint4*>(scalars + (i + PART_THREADS) * 8);
+        n0 = sp[0];
+        n1 = sp[1];
+      }
       s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
       if (scalars_mont) {
         Fr f;
@@ -611,11 +635,16 @@ inline PartGeom choose_part(uint64_t n, uint32_t WL, uint32_t nb) {
   while ((1u << lo_cap) < nb && lo_cap < PART_LO_MAX) ++lo_cap;  // one bin holds everything, or 2^PART_LO_MAX buckets
   auto nbin_of = [&](uint32_t lo) { return (uint32_t)(((uint64_t)nb + (1ull << lo) - 1) >> lo); };
   // as fine as the pass-A histogram (WL * nbin words of LDS) allows, but no finer than ~8192 elements per bin need
-  // pass A keeps WL * nbin 16-bit counters in LDS (two workgroups per CU); pass B scans nbin words with 1024 lanes x 4
-  auto fits = [&](uint32_t lo) { return (uint64_t)WL * nbin_of(lo) * 2 <= PART_LDS_A && nbin_of(lo) <= 4 * PART_THREADS; };
+  // pass A keeps WL * nbin 16-bit counters in LDS (two workgroups per CU while they fit PART_LDS_A, one up to twice that);
+  // pass B scans nbin words with 1024 lanes x 4
+  auto fits_lds = [&](uint32_t lo, uint64_t budget) { return (uint64_t)WL * nbin_of(lo) * 2 <= budget && nbin_of(lo) <= 4 * PART_THREADS; };
+  auto fits = [&](uint32_t lo) { return fits_lds(lo, 2 * PART_LDS_A); };
+  auto pop = [&](uint32_t lo) { return (uint64_t)n * (1ull << lo) / nb; };  // mean elements per (window, bin)
   uint32_t lo = lo_cap;
   const uint64_t pop_target = 12288;
-  while (lo > 0 && (uint64_t)n * (1ull << lo) / nb > pop_target && fits(lo - 1)) --lo;
+  const uint64_t pop_cap = (uint64_t)PART_EC * PART_THREADS * 85 / 100;     // pass C holds a bin in registers: stay clear of the cliff
+  while (lo > 0 && pop(lo) > pop_target && fits_lds(lo - 1, PART_LDS_A)) --lo;
+  while (lo > 0 && pop(lo) > pop_cap && fits(lo - 1)) --lo;
   while (!fits(lo) && lo < PART_LO_MAX) ++lo;
   if (env_lo) {
     const int v = std::atoi(env_lo);
@@ -1262,7 +1291,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t grid = P.n_st < 2u * (uint32_t)cus ? P.n_st : 2u * (uint32_t)cus;  // two 1024-lane workgroups per CU (LDS histograms)
+    const uint32_t per_cu = (size_t)((ncell + 1) / 2) * 4 <= PART_LDS_A ? 2u : 1u;     // 1024-lane workgroups per CU (LDS histograms)
+    const uint32_t grid = P.n_st < per_cu * (uint32_t)cus ? P.n_st : per_cu * (uint32_t)cus;
     hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_scalars, n, d_density, G, w_lo,
                        w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist, d_err + 1);
   }

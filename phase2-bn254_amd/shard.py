@@ -122,3 +122,32 @@ def allgather_join(partial: np.ndarray, device=None, group=None) -> np.ndarray:
     allp = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(allp, mine, group=group)
     return join_partials(allp.cpu().numpy().view(np.uint64).reshape(world, -1))
+
+
+def batch_exp_sharded(bases, exps, same_scalar: bool = False, gather: bool = True, group=None, fn=None):
+    """BASELINE config 5's "1 vs 8 GPU": the per-point scalar multiplications of phase2 `contribute` (parameters.rs:423-470, every
+    point of L and H by delta^-1) and of powersoftau `batch_exp` (batched_accumulator.rs:1130-1181) are independent, so they shard
+    by CONTIGUOUS POINT RANGE with no exchange at all: rank r transforms bases[lo:hi) (shard_range).  `bases` / `exps` are the FULL
+    vectors on every rank (or anything sliceable: a rank only touches its range); the local result comes back, or -- gather=True,
+    what a rank that writes the whole parameter file needs -- the concatenation of all ranges through ONE all-gather of the affine
+    records (ranges padded to equal length).  fn: the local kernel, default ceremony.batch_exp (the gloo CPU test passes a stand-in)."""
+    import torch
+    import torch.distributed as dist
+
+    from . import ceremony
+
+    fn = fn or ceremony.batch_exp
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = bases.shape[0]
+    lo, hi = shard_range(n, world, rank)
+    local = fn(bases[lo:hi].contiguous(), exps if same_scalar else exps[lo:hi].contiguous(), same_scalar)
+    if not gather or world == 1:
+        return local
+    longest = shard_range(n, world, 0)[1]                      # the first ranks hold the remainders: rank 0 is a longest range
+    pad = torch.zeros((longest, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[:hi - lo] = local
+    allp = torch.empty((world * longest, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(allp, pad, group=group)
+    parts = [allp[r * longest:r * longest + (shard_range(n, world, r)[1] - shard_range(n, world, r)[0])] for r in range(world)]
+    return torch.cat(parts)

@@ -83,3 +83,48 @@ def test_two_rank_shard_allgather_join(group, n, with_density):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+def _worker_batch_exp(rank, world, port, n, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    import inputs
+    import oracle_lib as O
+    import phase2_bn254_amd as zk
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bases = inputs.bases_progression_cpu(1, n, seed=31)
+    delta_inv = inputs.random_scalars(1, seed=32)
+
+    def stand_in(b, k, same_scalar):  # the oracle as the CPU stand-in of ceremony.batch_exp (which needs a GPU)
+        hb = b.numpy().view(np.uint64)
+        out = np.stack([O.G1.to_affine(O.G1.mul(O.G1.from_affine(p), k.numpy().view(np.uint64)[0])) for p in hb]) if len(hb) else hb
+        return torch.from_numpy(np.ascontiguousarray(out).view(np.int64))
+
+    got = zk.shard.batch_exp_sharded(torch.from_numpy(bases.view(np.int64)), torch.from_numpy(delta_inv.view(np.int64)), same_scalar=True, fn=stand_in)
+    want = np.stack([O.G1.to_affine(O.G1.mul(O.G1.from_affine(p), delta_inv[0])) for p in bases])
+    q.put((rank, bool(np.array_equal(got.numpy().view(np.uint64), want))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_contribute_by_point_range():
+    """config 5's multi-GPU leg (phase2 contribute): point ranges, no exchange but the optional all-gather of the results;
+    an odd length, so the ranges differ by one."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batch_exp, args=(r, 2, port, 37, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]

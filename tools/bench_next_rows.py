@@ -49,6 +49,19 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     for _ in range(a.iters): assert smv(*sargs) == 0
     dt = (time.perf_counter() - t) / a.iters
     out[f"g{g}_qap_sparse_matvec"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
+    # the same matrix with circom-like coefficients: 90 % of the terms +-1 (no scalar multiplication), 10 % general
+    kind = torch.randint(0, 20, (nnz,), device=dev, generator=g_)
+    cf1 = cf.clone()
+    one = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=dev)
+    rm1 = torch.tensor([0x43E1F593F0000000, 0x2833E84879B97091, 0xB85045B68181585D - (1 << 64), 0x30644E72E131A029], dtype=torch.int64, device=dev)
+    cf1[kind < 9] = one
+    cf1[(kind >= 9) & (kind < 18)] = rm1
+    sargs1 = sargs[:5] + (C.c_void_p(cf1.data_ptr()),) + sargs[6:]
+    assert smv(*sargs1) == 0
+    t = time.perf_counter()
+    for _ in range(a.iters): assert smv(*sargs1) == 0
+    dt = (time.perf_counter() - t) / a.iters
+    out[f"g{g}_qap_sparse_matvec_90pct_unit_coeffs"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
 # row 4: point FFT (prepare_phase2's Lagrange-basis conversion)
 for ln in (12, 16, a.log_n):
     m = 1 << ln
