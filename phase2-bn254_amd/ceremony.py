@@ -394,3 +394,116 @@ def eval_qap_polynomials(radix, at, bt, ct):
         start = start + ln
     ext = eval_qap(bases, row_ptr.to(torch.int32), col, coeff)
     return a_g1, b_g1, b_g2, ext
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Groth16 parameter files: bellman `Parameters::{write, read}` (bellman/src/groth16/mod.rs:104-198, 252-383) and
+# phase2 `MPCParameters::{write, read}` (phase2/src/parameters.rs:661-706; PublicKey phase2/src/keypair.rs:49-120).  Layout, every
+# point UNCOMPRESSED:
+#   vk: alpha_g1, beta_g1 (G1), beta_g2, gamma_g2 (G2), delta_g1 (G1), delta_g2 (G2), u32 BE |ic|, ic[] (G1)
+#   then five vectors, each u32 BE length + points: h (G1), l (G1), a (G1), b_g1 (G1), b_g2 (G2)
+#   MPC files append cs_hash[64], u32 BE number of contributions, and per contribution delta_after, s, s_delta (G1), r_delta (G2),
+#   transcript[64].
+# Offsets and the length words are host work; every point goes through the codec kernels.
+def _be32(data, off: int) -> int:
+    return int.from_bytes(bytes(data[off:off + 4].cpu().numpy()), "big")
+
+
+class _Reader:
+    def __init__(self, data):
+        self.data, self.off = data, 0
+
+    def points(self, n: int, group: int, checked: bool, no_infinity: bool, what: str):
+        sz = _ENC_SIZE[(group, False)]
+        if self.data.numel() < self.off + n * sz:
+            raise ValueError(f"parameter file too short in {what}")        # io::ErrorKind::UnexpectedEof
+        pts = decode_points(self.data[self.off:self.off + n * sz].view(n, sz), group, False, checked)
+        self.off += n * sz
+        return _no_infinity(pts, what) if no_infinity else pts
+
+    def u32(self) -> int:
+        v = _be32(self.data, self.off)
+        self.off += 4
+        return v
+
+    def raw(self, n: int):
+        out = self.data[self.off:self.off + n].clone()
+        self.off += n
+        return out
+
+
+def read_parameters(data, disallow_points_at_infinity: bool = True, checked: bool = True, _reader=None):
+    """Parameters::read (groth16/mod.rs:296-383).  data: 1-D uint8 device tensor.  Returns {"vk": {...device records...,
+    "ic": (n, 8)}, "h", "l", "a", "b_g1": (n, 8), "b_g2": (n, 16)} of raw affine device records.  The verifying key is always
+    read checked and its ic rejects the point at infinity (VerifyingKey::read, :143-198); the five vectors follow the two flags."""
+    rd = _reader or _Reader(data)
+    vk = {}
+    for name, g in (("alpha_g1", 1), ("beta_g1", 1), ("beta_g2", 2), ("gamma_g2", 2), ("delta_g1", 1), ("delta_g2", 2)):
+        vk[name] = rd.points(1, g, True, False, name)
+    vk["ic"] = rd.points(rd.u32(), 1, True, True, "ic")
+    out = {"vk": vk}
+    for name, g in (("h", 1), ("l", 1), ("a", 1), ("b_g1", 1), ("b_g2", 2)):
+        out[name] = rd.points(rd.u32(), g, checked, disallow_points_at_infinity, name)
+    return out
+
+
+def write_parameters(params):
+    """Parameters::write (groth16/mod.rs:253-294): one uint8 device tensor."""
+    import torch
+
+    dev = params["h"].device
+    be = lambda n: torch.frombuffer(bytearray(int(n).to_bytes(4, "big")), dtype=torch.uint8).to(dev)  # noqa: E731
+    enc = lambda pts: encode_points(pts.contiguous(), False).reshape(-1)  # noqa: E731
+    vk = params["vk"]
+    parts = [enc(vk[k]) for k in ("alpha_g1", "beta_g1", "beta_g2", "gamma_g2", "delta_g1", "delta_g2")]
+    parts += [be(vk["ic"].shape[0]), enc(vk["ic"])]
+    for name in ("h", "l", "a", "b_g1", "b_g2"):
+        parts += [be(params[name].shape[0]), enc(params[name])]
+    return torch.cat(parts)
+
+
+def read_mpc_parameters(data, disallow_points_at_infinity: bool = True, checked: bool = True):
+    """MPCParameters::read (phase2/src/parameters.rs:683-706): the Groth16 parameters, cs_hash and the contributions' public keys
+    (every public-key point checked and never the point at infinity, keypair.rs:64-120)."""
+    rd = _Reader(data)
+    out = {"params": read_parameters(data, disallow_points_at_infinity, checked, _reader=rd)}
+    out["cs_hash"] = rd.raw(64)
+    out["contributions"] = []
+    for _ in range(rd.u32()):
+        pk = {"delta_after": rd.points(1, 1, True, True, "delta_after"), "s": rd.points(1, 1, True, True, "s"),
+              "s_delta": rd.points(1, 1, True, True, "s_delta"), "r_delta": rd.points(1, 2, True, True, "r_delta")}
+        pk["transcript"] = rd.raw(64)
+        out["contributions"].append(pk)
+    return out
+
+
+def write_mpc_parameters(mpc):
+    """MPCParameters::write (phase2/src/parameters.rs:663-678)."""
+    import torch
+
+    dev = mpc["cs_hash"].device
+    enc = lambda pts: encode_points(pts.contiguous(), False).reshape(-1)  # noqa: E731
+    parts = [write_parameters(mpc["params"]), mpc["cs_hash"],
+             torch.frombuffer(bytearray(len(mpc["contributions"]).to_bytes(4, "big")), dtype=torch.uint8).to(dev)]
+    for pk in mpc["contributions"]:
+        parts += [enc(pk["delta_after"]), enc(pk["s"]), enc(pk["s_delta"]), enc(pk["r_delta"]), pk["transcript"]]
+    return torch.cat(parts)
+
+
+def contribute_parameters(params, delta: int):
+    """The device work of MPCParameters::contribute (phase2/src/parameters.rs:414-522) for a given private delta: every point of
+    l and h times delta^-1 (`batch_exp`, affine out), delta_g1 and delta_g2 times delta.  Returns new parameters; the key pair,
+    its transcript hash and the public key record (keypair.rs: hash-to-G2, BLAKE2b) stay with the caller."""
+    dev = params["h"].device
+    import torch
+
+    to_dev = lambda v: torch.tensor([_limbs_i64(v % _R_ORDER)], dtype=torch.int64, device=dev)  # noqa: E731
+    d_inv, d = to_dev(pow(delta, -1, _R_ORDER)), to_dev(delta)
+    out = dict(params)
+    out["l"] = batch_exp(params["l"], d_inv, same_scalar=True)
+    out["h"] = batch_exp(params["h"], d_inv, same_scalar=True)
+    vk = dict(params["vk"])
+    vk["delta_g1"] = batch_exp(params["vk"]["delta_g1"], d, same_scalar=True)
+    vk["delta_g2"] = batch_exp(params["vk"]["delta_g2"], d, same_scalar=True)
+    out["vk"] = vk
+    return out

@@ -340,3 +340,78 @@ def test_config5_contribute_at_size(zk, worker, group, log_n):
         rho = bench.gen_scalars(n, seed, dev)
         s, sx = zk.ceremony.merge_pairs(before, after, rho)
         assert np.array_equal(G.to_affine(s), G.to_affine(G.mul(sx, _limbs(delta))))
+
+
+def test_groth16_and_mpc_parameter_files(zk, worker):
+    """Parameters::{read, write} (bellman/src/groth16/mod.rs:104-198, 252-383) and MPCParameters::{read, write} (phase2/src/
+    parameters.rs:661-706) around the codec kernels, then the device work of `contribute` (:414-522) on the parsed file.
+    The file is laid out on the CPU with the oracle's encoder; parsed on the device element for element; written back byte
+    for byte; the two read flags and the never-infinity rules raise what the reference raises; after contribute(delta) the
+    re-read file holds delta^-1 L, delta^-1 H, delta delta_g1, delta delta_g2 (oracle mul_assign), everything else untouched."""
+    import torch
+
+    g1 = inputs.bases_progression_cpu(1, 80, seed=880)
+    g2 = inputs.bases_progression_cpu(2, 20, seed=881)
+    sizes = {"ic": 3, "h": 15, "l": 13, "a": 16, "b_g1": 9}
+    vk = {"alpha_g1": g1[0:1], "beta_g1": g1[1:2], "beta_g2": g2[0:1], "gamma_g2": g2[1:2], "delta_g1": g1[2:3], "delta_g2": g2[2:3], "ic": g1[3:6]}
+    vecs = {"h": g1[6:21], "l": g1[21:34], "a": g1[34:50], "b_g1": g1[50:59], "b_g2": g2[3:12]}
+    be = lambda n: np.frombuffer(int(n).to_bytes(4, "big"), np.uint8)  # noqa: E731
+    enc = lambda pts: O.encode_points(1 if pts.shape[1] == 8 else 2, pts, False).reshape(-1)  # noqa: E731
+    blob = [enc(vk[k]) for k in ("alpha_g1", "beta_g1", "beta_g2", "gamma_g2", "delta_g1", "delta_g2")] + [be(3), enc(vk["ic"])]
+    for name in ("h", "l", "a", "b_g1", "b_g2"):
+        blob += [be(len(vecs[name])), enc(vecs[name])]
+    params_bytes = np.concatenate(blob)
+    pk = {"delta_after": g1[60:61], "s": g1[61:62], "s_delta": g1[62:63], "r_delta": g2[12:13]}
+    cs_hash, transcript = np.arange(64, dtype=np.uint8), np.arange(100, 164, dtype=np.uint8)
+    mpc_bytes = np.concatenate([params_bytes, cs_hash, be(1), enc(pk["delta_after"]), enc(pk["s"]), enc(pk["s_delta"]), enc(pk["r_delta"]), transcript])
+    assert mpc_bytes.size == params_bytes.size + 64 + 4 + 3 * 64 + 128 + 64
+
+    mpc = zk.ceremony.read_mpc_parameters(torch.from_numpy(mpc_bytes).cuda())
+    p = mpc["params"]
+    for k in vk:
+        assert np.array_equal(_host(p["vk"][k]), vk[k]), k
+    for k in vecs:
+        assert np.array_equal(_host(p[k]), vecs[k]), k
+    assert bytes(mpc["cs_hash"].cpu().numpy()) == bytes(cs_hash) and len(mpc["contributions"]) == 1
+    assert np.array_equal(_host(mpc["contributions"][0]["r_delta"]), pk["r_delta"])
+    assert bytes(mpc["contributions"][0]["transcript"].cpu().numpy()) == bytes(transcript)
+    assert np.array_equal(zk.ceremony.write_mpc_parameters(mpc).cpu().numpy(), mpc_bytes)
+    assert np.array_equal(zk.ceremony.write_parameters(p).cpu().numpy(), params_bytes)
+
+    # a point at infinity inside l: rejected unless the caller allows it (mod.rs:318-324)
+    off_l = 576 + 4 + 3 * 64 + 4 + 15 * 64 + 4
+    bad = params_bytes.copy()
+    bad[off_l + 5 * 64:off_l + 6 * 64] = 0
+    bad[off_l + 5 * 64] = 0x40
+    with pytest.raises(zk.ceremony.DeserializationError):
+        zk.ceremony.read_parameters(torch.from_numpy(bad).cuda(), disallow_points_at_infinity=True, checked=True)
+    ok = zk.ceremony.read_parameters(torch.from_numpy(bad).cuda(), disallow_points_at_infinity=False, checked=True)
+    assert not _host(ok["l"])[5].any()
+    # a point off the curve inside a: NotOnCurve when checked, accepted unchecked (into_affine_unchecked)
+    off_a = off_l + 13 * 64 + 4
+    bad = params_bytes.copy()
+    bad[off_a + 2 * 64 + 63] ^= 1
+    with pytest.raises(zk.ceremony.GroupDecodingError) as e:
+        zk.ceremony.read_parameters(torch.from_numpy(bad).cuda(), checked=True)
+    assert e.value.kind == "NotOnCurve" and e.value.index == 2
+    zk.ceremony.read_parameters(torch.from_numpy(bad).cuda(), checked=False)
+    # ... but never in the verifying key (always checked)
+    bad = params_bytes.copy()
+    bad[63] ^= 1
+    with pytest.raises(zk.ceremony.GroupDecodingError):
+        zk.ceremony.read_parameters(torch.from_numpy(bad).cuda(), checked=False)
+    with pytest.raises(ValueError):
+        zk.ceremony.read_parameters(torch.from_numpy(params_bytes[:-10].copy()).cuda())
+
+    # contribute: the heavy part of phase2 `contribute` on the parsed file, written back and re-read
+    delta = 0x6A09E667F3BCC908BB67AE8584CAA73B3C6EF372FE94F82BA54FF53A5F1D36F1 % M.R_ORDER
+    after = zk.ceremony.read_parameters(zk.ceremony.write_parameters(zk.ceremony.contribute_parameters(p, delta)))
+    dinv, d = _limbs(pow(delta, -1, M.R_ORDER)), _limbs(delta)
+    mul = lambda G, pts, k: np.stack([G.to_affine(G.mul(G.from_affine(x), k)) for x in pts])  # noqa: E731
+    assert np.array_equal(_host(after["l"]), mul(O.G1, vecs["l"], dinv)) and np.array_equal(_host(after["h"]), mul(O.G1, vecs["h"], dinv))
+    assert np.array_equal(_host(after["vk"]["delta_g1"]), mul(O.G1, vk["delta_g1"], d))
+    assert np.array_equal(_host(after["vk"]["delta_g2"]), mul(O.G2, vk["delta_g2"], d))
+    for k in ("a", "b_g1", "b_g2"):
+        assert np.array_equal(_host(after[k]), vecs[k])
+    for k in ("alpha_g1", "beta_g1", "beta_g2", "gamma_g2", "ic"):
+        assert np.array_equal(_host(after["vk"][k]), vk[k])
