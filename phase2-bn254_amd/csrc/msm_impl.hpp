@@ -569,23 +569,19 @@ __global__ void __launch_bounds__(PART_THREADS) msm_bucket_kernel(const uint2* _
   const uint32_t fmask = nfmax - 1u;
   for (uint32_t t = threadIdx.x; t < nfmax; t += PART_THREADS) hist[t] = 0;
   __syncthreads();
-  const bool in_regs = cnt <= PART_EC * PART_THREADS;
+  if (cnt > PART_EC * PART_THREADS) return;  // a BIG bin (skewed exponents, or very large n): msm_bigbin_* kernels, many workgroups
   uint32_t val[PART_EC], fr[PART_EC];  // fr = fine bucket | rank << PART_LO_MAX
-  if (in_regs) {
 #pragma unroll
-    for (uint32_t k = 0; k < PART_EC; ++k) {
-      const uint32_t idx = k * PART_THREADS + threadIdx.x;
-      val[k] = 0;
-      fr[k] = 0;
-      if (idx < cnt) {
-        const uint2 e = pairs[(uint64_t)beg + idx];
-        const uint32_t f = e.x & fmask;
-        val[k] = e.y | (e.x & SIGN_BIT);
-        fr[k] = f | (atomicAdd(&hist[f], 1u) << PART_LO_MAX);
-      }
+  for (uint32_t k = 0; k < PART_EC; ++k) {
+    const uint32_t idx = k * PART_THREADS + threadIdx.x;
+    val[k] = 0;
+    fr[k] = 0;
+    if (idx < cnt) {
+      const uint2 e = pairs[(uint64_t)beg + idx];
+      const uint32_t f = e.x & fmask;
+      val[k] = e.y | (e.x & SIGN_BIT);
+      fr[k] = f | (atomicAdd(&hist[f], 1u) << PART_LO_MAX);
     }
-  } else {
-    for (uint32_t idx = threadIdx.x; idx < cnt; idx += PART_THREADS) atomicAdd(&hist[pairs[(uint64_t)beg + idx].x & fmask], 1u);
   }
   __syncthreads();
   const uint32_t padded = block_scan_1024(nf, scratch, [&](uint32_t x) { return (hist[x] + 3u) & ~3u; },
@@ -596,7 +592,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_bucket_kernel(const uint2* _
     first[id0 + t] = ob + start[t];
     last[id0 + t] = ob + start[t] + hist[t];
   }
-  if (in_regs && padded <= stage_cap) {
+  if (padded <= stage_cap) {
 #pragma unroll
     for (uint32_t k = 0; k < PART_EC; ++k) {
       const uint32_t idx = k * PART_THREADS + threadIdx.x;
@@ -607,22 +603,190 @@ __global__ void __launch_bounds__(PART_THREADS) msm_bucket_kernel(const uint2* _
     uint4* dst = reinterpret_cast<uint4*>(vals + ob);
     const uint4* src = reinterpret_cast<const uint4*>(staging);
     for (uint32_t q = threadIdx.x; q < padded / 4; q += PART_THREADS) dst[q] = src[q];
-  } else if (in_regs) {
+  } else {
 #pragma unroll
     for (uint32_t k = 0; k < PART_EC; ++k) {
       const uint32_t idx = k * PART_THREADS + threadIdx.x;
       if (idx < cnt) vals[(uint64_t)ob + start[fr[k] & ((1u << PART_LO_MAX) - 1u)] + (fr[k] >> PART_LO_MAX)] = val[k];
     }
-  } else {
-    // second read: `hist` becomes the running cursor of every bucket
-    __syncthreads();
+  }
+}
+
+// BIG bins: more elements than one workgroup holds in registers.  Prover-like exponents do this -- a Groth16 witness is full of
+// 0 / 1 / small values, so window 0 sends a large share of ALL points into the first few buckets, i.e. into one bin -- and so does
+// a uniform input at n > 2^26.  Such a bin is cut into SEGMENTS of PART_EC * 1024 elements, one workgroup each:
+//   msm_bigbin_plan_kernel   (one workgroup) the list of big bins and the prefix of their segment counts
+//   msm_bigbin_count_kernel  every segment adds its LDS histogram over the bin's buckets to gcnt[bucket id]
+//   msm_bigbin_place_kernel  every segment derives the bucket starts from gcnt (scan, 4-entry aligned like the small bins),
+//                            reserves its share of each bucket with ONE atomic per non-empty bucket (gcur) and writes its
+//                            indices; segment 0 of a bin also writes first[] / last[].
+// A fixed grid strides over the segments -- the host never reads the plan back -- and idle workgroups exit at once.
+constexpr uint32_t BIG_SEG = PART_EC * PART_THREADS;
+
+struct BigPlan {         // device-side
+  uint32_t n_big;        // big bins
+  uint32_t total_seg;    // their segments
+};
+
+__global__ void __launch_bounds__(PART_THREADS) msm_bigbin_plan_kernel(const uint32_t* __restrict__ bin_start, uint32_t ncell,
+                                                                       uint32_t* __restrict__ big_col, uint32_t* __restrict__ big_seg_off,
+                                                                       BigPlan* __restrict__ plan) {
+  __shared__ uint32_t part_n[PART_THREADS], part_s[PART_THREADS];
+  const uint32_t per = (ncell + PART_THREADS - 1) / PART_THREADS;
+  const uint32_t c0 = threadIdx.x * per, c1 = c0 + per < ncell ? c0 + per : ncell;
+  uint32_t nbig = 0, nseg = 0;
+  for (uint32_t col = c0; col < c1; ++col) {
+    const uint32_t cnt = bin_start[col + 1] - bin_start[col];
+    if (cnt > BIG_SEG) { ++nbig; nseg += (cnt + BIG_SEG - 1) / BIG_SEG; }
+  }
+  part_n[threadIdx.x] = nbig;
+  part_s[threadIdx.x] = nseg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t rn = 0, rs = 0;
+    for (uint32_t t = 0; t < PART_THREADS; ++t) {
+      const uint32_t a = part_n[t], b = part_s[t];
+      part_n[t] = rn;
+      part_s[t] = rs;
+      rn += a;
+      rs += b;
+    }
+    plan->n_big = rn;
+    plan->total_seg = rs;
+  }
+  __syncthreads();
+  uint32_t k = part_n[threadIdx.x], so = part_s[threadIdx.x];
+  for (uint32_t col = c0; col < c1; ++col) {
+    const uint32_t cnt = bin_start[col + 1] - bin_start[col];
+    if (cnt > BIG_SEG) {
+      big_col[k] = col;
+      big_seg_off[k] = so;
+      ++k;
+      so += (cnt + BIG_SEG - 1) / BIG_SEG;
+    }
+  }
+}
+
+// (big bin, segment) of workgroup b: the last k with big_seg_off[k] <= b
+__device__ __forceinline__ bool bigbin_locate(const BigPlan* plan, const uint32_t* big_col, const uint32_t* big_seg_off, uint32_t b,
+                                              uint32_t* col, uint32_t* seg) {
+  if (b >= plan->total_seg) return false;
+  uint32_t lo = 0, hi = plan->n_big;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (big_seg_off[mid] <= b) lo = mid;
+    else hi = mid;
+  }
+  *col = big_col[lo];
+  *seg = b - big_seg_off[lo];
+  return true;
+}
+
+__global__ void __launch_bounds__(PART_THREADS) msm_bigbin_count_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ bin_start,
+                                                                        const BigPlan* __restrict__ plan, const uint32_t* __restrict__ big_col,
+                                                                        const uint32_t* __restrict__ big_seg_off, uint32_t nb, PartGeom P,
+                                                                        uint32_t* __restrict__ gcnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  for (uint32_t b = blockIdx.x;; b += gridDim.x) {   // a fixed grid strides over the segments (their number is only known on the device)
+    uint32_t col, seg;
+    if (!bigbin_locate(plan, big_col, big_seg_off, b, &col, &seg)) return;
+    const uint32_t nfmax = 1u << P.lo_bits, fmask = nfmax - 1u;
+    const uint32_t wl = col / P.nbin, bin = col % P.nbin;
+    const uint32_t beg = bin_start[col] + seg * BIG_SEG, end = bin_start[col + 1];
+    const uint32_t cnt = end - beg < BIG_SEG ? end - beg : BIG_SEG;
     for (uint32_t t = threadIdx.x; t < nfmax; t += PART_THREADS) hist[t] = 0;
     __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < cnt; idx += PART_THREADS) {
+    for (uint32_t idx = threadIdx.x; idx < cnt; idx += PART_THREADS) atomicAdd(&hist[pairs[(uint64_t)beg + idx].x & fmask], 1u);
+    __syncthreads();
+    const uint32_t id0 = wl * nb + (bin << P.lo_bits);
+    for (uint32_t t = threadIdx.x; t < nfmax; t += PART_THREADS)
+      if (hist[t]) atomicAdd(&gcnt[id0 + t], hist[t]);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(PART_THREADS) msm_bigbin_place_kernel(const uint2* __restrict__ pairs, const uint32_t* __restrict__ bin_start,
+                                                                        const uint32_t* __restrict__ out_start, const BigPlan* __restrict__ plan,
+                                                                        const uint32_t* __restrict__ big_col, const uint32_t* __restrict__ big_seg_off,
+                                                                        uint32_t nb, PartGeom P, int staged, const uint32_t* __restrict__ gcnt,
+                                                                        uint32_t* __restrict__ gcur, uint32_t* __restrict__ first,
+                                                                        uint32_t* __restrict__ last, uint32_t* __restrict__ vals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {
+  uint32_t col, seg;
+  if (!bigbin_locate(plan, big_col, big_seg_off, blk, &col, &seg)) return;
+  const uint32_t nfmax = 1u << P.lo_bits, fmask = nfmax - 1u;
+  const uint32_t nfl = nfmax < 4 ? 4 : nfmax;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);   // this segment's count per bucket, then its reserved base inside the bucket
+  uint32_t* start = hist + nfl;                          // the bucket's first slot relative to the bin's region
+  uint32_t* scratch = start + nfl;                       // 32
+  uint32_t* lstart = scratch + 32;                       // staged: the bucket's first slot inside this segment's staging area, then its length
+  uint32_t* llen = lstart + nfl;
+  uint32_t* staging = llen + nfl;                        // staged: BIG_SEG indices
+  const uint32_t wl = col / P.nbin, bin = col % P.nbin;
+  const uint32_t beg = bin_start[col] + seg * BIG_SEG, end = bin_start[col + 1];
+  const uint32_t cnt = end - beg < BIG_SEG ? end - beg : BIG_SEG;
+  const uint32_t ob = out_start[col];
+  const uint32_t nf = (bin + 1) << P.lo_bits <= nb ? nfmax : nb - (bin << P.lo_bits);
+  const uint32_t id0 = wl * nb + (bin << P.lo_bits);
+  for (uint32_t t = threadIdx.x; t < nfmax; t += PART_THREADS) hist[t] = 0;
+  __syncthreads();
+  uint32_t val[PART_EC], fr[PART_EC];
+#pragma unroll
+  for (uint32_t k = 0; k < PART_EC; ++k) {
+    const uint32_t idx = k * PART_THREADS + threadIdx.x;
+    val[k] = 0;
+    fr[k] = 0;
+    if (idx < cnt) {
       const uint2 e = pairs[(uint64_t)beg + idx];
       const uint32_t f = e.x & fmask;
-      vals[(uint64_t)ob + start[f] + atomicAdd(&hist[f], 1u)] = e.y | (e.x & SIGN_BIT);
+      val[k] = e.y | (e.x & SIGN_BIT);
+      fr[k] = f | (atomicAdd(&hist[f], 1u) << PART_LO_MAX);   // rank < 2^15 (a segment has 2^15 elements): fits above the 12 bucket bits
     }
+  }
+  __syncthreads();
+  block_scan_1024(nf, scratch, [&](uint32_t x) { return (gcnt[id0 + x] + 3u) & ~3u; }, [&](uint32_t x, uint32_t ex) { start[x] = ex; });
+  if (staged) block_scan_1024(nf, scratch, [&](uint32_t x) { return hist[x]; }, [&](uint32_t x, uint32_t ex) { lstart[x] = ex; });
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < nf; t += PART_THREADS) {
+    if (seg == 0) {
+      first[id0 + t] = ob + start[t];
+      last[id0 + t] = ob + start[t] + gcnt[id0 + t];
+    }
+    const uint32_t mine = hist[t];
+    if (staged) llen[t] = mine;
+    hist[t] = mine ? atomicAdd(&gcur[id0 + t], mine) : 0u;   // this segment's base inside bucket t
+  }
+  __syncthreads();
+  if (staged) {
+    // the segment's indices grouped by bucket in LDS, then every bucket's run written by one wave: contiguous stores
+    // (64 lanes x 4 B) instead of one 4-byte store per lane all over the bin's region
+#pragma unroll
+    for (uint32_t k = 0; k < PART_EC; ++k) {
+      const uint32_t idx = k * PART_THREADS + threadIdx.x;
+      if (idx < cnt) staging[lstart[fr[k] & ((1u << PART_LO_MAX) - 1u)] + (fr[k] >> PART_LO_MAX)] = val[k];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t f = wv; f < nf; f += PART_THREADS / 64) {
+      const uint32_t len = llen[f];
+      const uint32_t* src = staging + lstart[f];
+      uint32_t* dst = vals + (uint64_t)ob + start[f] + hist[f];
+      for (uint32_t q = lane; q < len; q += 64) dst[q] = src[q];
+    }
+    __syncthreads();
+    continue;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < PART_EC; ++k) {
+    const uint32_t idx = k * PART_THREADS + threadIdx.x;
+    if (idx < cnt) {
+      const uint32_t f = fr[k] & ((1u << PART_LO_MAX) - 1u);
+      vals[(uint64_t)ob + start[f] + hist[f] + (fr[k] >> PART_LO_MAX)] = val[k];
+    }
+  }
+  __syncthreads();
   }
 }
 
@@ -1149,8 +1313,8 @@ int part_configure(int dev) {
   auto it = g_part_cfg.find(dev);
   if (it != g_part_cfg.end()) return it->second;
   int rc = ZK_OK;
-  const void* fns[3] = {reinterpret_cast<const void*>(msm_digits_hist_kernel), reinterpret_cast<const void*>(msm_scatter_kernel),
-                        reinterpret_cast<const void*>(msm_bucket_kernel)};
+  const void* fns[4] = {reinterpret_cast<const void*>(msm_digits_hist_kernel), reinterpret_cast<const void*>(msm_scatter_kernel),
+                        reinterpret_cast<const void*>(msm_bucket_kernel), reinterpret_cast<const void*>(msm_bigbin_place_kernel)};
   for (const void* fn : fns) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -1220,6 +1384,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_tile_hist = take((size_t)P.n_st * ((ncell + 1) & ~1u) * 2), o_tile_off = take((size_t)P.n_st * ncell * 4);
   size_t o_csum = take((size_t)P.n_chunk * ncell * 4), o_total = take((size_t)ncell * 4);
   size_t o_bin_start = take((size_t)(ncell + 1) * 4), o_out_start = take((size_t)(ncell + 1) * 4);
+  // big bins (msm_bigbin_*): per-bucket counts and cursors (contiguous: one memset), the list of big bins, the plan
+  size_t o_gcnt = take((size_t)n_buckets * 4), o_gcur = take((size_t)n_buckets * 4);
+  size_t o_big_col = take((size_t)ncell * 4), o_big_seg = take((size_t)ncell * 4), o_big_plan = take(sizeof(BigPlan));
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
   size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
   // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
@@ -1257,6 +1424,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t* col_total = (uint32_t*)(ws + o_total);
   uint32_t* bin_start = (uint32_t*)(ws + o_bin_start);
   uint32_t* out_start = (uint32_t*)(ws + o_out_start);
+  uint32_t* gcnt = (uint32_t*)(ws + o_gcnt);
+  uint32_t* gcur = (uint32_t*)(ws + o_gcur);
+  uint32_t* big_col = (uint32_t*)(ws + o_big_col);
+  uint32_t* big_seg = (uint32_t*)(ws + o_big_seg);
+  BigPlan* big_plan = (BigPlan*)(ws + o_big_plan);
   uint32_t* first = (uint32_t*)(ws + o_first);
   uint32_t* last = (uint32_t*)(ws + o_last);
   uint32_t* size_hist = (uint32_t*)(ws + o_hist);
@@ -1273,6 +1445,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   ZK_HIP(hipMemsetAsync(d_err, 0xff, 16, st));
   ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
+  ZK_HIP(hipMemsetAsync(gcnt, 0, o_big_col - o_gcnt, st));  // gcnt and gcur
 
   static const bool debug = std::getenv("MI355ZK_DEBUG") != nullptr;
   auto checkpoint = [&](const char* what) -> int {
@@ -1330,6 +1503,16 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     const uint32_t stage_cap = (uint32_t)want & ~3u;
     hipLaunchKernelGGL(msm_bucket_kernel, dim3(ncell), dim3(PART_THREADS), fixed + (size_t)stage_cap * 4, st, pairs, bin_start, out_start, G.nb, P,
                        stage_cap, first, last, vals_b);
+    // the big bins (none for uniform exponents up to 2^26 points: the surplus workgroups of these launches exit at once)
+    const uint32_t max_seg = (uint32_t)(2 * (m / BIG_SEG) + 2);
+    hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
+    const uint32_t big_grid = max_seg < 2048u ? max_seg : 2048u;
+    hipLaunchKernelGGL(msm_bigbin_count_kernel, dim3(big_grid), dim3(PART_THREADS), (size_t)nfl * 4, st, pairs, bin_start, big_plan, big_col, big_seg,
+                       G.nb, P, gcnt);
+    const size_t place_fixed = (size_t)(4 * nfl + 32) * 4, place_staged = place_fixed + (size_t)BIG_SEG * 4;
+    const int staged = place_staged <= PART_LDS_MAX ? 1 : 0;
+    hipLaunchKernelGGL(msm_bigbin_place_kernel, dim3(big_grid), dim3(PART_THREADS), staged ? place_staged : place_fixed, st, pairs, bin_start, out_start,
+                       big_plan, big_col, big_seg, G.nb, P, staged, gcnt, gcur, first, last, vals_b);
   }
   ZK_HIP(hipGetLastError());
   prof_end(slot_bucket, st);

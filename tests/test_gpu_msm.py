@@ -651,3 +651,44 @@ def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
     with pytest.raises(zk.SynthesisError) as e:
         zk.multiexp(worker, (h_bases[:used + off - 1].copy(), off), dm, h_scalars).wait()
     assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == int(sel[-1])
+
+
+def test_prover_like_exponents_at_2e22_take_the_big_bin_path(zk, worker):
+    """A Groth16 witness at size: 40 % ones, 30 % zeros, 10 % bytes, the rest uniform.  Window 0 then sends ~half of all points
+    into ONE coarse bin of the partition (far more than a workgroup holds in registers: the segmented msm_bigbin_* kernels) and
+    millions into single buckets (the segment-parallel heavy-bucket accumulation).  Closed form (sum s_i k_i) G, and the skewed
+    vector must not be slower than the uniform one (it has fewer non-zero digits)."""
+    import time
+
+    import torch
+
+    import bench
+    import bn254_model as M
+
+    bases, uniform, k = _dev_inputs(zk, 22, seed=2501)
+    n = 1 << 22
+    dev = bases.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(2502)
+    kind = torch.randint(0, 10, (n,), device=dev, generator=g)
+    skew = uniform.clone()
+    skew[kind < 4] = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=dev)
+    skew[(kind >= 4) & (kind < 7)] = 0
+    small = torch.randint(0, 256, (n,), device=dev, generator=g, dtype=torch.int64)
+    m8 = kind == 7
+    skew[m8] = torch.stack([small, torch.zeros_like(small), torch.zeros_like(small), torch.zeros_like(small)], dim=1)[m8]
+    got = zk.multiexp(worker, (bases, 0), zk.FullDensity(), skew).wait()
+    hs, hk = skew.cpu().numpy().view(np.uint64), k.cpu().numpy().view(np.uint64)
+    dot = int(sum(int(a) * int(b) for a, b in zip(_to_int(hs), _to_int(hk))) % M.R_ORDER)
+    want = O.G1.mul(O.G1.from_affine(inputs.G1_GEN_RAW), M.to_limbs(dot))
+    assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+
+    def timed(sc):
+        zk.multiexp(worker, (bases, 0), zk.FullDensity(), sc).wait()
+        t = time.perf_counter()
+        for _ in range(3):
+            zk.multiexp(worker, (bases, 0), zk.FullDensity(), sc).wait()
+        return (time.perf_counter() - t) / 3
+
+    t_uniform, t_skew = timed(uniform), timed(skew)
+    assert t_skew < 1.2 * t_uniform, f"prover-like exponents: {t_skew * 1e3:.2f} ms against {t_uniform * 1e3:.2f} ms uniform"
