@@ -676,21 +676,33 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
   uint32_t* d_density = nullptr;
   uint32_t* d_prefix = nullptr;
   if (density != nullptr && n > 0) {
+    // a grow-only buffer per host thread: hipMalloc / hipFree per call would synchronise the whole device and with it every
+    // other thread's multiexp
+    struct DensityBuf { int dev = -1; void* p = nullptr; size_t bytes = 0; };
+    thread_local DensityBuf buf;
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
     size_t words = (n + 31) / 32;
-    ZK_HIP(hipMalloc(&d_density, words * 8));
-    d_prefix = d_density + words;
-    hipError_t e = hipMemcpyAsync(d_density, density, words * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_prefix, P.prefix.data(), words * 4, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) {
-      (void)hipFree(d_density);
-      ZK_HIP(e);
+    if (buf.dev != dev || buf.bytes < words * 8) {
+      if (buf.p) {
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipFree(buf.p));
+      }
+      buf.p = nullptr;
+      buf.bytes = 0;
+      ZK_HIP(hipMalloc(&buf.p, words * 8));
+      buf.bytes = words * 8;
+      buf.dev = dev;
     }
+    d_density = (uint32_t*)buf.p;
+    d_prefix = d_density + words;
+    ZK_HIP(hipMemcpyAsync(d_density, density, words * 4, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_prefix, P.prefix.data(), words * 4, hipMemcpyHostToDevice, st));
   }
   long long err_index = -1;
   const bool mont = (flags & MI355ZK_MSM_SCALARS_MONTGOMERY) != 0;
   if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont);
   else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont);
-  if (d_density) (void)hipFree(d_density);
   if (rc == ZK_ERR_UNEXPECTED_IDENTITY) {
     // the kernels report the lowest BASE index that was the identity under a non-zero exponent; the exponent that owns it
     // is the (index - base_offset)-th selected one (source.rs:101-118): itself under FullDensity

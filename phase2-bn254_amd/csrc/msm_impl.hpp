@@ -133,8 +133,10 @@ __device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint3
 
 // Digits of one scalar (canonical limbs s[0..7], s[8] = 0): emit(w, d, neg) for every window w of the geometry, d = |digit|
 // (0 = no bucket), neg = SIGN_BIT for a negative digit.  The carry chain of the signed digits runs from window 0.
+// Only the windows below w_stop are produced (a multi-GPU rank that owns a group of windows needs the carry chain / the
+// division chain from window 0 up to its last window, not beyond).
 template <class Emit>
-__device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& G, Emit emit) {
+__device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& G, uint32_t w_stop, Emit emit) {
   uint32_t carry = 0;
   if (G.rmul != 1) {
     // mixed radix: repeatedly  low = q mod 2^rshift;  q >>= rshift;  (q, r) = divmod(q, rmul);  digit = low + 2^rshift * r
@@ -146,7 +148,7 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
     int nbits = 254;                                           // q < 2^nbits (exponents are < r < 2^254)
     uint32_t pending = 0;
     bool have_pending = false;
-    for (uint32_t w = 0; w < G.W; ++w) {
+    for (uint32_t w = 0; w < w_stop; ++w) {
       const int top = nbits > 0 ? (nbits - 1) >> 5 : 0;
       uint32_t d, neg = 0;
       if (w + 1 < G.W) {
@@ -197,7 +199,7 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
     }
     return;
   }
-  for (uint32_t w = 0; w < G.W; ++w) {
+  for (uint32_t w = 0; w < w_stop; ++w) {
     const uint32_t width = G.width[w], bit = G.shift[w];
     uint32_t limb = bit >> 5, off = bit & 31;
     uint64_t two = limb < 8 ? ((uint64_t)s[limb] | ((uint64_t)s[limb + 1] << 32)) : 0ull;
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
       }
       // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is
       // loaded anyway, in accumulate_run)
-      msm_scalar_digits(s, G, [&](uint32_t w, uint32_t d, uint32_t neg) {
+      msm_scalar_digits(s, G, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
         if (w >= w_lo && w < w_hi) {
           const uint32_t wl = w - w_lo;
           keys[(uint64_t)wl * kstride + i] = d ? ((d - 1) | neg) : G.nb;
@@ -1206,7 +1208,51 @@ int ws_reserve(int dev, size_t bytes, void** out) {
   return 0;
 }
 
+// Calls whose workspace is small (<= WS_SMALL: up to ~2^21 points) do not share the device-wide workspace and its lock: every
+// host thread keeps its own buffer.  The prover queues eight multiexps from eight threads (prover.rs:250-298) -- the short ones
+// (inputs, B_G1 ...) then run concurrently on their callers' streams instead of waiting behind the long ones.
+constexpr size_t WS_SMALL = (size_t)1 << 30;
+struct ThreadWs {
+  int dev = -1;
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+std::mutex g_tws_mu;
+std::vector<ThreadWs*> g_tws;  // every thread's buffer, for the shutdown
+int tws_reserve(int dev, size_t bytes, hipStream_t st, void** out) {
+  thread_local ThreadWs* mine = nullptr;
+  if (mine == nullptr) {
+    mine = new ThreadWs();
+    std::lock_guard<std::mutex> lk(g_tws_mu);
+    g_tws.push_back(mine);
+  }
+  if (mine->dev != dev || mine->bytes < bytes) {
+    if (mine->p) {
+      ZK_HIP(hipStreamSynchronize(st));
+      ZK_HIP(hipFree(mine->p));
+    }
+    mine->p = nullptr;
+    mine->bytes = 0;
+    ZK_HIP(hipMalloc(&mine->p, bytes));
+    mine->bytes = bytes;
+    mine->dev = dev;
+  }
+  *out = mine->p;
+  return 0;
+}
+
 void ws_release_all() {
+  {
+    std::lock_guard<std::mutex> lk(g_tws_mu);
+    for (ThreadWs* t : g_tws) {
+      if (t->p) {
+        (void)hipSetDevice(t->dev);
+        (void)hipFree(t->p);
+      }
+      t->p = nullptr;
+      t->bytes = 0;
+    }
+  }
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (auto& kv : g_ws) {
     (void)hipSetDevice(kv.first);
@@ -1390,8 +1436,16 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
   size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
   // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
+  // ... and, more to the point, when ONE lane walking it would outlast the whole launch: the lanes of a launch share ~2^18 lane
+  // slots (256 CUs x 4 SIMDs x 4 waves x 64), so a launch lasts about m / 2^18 additions per slot; a longer bucket is a straggler
+  // (it starts first -- buckets run in size order -- but finishes alone).  Prover-like exponents produce such buckets by the
+  // hundred (every byte-sized witness value lands in one of 255 buckets of window 0).
   const uint64_t mean_len = n / G.nb + 1;
-  const uint32_t heavy = (uint32_t)(mean_len * 8 + 1024 > 0xffffffffull ? 0xffffffffull : mean_len * 8 + 1024);
+  uint64_t heavy64 = mean_len * 8 + 1024;
+  const uint64_t per_slot = m >> 18;
+  if (heavy64 > (per_slot > 256 ? per_slot : 256)) heavy64 = per_slot > 256 ? per_slot : 256;
+  if (heavy64 < 2 * mean_len + 64) heavy64 = 2 * mean_len + 64;   // never the ordinary buckets
+  const uint32_t heavy = (uint32_t)(heavy64 > 0xffffffffull ? 0xffffffffull : heavy64);
   uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
   if ((uint64_t)hb > m / heavy + 1) hb = (uint32_t)(m / heavy + 1);
   const uint32_t max_items = (uint32_t)(m / MSM_HEAVY_SEG) + hb;  // every heavy bucket adds at most one partial segment
@@ -1410,9 +1464,15 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   int rc = part_configure(dev);
   if (rc) return rc;
-  std::unique_lock<std::mutex> lk(g_ws_mu);
+  const bool small_ws = off <= WS_SMALL;
+  std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
   void* base = nullptr;
-  rc = ws_reserve(dev, off, &base);
+  if (small_ws) {
+    rc = tws_reserve(dev, off, st, &base);
+  } else {
+    lk.lock();
+    rc = ws_reserve(dev, off, &base);
+  }
   if (rc) return rc;
   char* ws = (char*)base;
   uint32_t* keys = (uint32_t*)(ws + o_keys);
@@ -1607,7 +1667,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     const unsigned long long h_err = h_errs[0];
     // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
     // flight, prover.rs:250-298) start while this thread joins its partial sums
-    if (last_set) lk.unlock();
+    if (last_set && lk.owns_lock()) lk.unlock();
     if (h_errs[1] != ~0ull) {
       *err_index_out = (long long)h_errs[1];
       return ZK_ERR_BAD_ARGS;

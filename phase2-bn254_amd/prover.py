@@ -129,7 +129,9 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
             return fut.wait
 
         def call():
-            with torch.cuda.device(device):
+            # its own stream: small multiexps (per-thread workspace in the library) overlap with the long ones instead of
+            # queueing behind them on one stream; inputs are complete (the caller synchronised), results come back on the host
+            with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
                 return multiexp(pool, bases, density, exponents, scalars_montgomery=True)
 
         f = ex.submit(call)
