@@ -292,6 +292,17 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t len, uint32_t* scra
   return scratch[16];
 }
 
+// the same over any length: chunks of 4 * PART_THREADS values with a running carry
+template <class In, class Out>
+__device__ __forceinline__ uint32_t block_scan_long(uint32_t len, uint32_t* scratch, In value, Out out) {
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < len; base += 4 * PART_THREADS) {
+    const uint32_t m = len - base < 4 * PART_THREADS ? len - base : 4 * PART_THREADS;
+    carry += block_scan_1024(m, scratch, [&](uint32_t x) { return value(base + x); }, [&](uint32_t x, uint32_t ex) { out(base + x, carry + ex); });
+  }
+  return carry;
+}
+
 // pass A.  density == nullptr: FullDensity (source.rs:80-99).  Otherwise bit i of `density` selects exponent i
 // (source.rs:101-118).  scalars_mont != 0: the exponents are Fr elements in Montgomery form (what the prover holds before
 // scalars_into_representations, prover.rs:89-129): the conversion into_repr() is one Montgomery reduction, fused here.
@@ -402,43 +413,17 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // entries: + up to 3 per bucket).
 __global__ void __launch_bounds__(PART_THREADS) msm_binscan_kernel(const uint32_t* __restrict__ total, PartGeom P, uint32_t ncell, uint32_t nb,
                                                                    uint32_t* __restrict__ bin_start, uint32_t* __restrict__ out_start) {
-  __shared__ uint32_t part[PART_THREADS], part_out[PART_THREADS];
-  const uint32_t per = (ncell + PART_THREADS - 1) / PART_THREADS;
-  const uint32_t c0 = threadIdx.x * per, c1 = c0 + per < ncell ? c0 + per : ncell;
-  auto padded = [&](uint32_t col, uint32_t tot) {
+  __shared__ uint32_t scratch[32];
+  auto padded = [&](uint32_t col) {
     const uint32_t bin = col % P.nbin;
     const uint32_t nf = ((bin + 1) << P.lo_bits) <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
-    return (tot + 3u * nf + 3u) & ~3u;
+    return (total[col] + 3u * nf + 3u) & ~3u;
   };
-  uint32_t sum = 0, sum_out = 0;
-  for (uint32_t col = c0; col < c1; ++col) {
-    const uint32_t tot = total[col];
-    sum += tot;
-    sum_out += padded(col, tot);
-  }
-  part[threadIdx.x] = sum;
-  part_out[threadIdx.x] = sum_out;
-  __syncthreads();
+  const uint32_t t0 = block_scan_long(ncell, scratch, [&](uint32_t c) { return total[c]; }, [&](uint32_t c, uint32_t ex) { bin_start[c] = ex; });
+  const uint32_t t1 = block_scan_long(ncell, scratch, padded, [&](uint32_t c, uint32_t ex) { out_start[c] = ex; });
   if (threadIdx.x == 0) {
-    uint32_t run = 0, run_out = 0;
-    for (uint32_t t = 0; t < PART_THREADS; ++t) {
-      const uint32_t v = part[t], vo = part_out[t];
-      part[t] = run;
-      part_out[t] = run_out;
-      run += v;
-      run_out += vo;
-    }
-    bin_start[ncell] = run;
-    out_start[ncell] = run_out;
-  }
-  __syncthreads();
-  uint32_t run = part[threadIdx.x], run_out = part_out[threadIdx.x];
-  for (uint32_t col = c0; col < c1; ++col) {
-    const uint32_t tot = total[col];
-    bin_start[col] = run;
-    out_start[col] = run_out;
-    run += tot;
-    run_out += padded(col, tot);
+    bin_start[ncell] = t0;
+    out_start[ncell] = t1;
   }
 }
 
@@ -633,39 +618,17 @@ struct BigPlan {         // device-side
 __global__ void __launch_bounds__(PART_THREADS) msm_bigbin_plan_kernel(const uint32_t* __restrict__ bin_start, uint32_t ncell,
                                                                        uint32_t* __restrict__ big_col, uint32_t* __restrict__ big_seg_off,
                                                                        BigPlan* __restrict__ plan) {
-  __shared__ uint32_t part_n[PART_THREADS], part_s[PART_THREADS];
-  const uint32_t per = (ncell + PART_THREADS - 1) / PART_THREADS;
-  const uint32_t c0 = threadIdx.x * per, c1 = c0 + per < ncell ? c0 + per : ncell;
-  uint32_t nbig = 0, nseg = 0;
-  for (uint32_t col = c0; col < c1; ++col) {
-    const uint32_t cnt = bin_start[col + 1] - bin_start[col];
-    if (cnt > BIG_SEG) { ++nbig; nseg += (cnt + BIG_SEG - 1) / BIG_SEG; }
-  }
-  part_n[threadIdx.x] = nbig;
-  part_s[threadIdx.x] = nseg;
+  __shared__ uint32_t scratch[32];
+  auto cnt_of = [&](uint32_t col) { return bin_start[col + 1] - bin_start[col]; };
+  // compact the big bins, then the prefix of their segment counts
+  const uint32_t n_big = block_scan_long(ncell, scratch, [&](uint32_t c) { return cnt_of(c) > BIG_SEG ? 1u : 0u; },
+                                         [&](uint32_t c, uint32_t ex) { if (cnt_of(c) > BIG_SEG) big_col[ex] = c; });
   __syncthreads();
+  const uint32_t n_seg = block_scan_long(n_big, scratch, [&](uint32_t k) { return (cnt_of(big_col[k]) + BIG_SEG - 1) / BIG_SEG; },
+                                         [&](uint32_t k, uint32_t ex) { big_seg_off[k] = ex; });
   if (threadIdx.x == 0) {
-    uint32_t rn = 0, rs = 0;
-    for (uint32_t t = 0; t < PART_THREADS; ++t) {
-      const uint32_t a = part_n[t], b = part_s[t];
-      part_n[t] = rn;
-      part_s[t] = rs;
-      rn += a;
-      rs += b;
-    }
-    plan->n_big = rn;
-    plan->total_seg = rs;
-  }
-  __syncthreads();
-  uint32_t k = part_n[threadIdx.x], so = part_s[threadIdx.x];
-  for (uint32_t col = c0; col < c1; ++col) {
-    const uint32_t cnt = bin_start[col + 1] - bin_start[col];
-    if (cnt > BIG_SEG) {
-      big_col[k] = col;
-      big_seg_off[k] = so;
-      ++k;
-      so += (cnt + BIG_SEG - 1) / BIG_SEG;
-    }
+    plan->n_big = n_big;
+    plan->total_seg = n_seg;
   }
 }
 
@@ -994,32 +957,12 @@ constexpr uint32_t MSM_HEAVY_LANES = 64;   // one wave per segment: 64 strided p
 
 __global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __restrict__ sizes_sorted, uint32_t hb, uint32_t heavy,
                                                              uint32_t* __restrict__ item_off /* hb + 1 */) {
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (hb + 1023) / 1024;
-  const uint32_t lo = threadIdx.x * per, hi = lo + per < hb ? lo + per : hb;
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; ++i) {
-    uint32_t sz = sizes_sorted[i];
-    sum += sz > heavy ? (sz + MSM_HEAVY_SEG - 1) / MSM_HEAVY_SEG : 0;
-  }
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t t = 0; t < 1024; ++t) {
-      uint32_t v = part[t];
-      part[t] = run;
-      run += v;
-    }
-    item_off[hb] = run;
-  }
-  __syncthreads();
-  uint32_t run = part[threadIdx.x];
-  for (uint32_t i = lo; i < hi; ++i) {
-    item_off[i] = run;
-    uint32_t sz = sizes_sorted[i];
-    run += sz > heavy ? (sz + MSM_HEAVY_SEG - 1) / MSM_HEAVY_SEG : 0;
-  }
+  __shared__ uint32_t scratch[32];
+  const uint32_t tot = block_scan_long(hb, scratch, [&](uint32_t i) {
+    const uint32_t sz = sizes_sorted[i];
+    return sz > heavy ? (sz + MSM_HEAVY_SEG - 1) / MSM_HEAVY_SEG : 0u;
+  }, [&](uint32_t i, uint32_t ex) { item_off[i] = ex; });
+  if (threadIdx.x == 0) item_off[hb] = tot;
 }
 
 template <class F>
@@ -1566,12 +1509,17 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     // the big bins (none for uniform exponents up to 2^26 points: the surplus workgroups of these launches exit at once)
     const uint32_t max_seg = (uint32_t)(2 * (m / BIG_SEG) + 2);
     hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
-    const uint32_t big_grid = max_seg < 2048u ? max_seg : 2048u;
+    // (small grids: when there is no big bin -- uniform exponents -- the launches only cost their workgroups' start-up, and the
+    // place kernel's LDS allows one workgroup per CU anyway)
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t big_grid = max_seg < 2u * (uint32_t)n_cu ? max_seg : 2u * (uint32_t)n_cu;
+    const uint32_t place_grid = max_seg < (uint32_t)n_cu ? max_seg : (uint32_t)n_cu;
     hipLaunchKernelGGL(msm_bigbin_count_kernel, dim3(big_grid), dim3(PART_THREADS), (size_t)nfl * 4, st, pairs, bin_start, big_plan, big_col, big_seg,
                        G.nb, P, gcnt);
     const size_t place_fixed = (size_t)(4 * nfl + 32) * 4, place_staged = place_fixed + (size_t)BIG_SEG * 4;
     const int staged = place_staged <= PART_LDS_MAX ? 1 : 0;
-    hipLaunchKernelGGL(msm_bigbin_place_kernel, dim3(big_grid), dim3(PART_THREADS), staged ? place_staged : place_fixed, st, pairs, bin_start, out_start,
+    hipLaunchKernelGGL(msm_bigbin_place_kernel, dim3(staged ? place_grid : big_grid), dim3(PART_THREADS), staged ? place_staged : place_fixed, st, pairs, bin_start, out_start,
                        big_plan, big_col, big_seg, G.nb, P, staged, gcnt, gcur, first, last, vals_b);
   }
   ZK_HIP(hipGetLastError());
