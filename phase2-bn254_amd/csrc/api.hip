@@ -265,17 +265,31 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
   zbuf[i] = r.z;
 }
 
-// G2 (memory-format Fq2 arithmetic, curve.hpp): the same fixed signed 4-bit windows on a JACOBIAN accumulator
-// (doubling 2M + 5S against XYZZ's 6M + 3S; 254 doublings + ~60 full additions + the table against 254 x (doubling +
-// mixed addition) when lanes diverge).  Table build and main loop run through ONE loop with a single inlined
-// jac_double and a single inlined jac_add: the Fq2 group law is > 100 KB of code per copy.
-//   step = (load entry, double?, add entry, store entry); entries 1..8 hold 1P..8P, 0 = none.
-template <class F>
-__global__ void __launch_bounds__(256) batch_exp_win_std_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
-                                                               const uint32_t* __restrict__ scalars, int same_scalar, uint64_t i0,
-                                                               uint64_t n_chunk, const uint32_t* __restrict__ base_index,
-                                                               F* __restrict__ zbuf, Jacobian<F>* __restrict__ tab,
-                                                               const uint32_t* __restrict__ term_list, const uint32_t* __restrict__ term_count) {
+// G2: the same fixed signed 4-bit windows on the U-form Fq2 Jacobian accumulator of curveu.hpp (JacU2: 29-bit lazy limbs, one
+// v_mad_u64_u32 per partial product, shared Montgomery reductions) -- round 1 ran this on memory-format Fq2 at 9 Mpoint/s.
+// Table build and main loop run through ONE loop with a single inlined jacu2_double and a single inlined jacu2_add_tab: the Fq2
+// group law is > 100 KB of code per copy.
+//   step = (load entry, double?, add entry, store entry); entries 1..8 hold 1P..8P (with Z^2, Z^3), 0 = none.
+__device__ __forceinline__ JacTabU2 tabu2_load(const JacTabU2* p) {
+  JacTabU2 r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(JacTabU2) / 16); ++i) d[i] = q[i];
+  return r;
+}
+__device__ __forceinline__ void tabu2_store(JacTabU2* p, const JacTabU2& v) {
+  const uint4* s = reinterpret_cast<const uint4*>(&v);
+  uint4* d = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(JacTabU2) / 16); ++i) d[i] = s[i];
+}
+
+__global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __restrict__ out, const Affine<Fq2>* __restrict__ bases, int same_base,
+                                                              const uint32_t* __restrict__ scalars, int same_scalar, uint64_t i0,
+                                                              uint64_t n_chunk, const uint32_t* __restrict__ base_index,
+                                                              Fq2* __restrict__ zbuf, JacTabU2* __restrict__ tab,
+                                                              const uint32_t* __restrict__ term_list, const uint32_t* __restrict__ term_count) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunk) return;
   uint64_t i = i0 + t;
@@ -287,10 +301,10 @@ __global__ void __launch_bounds__(256) batch_exp_win_std_kernel(Affine<F>* __res
   const uint32_t* sp = scalars + (same_scalar ? 0 : i * 8);
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = sp[l];
-  const Affine<F> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
-  Jacobian<F> acc{F::zero(), F::zero(), F::zero()};
+  const Affine<Fq2> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
+  JacU2 acc = JacU2::zero();
   if (!base.is_zero()) {
-    tab[t] = Jacobian<F>{base.x, base.y, F::one()};
+    tabu2_store(tab + t, jacu2_tab_from_affine(base.x, base.y));
     uint32_t mag[8], sgn[2] = {0, 0};  // signed digits d_j in [-8, 8]: k = sum d_j 16^j
     uint32_t carry = 0;
 #pragma unroll
@@ -321,25 +335,25 @@ __global__ void __launch_bounds__(256) batch_exp_win_std_kernel(Affine<F>* __res
         store = pr & 15u;
       } else {
         const int m = step - 7;        // 256 doublings; after the 4th of each window the window's digit is added
-        if (m == 0) acc = Jacobian<F>{F::zero(), F::zero(), F::zero()};
+        if (m == 0) acc = JacU2::zero();
         if ((m & 3) == 3) {
           const int j = 63 - (m >> 2);
           add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
           negate = (sgn[j >> 5] >> (j & 31)) & 1u;
         }
       }
-      if (load) acc = tab[(uint64_t)(load - 1) * n_chunk + t];
-      if (dbl_it) jac_double(acc);
-      if (add) {
-        Jacobian<F> o = tab[(uint64_t)(add - 1) * n_chunk + t];
-        if (negate) o.y = neg(o.y);
-        jac_add(acc, o);
+      if (load) {
+        const JacTabU2 e = tabu2_load(tab + (uint64_t)(load - 1) * n_chunk + t);
+        acc = JacU2{e.x, e.y, e.z};
       }
-      if (store) tab[(uint64_t)(store - 1) * n_chunk + t] = acc;
+      if (dbl_it) acc = jacu2_double(acc);
+      if (add) jacu2_add_tab(acc, tabu2_load(tab + (uint64_t)(add - 1) * n_chunk + t), negate != 0);
+      if (store) tabu2_store(tab + (uint64_t)(store - 1) * n_chunk + t, jacu2_tab_entry(acc));
     }
   }
-  out[i] = Affine<F>{acc.x, acc.y};
-  zbuf[i] = acc.z;
+  const Jacobian<Fq2> r = jacu2_to_std(acc);
+  out[i] = Affine<Fq2>{r.x, r.y};
+  zbuf[i] = r.z;
 }
 
 // io[i] = (X, Y) of a Jacobian point whose Z is z[i]  ->  the affine record (X / Z^2, Y / Z^3); Z == 0 -> all-zero record.
@@ -521,7 +535,7 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
     const bool shortcut = shortcut_unit_scalars && !same_scalar && !same_base;
     const size_t list_bytes = shortcut ? ((n + 1) * 4 + 255) & ~(size_t)255 : 0;
     void* p = nullptr;
-    int rc = exp_scratch(z_bytes + list_bytes + (size_t)EXP_TAB * chunk * sizeof(Jacobian<F>), stream, &p);
+    int rc = exp_scratch(z_bytes + list_bytes + (size_t)EXP_TAB * chunk * sizeof(JacTabU2), stream, &p);
     if (rc) return rc;
     F* zbuf = (F*)p;
     uint32_t* list = shortcut ? (uint32_t*)((char*)p + z_bytes) : nullptr;
@@ -530,12 +544,12 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
       hipLaunchKernelGGL(exp_classify_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, zbuf, (const Affine<F>*)d_bases,
                          (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list);
     }
-    Jacobian<F>* tab = (Jacobian<F>*)((char*)p + z_bytes + list_bytes);
+    JacTabU2* tab = (JacTabU2*)((char*)p + z_bytes + list_bytes);
     for (size_t i0 = 0; i0 < n; i0 += chunk) {
       const size_t m = n - i0 < chunk ? n - i0 : chunk;
-      hipLaunchKernelGGL(batch_exp_win_std_kernel<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out,
-                         (const Affine<F>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
-                         zbuf, tab, shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
+      hipLaunchKernelGGL(batch_exp_win_u2_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq2>*)d_out,
+                         (const Affine<Fq2>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
+                         (Fq2*)zbuf, tab, shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
     }
     ZK_HIP(hipGetLastError());
     constexpr int K = 8;

@@ -408,4 +408,137 @@ ZK_HD void xyzzu2_add_mixed(XYZZU2& acc, const Fq2& x2s, const Fq2& y2s, bool ne
   acc.zzz = zzz3;
 }
 
+// =================================================================================================
+// G2 Jacobian accumulator on U-form Fq2, for SCALAR MULTIPLICATION (batch_exp, the terms of the QAP sums): the G1 design above,
+// componentwise.  Fq2 squaring is (a0 + a1)(a0 - a1) + 2 a0 a1 u (two products), an Fq2 product two fused pairs (f2u_mul), and
+// the two "r (V - X3) - 2 S1 J"-shaped lines take ONE Montgomery reduction per component (u_mul3 / u_mul4).
+//   Invariants (N-form, per component):  X < 7p,  Y <= 3p,  Z < 3p;   infinity is Z == literal zero limbs.
+//   Every coordinate lives in the 2^261 domain.  c = p / 2^261 < 0.006:  u_mul(a, b) < (a/p)(b/p) c p + p.
+struct JacU2 {
+  Fq2U x, y, z;
+  ZK_HD static JacU2 zero() { return JacU2{Fq2U::zero(), Fq2U::zero(), Fq2U::zero()}; }
+  ZK_HD bool is_zero() const { return z.limbs_all_zero(); }
+};
+
+ZK_HD Fq2U f2u_carry(const Fq2U& a) { return Fq2U{u_carry(a.c0), u_carry(a.c1)}; }
+ZK_HD Fq2U f2u_dbl(const Fq2U& a) { return Fq2U{u_dbl(a.c0), u_dbl(a.c1)}; }
+ZK_HD Fq2U f2u_add(const Fq2U& a, const Fq2U& b) { return Fq2U{u_add(a.c0, b.c0), u_add(a.c1, b.c1)}; }
+// a^2; a N-form, K bounds value(a.c1) <= K p.   c0 < (va0 + va1)(va0 + K) c + 1,  c1 < 2 va0 va1 c + 1.
+template <int K>
+ZK_HD Fq2U f2u_sqr(const Fq2U& a) {
+  return Fq2U{u_mul(u_carry(u_add(a.c0, a.c1)), u_sub<K, 1>(a.c0, a.c1)), u_mul(u_dbl(a.c0), a.c1)};
+}
+
+// 2 * a   [dbl-2009-l, D = 4 X B as a product like jacu_double]
+ZK_HD JacU2 jacu2_double(const JacU2& a) {
+  if (a.is_zero()) return a;
+  const Fq2U A = f2u_sqr<8>(a.x);                            // X1 < 7 <= 8:  c0 < 14*15c + 1 < 2.26p,  c1 < 98c + 1 < 1.59p
+  const Fq2U B = f2u_sqr<4>(a.y);                            // Y1 <= 3 <= 4:  c0 < 6*7c + 1 < 1.26p,  c1 < 18c + 1 < 1.11p
+  const Fq2U C = f2u_sqr<2>(B);                              // < 1.05p
+  const Fq2U X4 = f2u_carry(f2u_dbl(f2u_dbl(a.x)));          // 4X < 28p, N
+  const Fq2U D = f2u_mul<2>(X4, B);                          // B1 < 1.11 <= 2:  c0 < (28*1.26 + 28*2)c + 1 < 1.55p,  c1 < 1.40p
+  const Fq2U E = f2u_carry(f2u_add(f2u_dbl(A), A));          // 3A < 6.8p, N
+  const Fq2U F = f2u_sqr<8>(E);                              // c0 < 13.6*14.8c + 1 < 2.21p,  c1 < 1.56p
+  JacU2 r;
+  r.x = Fq2U{u_sub<4, 2>(F.c0, u_dbl(D.c0)), u_sub<4, 2>(F.c1, u_dbl(D.c1))};   // 2D < 3.1p <= 4p, limbs < 2^30;  X3 < 6.21p
+  const Fq2U dmx = f2u_sub<8>(D, r.x);                       // X3 <= 8p;  < 9.55p, N
+  const Fq2U negc = f2u_sub<2>(Fq2U::zero(), C);             // 2p - C in (0, 2p], N
+  const FqU nd1 = u_sub<16, 1>(FqU::zero(), dmx.c1);         // 16p - d1
+  const FqU c8 = UPow2<FqParams, 264>::get();                // 8 * 2^261:  negc * c8 / 2^261 = -8C
+  r.y.c0 = u_mul3(E.c0, dmx.c0, E.c1, nd1, negc.c0, c8);     // E (D - X3) - 8C:  (64.9 + 108.8 + 2)c + 1 < 2.06p
+  r.y.c1 = u_mul3(E.c0, dmx.c1, E.c1, dmx.c0, negc.c1, c8);  // (64.9 + 64.9 + 2)c + 1 < 1.80p
+  r.z = f2u_mul<4>(f2u_carry(f2u_dbl(a.y)), a.z);            // 2 Y Z:  2Y <= 6p, Z1 < 3 <= 4:  (18 + 24)c + 1 < 1.26p
+  return r;
+}
+
+// A table entry for windowed scalar multiplication: the point with Z^2 and Z^3 (80 words used of 92: 368 bytes).
+struct alignas(16) JacTabU2 {
+  Fq2U x, y, z, zz, zzz;
+  uint32_t pad[2];
+};
+ZK_HD JacTabU2 jacu2_tab_entry(const JacU2& q) {
+  JacTabU2 t;
+  t.x = q.x;
+  t.y = q.y;
+  t.z = q.z;
+  t.zz = f2u_sqr<4>(q.z);                                    // Z < 3 <= 4:  < 1.26p, < 1.11p
+  t.zzz = f2u_mul<2>(q.z, t.zz);                             // ZZ1 < 1.11 <= 2:  (3*1.26 + 3*2)c + 1 < 1.06p
+  t.pad[0] = t.pad[1] = 0;
+  return t;
+}
+
+// acc += (+/-) t;  t != infinity   [add-2007-bl with the entry's Z^2, Z^3 given]
+ZK_HD void jacu2_add_tab(JacU2& acc, const JacTabU2& t, bool negate) {
+  Fq2U y2 = t.y;
+  {
+    const Fq2U ny = f2u_sub<3>(Fq2U::zero(), t.y);           // 3p - Y2 in [0, 3p], N   (Y2 <= 3p)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      y2.c0.l[i] = negate ? ny.c0.l[i] : t.y.c0.l[i];
+      y2.c1.l[i] = negate ? ny.c1.l[i] : t.y.c1.l[i];
+    }
+  }
+  if (acc.is_zero()) {
+    acc.x = t.x;
+    acc.y = y2;
+    acc.z = t.z;
+    return;
+  }
+  const Fq2U z1z1 = f2u_sqr<4>(acc.z);                       // < 1.26p, < 1.11p
+  const Fq2U u1 = f2u_mul<2>(acc.x, t.zz);                   // (7*1.26 + 7*2)c + 1 < 1.14p
+  const Fq2U u2 = f2u_mul<2>(t.x, z1z1);                     // < 1.14p
+  const Fq2U s1 = f2u_mul<2>(acc.y, t.zzz);                  // (3*1.06 + 3*2)c + 1 < 1.06p
+  const Fq2U s2 = f2u_mul<2>(y2, f2u_mul<2>(acc.z, z1z1));   // Z1^3 < 1.06p;  < 1.06p
+  const Fq2U h = f2u_sub<2>(u2, u1);                         // < 3.14p, N
+  const Fq2U hh = f2u_sqr<4>(h);                             // H1 < 3.14 <= 4:  c0 < 6.28*7.14c + 1 < 1.27p,  c1 < 1.12p
+  const Fq2U i4 = f2u_carry(f2u_dbl(f2u_dbl(hh)));           // I = 4 HH < 5.1p, N
+  const Fq2U j = f2u_mul<8>(h, i4);                          // I1 < 4.5 <= 8:  (3.14*5.1 + 3.14*8)c + 1 < 1.25p
+  const Fq2U r = f2u_carry(f2u_dbl(f2u_sub<2>(s2, s1)));     // 2 (S2 - S1 + 2p) < 6.12p, N
+  const Fq2U v = f2u_mul<8>(u1, i4);                         // < 1.09p
+  const Fq2U rr = f2u_sqr<8>(r);                             // r1 < 6.12 <= 8:  c0 < 12.24*14.12c + 1 < 2.04p,  c1 < 1.45p
+  Fq2U x3;                                                   // r^2 - J - 2V:  J + 2V < 3.43p <= 4p, limbs < 3 * 2^29;  X3 < 6.04p
+  x3.c0 = u_sub<4, 3>(rr.c0, u_add(j.c0, u_dbl(v.c0)));
+  x3.c1 = u_sub<4, 3>(rr.c1, u_add(j.c1, u_dbl(v.c1)));
+  const Fq2U vmx = f2u_sub<8>(v, x3);                        // < 9.09p, N
+  const FqU nvmx1 = u_sub<16, 1>(FqU::zero(), vmx.c1);       // 16p - (V - X3)_1
+  const FqU n2s0 = u_sub<4, 2>(FqU::zero(), u_dbl(s1.c0));   // 4p - 2 S1_0 in (0, 4p], N
+  const FqU n2s1 = u_sub<4, 2>(FqU::zero(), u_dbl(s1.c1));
+  const FqU p2s1 = u_carry(u_dbl(s1.c1));                    // 2 S1_1 < 2.12p, N
+  Fq2U y3;                                                   // r (V - X3) - 2 S1 J
+  y3.c0 = u_mul4(r.c0, vmx.c0, r.c1, nvmx1, n2s0, j.c0, p2s1, j.c1);   // (55.6 + 97.9 + 5 + 2.7)c + 1 < 1.97p
+  y3.c1 = u_mul4(r.c0, vmx.c1, r.c1, vmx.c0, n2s0, j.c1, n2s1, j.c0);  // (55.6 + 55.6 + 5 + 5)c + 1 < 1.73p
+  const Fq2U z3 = f2u_mul<4>(f2u_mul<4>(f2u_carry(f2u_dbl(acc.z)), t.z), h);   // 2 Z1 Z2 < 1.26p;  times H (H1 < 3.14 <= 4):  < 1.06p
+  if (u_is_zero_lt2p(z3.c0) && u_is_zero_lt2p(z3.c1)) {
+    // H == 0: same x.  Same point -> double; opposite -> infinity (ec.rs:398-408).
+    if (u_is_zero_lt8p(r.c0) && u_is_zero_lt8p(r.c1)) acc = jacu2_double(JacU2{t.x, y2, t.z});
+    else acc = JacU2::zero();
+    return;
+  }
+  acc.x = x3;
+  acc.y = y3;
+  acc.z = z3;
+}
+
+// raw affine point (memory format, not infinity) -> table entry of 1 * P in the 2^261 domain
+ZK_HD JacTabU2 jacu2_tab_from_affine(const Fq2& x, const Fq2& y) {
+  const FqU C = UPow2<FqParams, 266>::get();                 // x*2^256 * 2^266 / 2^261 = x * 2^261
+  JacU2 q;
+  q.x = Fq2U{u_mul(u_from_std(x.c0), C), u_mul(u_from_std(x.c1), C)};   // < 2p
+  q.y = Fq2U{u_mul(u_from_std(y.c0), C), u_mul(u_from_std(y.c1), C)};
+  q.z = Fq2U{UPow2<FqParams, 261>::get(), FqU::zero()};      // one
+  return jacu2_tab_entry(q);
+}
+
+// accumulator -> memory-format Jacobian (canonical coordinates, 2^256 domain); infinity -> z == 0 (x, y zero too)
+ZK_HD Jacobian<Fq2> jacu2_to_std(const JacU2& a) {
+  Jacobian<Fq2> r{Fq2::zero(), Fq2::zero(), Fq2::zero()};
+  if (a.is_zero()) return r;
+  const FqU c256 = UPow2<FqParams, 256>::get();              // v*2^261 * 2^256 / 2^261 = v * 2^256
+  auto cv = [&](const Fq2U& v) { return Fq2{u_to_std_lt2p(u_mul(v.c0, c256)), u_to_std_lt2p(u_mul(v.c1, c256))}; };
+  r.x = cv(a.x);
+  r.y = cv(a.y);
+  r.z = cv(a.z);
+  return r;
+}
+
 }  // namespace zk

@@ -210,6 +210,42 @@ int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const u
   return ZK_OK;
 }
 
+// k * P for ONE G2 point on the HOST with the program batch_exp_win_u2_kernel runs (table 1P..8P, signed 4-bit windows, 256
+// doublings) on the U-form Fq2 Jacobian arithmetic of curveu.hpp.  out = memory-format Jacobian X, Y, Z (24 u64).
+int mi355zk_selftest_g2_scalar_mul_u(const uint64_t affine_pt[16], const uint64_t scalar[4], uint64_t out_xyz[24]) {
+  if (!affine_pt || !scalar || !out_xyz) return ZK_ERR_BAD_ARGS;
+  zk::G2Affine base;
+  std::memcpy(&base, affine_pt, 128);
+  uint32_t s[8];
+  std::memcpy(s, scalar, 32);
+  zk::JacU2 acc = zk::JacU2::zero();
+  if (!base.is_zero()) {
+    zk::JacTabU2 tab[8];
+    tab[0] = zk::jacu2_tab_from_affine(base.x, base.y);
+    for (int e = 2; e <= 8; ++e) {
+      const zk::JacTabU2& src = tab[(e & 1) ? e - 2 : e / 2 - 1];
+      zk::JacU2 q{src.x, src.y, src.z};
+      if (e & 1) zk::jacu2_add_tab(q, tab[0], false);
+      else q = zk::jacu2_double(q);
+      tab[e - 1] = zk::jacu2_tab_entry(q);
+    }
+    int dig[65];
+    uint32_t carry = 0;
+    for (int j = 0; j < 64; ++j) {
+      uint32_t d = ((s[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
+      carry = d > 8u ? 1u : 0u;
+      dig[j] = carry ? (int)d - 16 : (int)d;
+    }
+    for (int j = 63; j >= 0; --j) {
+      for (int rep = 0; rep < 4; ++rep) acc = zk::jacu2_double(acc);
+      if (dig[j]) zk::jacu2_add_tab(acc, tab[(dig[j] < 0 ? -dig[j] : dig[j]) - 1], dig[j] < 0);
+    }
+  }
+  const zk::Jacobian<zk::Fq2> r = zk::jacu2_to_std(acc);
+  std::memcpy(out_xyz, &r, sizeof r);
+  return ZK_OK;
+}
+
 int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 0); }
 int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 1); }
 int mi355zk_bn254_fr_into_repr_dev(void* d_out, const void* d_in, size_t n, void* stream) {

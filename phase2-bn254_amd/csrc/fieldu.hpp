@@ -348,6 +348,25 @@ ZK_HD FpU<PR> u_mul2(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const
   });
 }
 
+// (a*b + c*d + e*f) * 2^-261 mod p with ONE Montgomery reduction.
+//   preconditions: all six operands N-form (27 products < 2^58 plus the Montgomery terms < 2^63.3 per column);
+//   result: N-form, value < (sum of the three value products) / 2^261 + p.
+template <class PR>
+ZK_HD FpU<PR> u_mul3(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const FpU<PR>& d, const FpU<PR>& e, const FpU<PR>& f) {
+  return u_montgomery_columns<PR>([&](auto kc, uint64_t& acc) {
+    constexpr int k = decltype(kc)::value;
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) {
+        u_mad(acc, a.l[i], b.l[j]);
+        u_mad(acc, c.l[i], d.l[j]);
+        u_mad(acc, e.l[i], f.l[j]);
+      }
+    });
+  });
+}
+
 // (a*b + c*d + e*f + g*h) * 2^-261 mod p with ONE Montgomery reduction (Fq2 products of sums).
 //   preconditions: all eight operands N-form: 36 products < 2^58 plus the Montgomery terms < 2^63.6 per column;
 //   result: N-form, value < (sum of the four value products) / 2^261 + p.

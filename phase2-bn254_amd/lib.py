@@ -59,6 +59,7 @@ SIGNATURES = {
     "mi355zk_selftest_u_pack": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mi355zk_selftest_u_reduce32": (_i, [_i, _vp, _vp]),
     "mi355zk_selftest_g1_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "mi355zk_selftest_g2_scalar_mul_u": (_i, [_vp, _vp, _vp]),
     "mi355zk_selftest_g2_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_bn254_g2_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),

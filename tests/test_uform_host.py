@@ -210,3 +210,18 @@ def test_g2_u_accumulation_long_chain(lib):
         assert lib.mi355zk_selftest_g2_accumulate(mode, raw.ctypes.data, neg.ctypes.data, n, out.ctypes.data) == 0
         outs.append(_xyzz2_to_affine(out))
     assert outs[0] == outs[1] and outs[0] is not None
+
+
+def test_g2_scalar_mul_on_u_form_jacobian_host(lib):
+    """The U-form Fq2 Jacobian arithmetic (jacu2_double, jacu2_add_tab, table entries) run on the HOST through the same
+    windowed program as batch_exp_win_u2_kernel, against the oracle's mul_assign + into_affine: random scalars, 0, 1, 2, r - 1,
+    digits that hit every table entry and both signs."""
+    pts = inputs.bases_progression_cpu(2, 6, seed=77)
+    ks = [0, 1, 2, 8, 9, 0x8888, 0xFFFFFFFF, M.R_ORDER - 1, M.R_ORDER - 2] + [rnd.randrange(M.R_ORDER) for _ in range(12)]
+    for idx, k in enumerate(ks):
+        p = pts[idx % len(pts)]
+        kl = np.array(M.to_limbs(k), dtype=np.uint64)
+        out = np.zeros(24, np.uint64)
+        assert lib.mi355zk_selftest_g2_scalar_mul_u(p.ctypes.data, kl.ctypes.data, out.ctypes.data) == 0
+        want = O.G2.to_affine(O.G2.mul(O.G2.from_affine(p), kl))
+        assert np.array_equal(O.G2.to_affine(out), want), hex(k)
