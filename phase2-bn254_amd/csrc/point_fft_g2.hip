@@ -5,14 +5,15 @@
 // Same network and the same program as point_fft.hip (G1): bit-reversed load into a working array of JACOBIAN
 // points, one lane per butterfly per stage, the twiddle multiplication by fixed signed 4-bit windows over a per-lane
 // table {1..8} * t in scratch ([entry][lane]) so that the lanes of a wave add at the same places, affine raw records
-// (128 B, all-zero = infinity) in and out with one inversion per 8 points.  The group law runs on the memory-format
-// Fq2 arithmetic (curve.hpp / field.hpp); table build, doublings and the closing u + t / u - t share ONE inlined
-// jac_double and ONE inlined jac_add (the Fq2 group law is > 100 KB of gfx950 code per copy, and out-of-line calls
-// with these operands go through scratch and crawl).
+// (128 B, all-zero = infinity) in and out with one inversion per 8 points.  The group law runs on the U-form Fq2 Jacobian
+// arithmetic of curveu.hpp (JacU2: 29-bit lazy limbs, 2^261 domain; round 1 ran the memory-format Fq2 formulas at half the
+// rate): the working array holds U-form points between the stages; table build, doublings and the closing u + t / u - t share
+// ONE inlined jacu2_double and ONE inlined jacu2_add_tab (the Fq2 group law is > 100 KB of gfx950 code per copy, and
+// out-of-line calls with these operands go through scratch and crawl).
 #include <hip/hip_runtime.h>
 
 #include "../../include/mi355zk.h"
-#include "curve.hpp"
+#include "curveu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -22,40 +23,54 @@ int batch_normalize_g2(void* d_io_affine, const void* d_z, uint64_t n, hipStream
 
 namespace {
 
-using J2 = Jacobian<Fq2>;
+struct alignas(16) J2 {   // a working-array point: U-form Jacobian, 216 bytes + padding to whole 16-byte words
+  JacU2 p;
+  uint32_t pad[2];
+};
+static_assert(sizeof(J2) == 224 && sizeof(JacTabU2) % 16 == 0, "16-byte copies");
 
-__device__ __forceinline__ J2 j2_load(const J2* p) {
-  J2 r;
+template <class T>
+__device__ __forceinline__ T v_load(const T* p) {
+  T r;
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint4* d = reinterpret_cast<uint4*>(&r);
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(J2) / 16); ++i) d[i] = q[i];
+  for (int i = 0; i < (int)(sizeof(T) / 16); ++i) d[i] = q[i];
   return r;
 }
-__device__ __forceinline__ void j2_store(J2* p, const J2& v) {
+template <class T>
+__device__ __forceinline__ void v_store(T* p, const T& v) {
   const uint4* s = reinterpret_cast<const uint4*>(&v);
   uint4* d = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(J2) / 16); ++i) d[i] = s[i];
+  for (int i = 0; i < (int)(sizeof(T) / 16); ++i) d[i] = s[i];
 }
-__device__ __forceinline__ J2 j2_zero() { return J2{Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+__device__ __forceinline__ J2 j2_of(const JacU2& q) {
+  J2 r;
+  r.p = q;
+  r.pad[0] = r.pad[1] = 0;
+  return r;
+}
 
 __global__ void __launch_bounds__(256) pfft2_load_kernel(const G2Affine* __restrict__ in, J2* __restrict__ work, uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
   G2Affine a = in[i];
-  J2 v = j2_zero();
-  if (!a.is_zero()) v = J2{a.x, a.y, Fq2::one()};
+  JacU2 v = JacU2::zero();
+  if (!a.is_zero()) {
+    const JacTabU2 e = jacu2_tab_from_affine(a.x, a.y);    // (x, y, one) in the 2^261 domain
+    v = JacU2{e.x, e.y, e.z};
+  }
   uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0;
-  j2_store(work + r, v);
+  v_store(work + r, j2_of(v));
 }
 
-// The program of point_fft.hip's pfft_stage_kernel, on memory-format Jacobian points:
+// The program of point_fft.hip's pfft_stage_kernel, on U-form Jacobian points:
 //   steps 0..6 table (2t .. 8t), steps 7..262 the 256 doublings with a digit addition after every 4th,
 //   step 263 entry 1 := product, steps 264 / 265: a[i0] = u + product, a[i1] = u - product   (mode 0, domain.rs:303-309)
 //   mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173)
 __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
-                                                         uint32_t s, uint64_t b0, uint64_t n_chunk, J2* __restrict__ tab, int mode, Fr c) {
+                                                         uint32_t s, uint64_t b0, uint64_t n_chunk, JacTabU2* __restrict__ tab, int mode, Fr c) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunk) return;
   const uint64_t b = b0 + t;
@@ -75,8 +90,8 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
 #pragma unroll
     for (int l = 0; l < 8; ++l) kk[l] = c.l[l];
   }
-  const J2 u = mode == 0 ? j2_load(work + i0) : j2_zero();
-  J2 acc = j2_load(work + i1);
+  const JacU2 u = mode == 0 ? v_load(work + i0).p : JacU2::zero();
+  JacU2 acc = v_load(work + i1).p;
   // signed 4-bit digits: k = sum d_j 16^j, d_j in [-8, 8]
   uint32_t mag[8], sgn[2] = {0, 0};
   uint32_t carry = 0;
@@ -97,9 +112,9 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
   }
   const bool t_inf = acc.is_zero();
   if (t_inf && mode == 1) return;
-  j2_store(tab + t, acc);
+  if (!t_inf) v_store(tab + t, jacu2_tab_entry(acc));
   constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};  // nibbles: load, double, add, store
-  const int first = (unit || t_inf) ? 263 : 0;
+  const int first = (unit || t_inf) ? 264 : 0;   // twiddle one, or t = infinity: the product is t itself (entry 1 already holds it)
   const int last = mode == 0 ? 265 : 262;
 #pragma unroll 1
   for (int step = first; step <= last; ++step) {
@@ -112,7 +127,7 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
       store = pr & 15u;
     } else if (step < 263) {
       const int m = step - 7;
-      if (m == 0) acc = j2_zero();
+      if (m == 0) acc = JacU2::zero();
       dbl_it = 1;
       if ((m & 3) == 3) {
         const int j = 63 - (m >> 2);
@@ -120,31 +135,31 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
         negate = (sgn[j >> 5] >> (j & 31)) & 1u;
       }
     } else if (step == 263) {
-      store = 1;
+      store = acc.is_zero() ? 0u : 1u;   // (an infinite product: nothing to add below)
+      if (!store) { v_store(work + i0, j2_of(u)); v_store(work + i1, j2_of(u)); break; }
     } else {
       acc = u;
-      add = 1;
+      add = t_inf ? 0u : 1u;             // u +- infinity = u
       negate = step == 265;
     }
-    if (load) acc = j2_load(tab + (uint64_t)(load - 1) * n_chunk + t);
-    if (dbl_it) jac_double(acc);
-    if (add) {
-      J2 o = j2_load(tab + (uint64_t)(add - 1) * n_chunk + t);
-      if (negate) o.y = neg(o.y);
-      jac_add(acc, o);
+    if (load) {
+      const JacTabU2 e = v_load(tab + (uint64_t)(load - 1) * n_chunk + t);
+      acc = JacU2{e.x, e.y, e.z};
     }
-    if (store) j2_store(tab + (uint64_t)(store - 1) * n_chunk + t, acc);
-    if (step == 264) j2_store(work + i0, acc);
-    if (step == 265) j2_store(work + i1, acc);
+    if (dbl_it) acc = jacu2_double(acc);
+    if (add) jacu2_add_tab(acc, v_load(tab + (uint64_t)(add - 1) * n_chunk + t), negate != 0);
+    if (store) v_store(tab + (uint64_t)(store - 1) * n_chunk + t, jacu2_tab_entry(acc));
+    if (step == 264) v_store(work + i0, j2_of(acc));
+    if (step == 265) v_store(work + i1, j2_of(acc));
   }
-  if (mode == 1) j2_store(work + i0, acc);
+  if (mode == 1) v_store(work + i0, j2_of(acc));
 }
 
 __global__ void __launch_bounds__(256) pfft2_store_kernel(const J2* __restrict__ work, G2Affine* __restrict__ out, Fq2* __restrict__ zbuf,
                                                          uint32_t log_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
-  const J2 r = j2_load(work + i);
+  const Jacobian<Fq2> r = jacu2_to_std(v_load(work + i).p);
   out[i] = G2Affine{r.x, r.y};
   zbuf[i] = r.z;
 }
@@ -163,15 +178,15 @@ __global__ void pfft2_twiddle_kernel(uint32_t* tw, Fr omega, uint64_t count) {
 int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st) {
   const uint64_t n = 1ull << log_n;
   const uint64_t lanes_max = scale ? n : (n >= 2 ? n / 2 : 1);
-  const uint64_t chunk = lanes_max < (1ull << 19) ? lanes_max : (1ull << 19);  // table: 8 x 192 B per lane
+  const uint64_t chunk = lanes_max < (1ull << 19) ? lanes_max : (1ull << 19);  // table: 8 x 368 B per lane
   char* buf = nullptr;
   const size_t o_work = 0, o_tw = o_work + ((n * sizeof(J2) + 255) & ~(size_t)255), o_z = o_tw + (((n / 2 + 1) * 32 + 255) & ~(size_t)255),
-               o_tab = o_z + ((n * sizeof(Fq2) + 255) & ~(size_t)255), total = o_tab + 8 * chunk * sizeof(J2);
+               o_tab = o_z + ((n * sizeof(Fq2) + 255) & ~(size_t)255), total = o_tab + 8 * chunk * sizeof(JacTabU2);
   ZK_HIP(hipMalloc(&buf, total));
   J2* work = (J2*)(buf + o_work);
   uint32_t* tw = (uint32_t*)(buf + o_tw);
   Fq2* zbuf = (Fq2*)(buf + o_z);
-  J2* tab = (J2*)(buf + o_tab);
+  JacTabU2* tab = (JacTabU2*)(buf + o_tab);
   if (n >= 2) hipLaunchKernelGGL(pfft2_twiddle_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, tw, omega, n / 2);
   hipLaunchKernelGGL(pfft2_load_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const G2Affine*)d_points, work, log_n);
   for (uint32_t s = 0; s < log_n; ++s)
