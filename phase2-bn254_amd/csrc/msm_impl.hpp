@@ -201,8 +201,14 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
   }
   for (uint32_t w = 0; w < w_stop; ++w) {
     const uint32_t width = G.width[w], bit = G.shift[w];
-    uint32_t limb = bit >> 5, off = bit & 31;
-    uint64_t two = limb < 8 ? ((uint64_t)s[limb] | ((uint64_t)s[limb + 1] << 32)) : 0ull;
+    const uint32_t limb = bit >> 5, off = bit & 31;
+    // (static indices under a uniform condition: a dynamic s[limb] would move the whole array, in every path of the
+    // kernel, from registers to scratch memory)
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (limb == (uint32_t)l) { lo = s[l]; hi = s[l + 1]; }
+    const uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
     uint32_t d = ((uint32_t)(two >> off) & ((1u << width) - 1u)) + carry;
     uint32_t neg = 0;
     carry = 0;
@@ -380,6 +386,77 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
     for (uint32_t t = threadIdx.x; t < nword; t += PART_THREADS) row[t] = lh[t];
     __syncthreads();
   }
+}
+
+// pass A in two kernels (the default): a plain streaming digit kernel -- one scalar per lane, no LDS, any number of workgroups
+// in flight -- and the tile histograms taken from the keys it wrote.  The fused kernel above saves the 4 bytes per (point,
+// window) the histogram pass reads again, but its 1024-lane workgroups with a 61 KiB LDS histogram stream the scalars at under
+// half the rate of the plain kernel (2.75 ms against 1.1 + 0.7 ms at 2^26), and a multi-GPU rank that owns a few windows pays
+// the slow scalar stream in full.
+__global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* __restrict__ scalars, uint64_t n, const uint32_t* __restrict__ density,
+                                                              MsmGeom G, uint32_t w_lo, uint32_t w_hi, int scalars_mont, uint64_t kstride,
+                                                              uint32_t* __restrict__ keys, unsigned long long* __restrict__ err_scalar) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t WL = w_hi - w_lo;
+  bool active = true;
+  if (density != nullptr) active = (density[i >> 5] >> (i & 31)) & 1;
+  uint32_t s[9];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  const uint4 s0 = sp[0], s1 = sp[1];
+  s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w; s[8] = 0;
+  if (scalars_mont) {
+    Fr f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) f.l[l] = s[l];
+    f = to_canonical(f);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) s[l] = f.l[l];
+  }
+  const uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
+  if (active && (s[7] >> 30)) {   // not a canonical FrRepr: see msm_digits_hist_kernel
+    atomicMin(err_scalar, (unsigned long long)i);
+    active = false;
+  }
+  if (!active || any == 0) {
+    for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * kstride + i] = G.nb;
+    return;
+  }
+  msm_scalar_digits(s, G, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
+    if (w >= w_lo && w < w_hi) keys[(uint64_t)(w - w_lo) * kstride + i] = d ? ((d - 1) | neg) : G.nb;
+  });
+}
+
+// tile_hist[st][wl][bin] from the keys of (window wl, super-tile st): one workgroup each
+__global__ void __launch_bounds__(PART_THREADS) msm_tile_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint64_t kstride, uint32_t nb,
+                                                                     uint32_t WL, PartGeom P, uint16_t* __restrict__ tile_hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* lh = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t st = blockIdx.x % P.n_st, wl = blockIdx.x / P.n_st;
+  const uint64_t i0 = (uint64_t)st * P.st;
+  const uint32_t cnt = (uint32_t)(n - i0 < P.st ? n - i0 : P.st);
+  for (uint32_t t = threadIdx.x; t < P.nbin; t += PART_THREADS) lh[t] = 0;
+  __syncthreads();
+  const uint32_t* kp = keys + (uint64_t)wl * kstride + i0;
+  for (uint32_t idx = 4u * threadIdx.x; idx < cnt; idx += 4u * PART_THREADS) {
+    uint32_t v[4] = {nb, nb, nb, nb};
+    if (idx + 4 <= cnt) {
+      const uint4 q = *reinterpret_cast<const uint4*>(kp + idx);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      for (uint32_t e = 0; e < 4; ++e)
+        if (idx + e < cnt) v[e] = kp[idx + e];
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      const uint32_t b = v[e] & KEY_NONE_MASK;
+      if (b < nb) atomicAdd(&lh[b >> P.lo_bits], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t ncell = WL * P.nbin, stride = (ncell + 1u) & ~1u;
+  uint16_t* row = tile_hist + (uint64_t)st * stride + (uint64_t)wl * P.nbin;
+  for (uint32_t t = threadIdx.x; t < P.nbin; t += PART_THREADS) row[t] = (uint16_t)lh[t];
 }
 
 // column sums of tile_hist over one chunk of rows: csum[chunk][col]
@@ -1464,7 +1541,12 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   // "msm_sort" spans the whole partition after the digits (scan + scatter + bucket + size order), as it did for the library sort
   prof_begin(slot_digits, st);
-  {
+  static const bool fused_a = std::getenv("MI355ZK_PART_FUSED_A") != nullptr;  // (the one-kernel pass A, kept for the comparison in DESIGN.md)
+  if (!fused_a) {
+    hipLaunchKernelGGL(msm_digits_plain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, d_density, G, w_lo, w_hi,
+                       scalars_mont ? 1 : 0, kstride, keys, d_err + 1);
+    hipLaunchKernelGGL(msm_tile_hist_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)P.nbin * 4, st, keys, n, kstride, G.nb, WL, P, tile_hist);
+  } else {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t per_cu = (size_t)((ncell + 1) / 2) * 4 <= PART_LDS_A ? 2u : 1u;     // 1024-lane workgroups per CU (LDS histograms)
