@@ -956,7 +956,7 @@ inline void msm_order_by_size(const uint32_t* first, const uint32_t* last, uint3
 constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take the segment-parallel path (the rest of a pathological input runs one lane per bucket)
 
 // A4: the index list starts on a multiple of 4 entries, is walked with stride 1 and its padding slots are readable (the
-// lists the partition writes): a lane reads its indices FOUR AT A TIME with one 16-byte load, one group ahead.  Read one by
+// lists the partition writes): a lane reads its indices FOUR AT A TIME with one 16-byte load.  Read one by
 // one, a lane touches each 128-byte line of its list 32 times, ~10^4 instructions apart, and by then the line has usually
 // left the caches (64 lanes x 16 waves x 32 CUs share an L2 that 52 GB of bases stream through): 8 touches instead of 32.
 template <class F, bool A4 = false>
@@ -971,12 +971,12 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
     // The gather of point k+1 is issued, as four back-to-back 16-byte loads, before the ~2200 ALU instructions of
     // addition k: the four loads of a record then hit the same 128-byte line while it is still in cache (left to the
     // scheduler they drift apart to their uses and the line is fetched more than once: +22 % HBM traffic).
-    uint4 q = make_uint4(0, 0, 0, 0), qn = q;  // A4: this group of four indices (rotated so that q.x is the current one), the next group
+    // A4: this group of four indices, rotated so that q.x is the current one.  (A second group loaded one step ahead was
+    // measured too: it costs four more VGPRs -- 129, one over the 128 that allow four waves per SIMD.)
+    uint4 q = make_uint4(0, 0, 0, 0);
     uint32_t v;
     if constexpr (A4) {
       q = *reinterpret_cast<const uint4*>(vals + j);
-      qn = q;
-      if (j + 4 < e) qn = *reinterpret_cast<const uint4*>(vals + j + 4);
       v = q.x;
     } else {
       v = vals[j];
@@ -989,8 +989,7 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
       Affine<F> pn = p;
       if constexpr (A4) {
         if ((jn & 3u) == 0) {  // uniform over the wave: every lane started on a multiple of 4
-          q = qn;
-          if (jn + 4 < e) qn = *reinterpret_cast<const uint4*>(vals + jn + 4);
+          if (more) q = *reinterpret_cast<const uint4*>(vals + jn);
         } else {
           q.x = q.y; q.y = q.z; q.z = q.w;
         }

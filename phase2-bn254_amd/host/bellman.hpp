@@ -143,7 +143,62 @@ class EvaluationDomain {
   void ifft(const Worker&) { op(MI355ZK_OP_IFFT); }              // domain.rs:159
   void coset_fft(const Worker&) { op(MI355ZK_OP_COSET_FFT); }    // domain.rs:191
   void icoset_fft(const Worker&) { op(MI355ZK_OP_ICOSET_FFT); }  // domain.rs:197
+  // the elementwise steps of the prover's H pipeline (prover.rs:217-241).  This host-vector mirror uploads, runs the device
+  // op and downloads; a caller that keeps the polynomial in HBM calls the `_dev` entry points directly (prover.py does).
+  Fr z(const Fr& tau) const {                                    // domain.rs:207-212
+    Fr out{};
+    if (mi355zk_bn254_fr_domain_z(exp_, tau.data(), out.data()) != 0) throw SynthesisError(SynthesisError::Device);
+    return out;
+  }
+  void divide_by_z_on_coset(const Worker&) {                     // domain.rs:217-234
+    with_device([&](void* d) { return mi355zk_bn254_fr_divide_by_z_on_coset_dev(d, exp_, nullptr); });
+  }
+  void mul_assign(const Worker&, const EvaluationDomain& other) {  // domain.rs:236-249
+    if (other.coeffs_.size() != coeffs_.size()) throw std::logic_error("assertion failed: self.coeffs.len() == other.coeffs.len()");
+    pointwise(other, mi355zk_bn254_fr_mul_assign_dev);
+  }
+  void sub_assign(const Worker&, const EvaluationDomain& other) {  // domain.rs:251-260
+    if (other.coeffs_.size() != coeffs_.size()) throw std::logic_error("assertion failed: self.coeffs.len() == other.coeffs.len()");
+    pointwise(other, mi355zk_bn254_fr_sub_assign_dev);
+  }
+  // scalars_into_representations (prover.rs:110-129): Montgomery -> canonical, on the device
+  std::vector<FrRepr> into_representations() const {
+    std::vector<FrRepr> out(coeffs_.size());
+    void* d = nullptr;
+    if (mi355zk_malloc(&d, coeffs_.size() * 32) != 0) throw SynthesisError(SynthesisError::Device);
+    int rc = mi355zk_memcpy_h2d(d, coeffs_.data(), coeffs_.size() * 32);
+    if (rc == 0) rc = mi355zk_bn254_fr_into_repr_dev(d, d, coeffs_.size(), nullptr);
+    if (rc == 0) rc = mi355zk_sync(nullptr);
+    if (rc == 0) rc = mi355zk_memcpy_d2h(out.data(), d, coeffs_.size() * 32);
+    (void)mi355zk_free(d);
+    if (rc != 0) throw SynthesisError(SynthesisError::Device);
+    return out;
+  }
  private:
+  template <class Fn>
+  void with_device(Fn&& fn) {
+    void* d = nullptr;
+    if (mi355zk_malloc(&d, coeffs_.size() * 32) != 0) throw SynthesisError(SynthesisError::Device);
+    int rc = mi355zk_memcpy_h2d(d, coeffs_.data(), coeffs_.size() * 32);
+    if (rc == 0) rc = fn(d);
+    if (rc == 0) rc = mi355zk_sync(nullptr);
+    if (rc == 0) rc = mi355zk_memcpy_d2h(coeffs_.data(), d, coeffs_.size() * 32);
+    (void)mi355zk_free(d);
+    if (rc != 0) throw SynthesisError(SynthesisError::Device);
+  }
+  void pointwise(const EvaluationDomain& other, int (*fn)(void*, const void*, size_t, void*)) {
+    void* db = nullptr;
+    if (mi355zk_malloc(&db, coeffs_.size() * 32) != 0) throw SynthesisError(SynthesisError::Device);
+    int rc0 = mi355zk_memcpy_h2d(db, other.coeffs_.data(), coeffs_.size() * 32);
+    try {
+      if (rc0 != 0) throw SynthesisError(SynthesisError::Device);
+      with_device([&](void* d) { return fn(d, db, coeffs_.size(), nullptr); });
+    } catch (...) {
+      (void)mi355zk_free(db);
+      throw;
+    }
+    (void)mi355zk_free(db);
+  }
   void op(int which) {
     int rc = mi355zk_bn254_fr_domain_op(reinterpret_cast<uint64_t*>(coeffs_.data()), exp_, which);
     if (rc != 0) throw SynthesisError(SynthesisError::Device);

@@ -17,6 +17,8 @@ void oracle_g1_naive_multiexp(const uint64_t* bases, const uint64_t* scalars, si
 void oracle_g1_to_affine(uint64_t r[8], const uint64_t p[12]);
 int oracle_fr_domain_op(uint64_t* a, uint32_t log_n, int op, uint32_t log_cpus);
 void oracle_fe_from_canonical(int which, uint64_t r[4], const uint64_t a[4]);
+void oracle_fe_mul(int which, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]);
+void oracle_fe_sub(int which, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]);
 void oracle_g1_mul(uint64_t p[12], const uint64_t k[4]);
 void oracle_g1_from_affine(uint64_t r[12], const uint64_t p[8]);
 void oracle_g1_add(uint64_t p[12], const uint64_t o[12]);
@@ -96,6 +98,35 @@ int main() {
     for (auto& x : a) x = rand_scalar(gen);
     EvaluationDomain d = EvaluationDomain::from_coeffs(a);
     CHECK(d.exp() == 3 && d.as_ref().size() == 8 && d.as_ref()[7] == (Fr{0, 0, 0, 0}));
+  }
+  {  // the H pipeline's elementwise steps (prover.rs:217-241) and scalars_into_representations against oracle field arithmetic
+    const uint32_t log_n = 9;
+    std::vector<Fr> a((size_t)1 << log_n), b(a.size()), c(a.size());
+    for (auto& x : a) x = rand_scalar(gen);
+    for (auto& x : b) x = rand_scalar(gen);
+    for (auto& x : c) x = rand_scalar(gen);
+    EvaluationDomain da = EvaluationDomain::from_coeffs(a), db = EvaluationDomain::from_coeffs(b), dc = EvaluationDomain::from_coeffs(c);
+    da.mul_assign(worker, db);
+    da.sub_assign(worker, dc);
+    da.divide_by_z_on_coset(worker);
+    // want[i] = (a[i] b[i] - c[i]) * z(g)^-1 with g = 7:  z(g) * want[i] == a[i] b[i] - c[i]
+    uint64_t seven_c[4] = {7, 0, 0, 0}, seven[4];
+    oracle_fe_from_canonical(1, seven, seven_c);
+    Fr g{seven[0], seven[1], seven[2], seven[3]};
+    const Fr zg = da.z(g);
+    for (size_t i = 0; i < a.size(); i += 37) {
+      uint64_t ab[4], lhs[4], rhs[4];
+      oracle_fe_mul(1, ab, a[i].data(), b[i].data());
+      oracle_fe_sub(1, rhs, ab, c[i].data());
+      oracle_fe_mul(1, lhs, da.as_ref()[i].data(), zg.data());
+      CHECK(std::memcmp(lhs, rhs, 32) == 0);
+    }
+    const std::vector<FrRepr> reps = EvaluationDomain::from_coeffs(a).into_representations();
+    for (size_t i = 0; i < a.size(); i += 41) {
+      uint64_t back[4];
+      oracle_fe_from_canonical(1, back, reps[i].data());
+      CHECK(std::memcmp(back, a[i].data(), 32) == 0);
+    }
   }
   std::puts("ok evaluation_domain");
 
