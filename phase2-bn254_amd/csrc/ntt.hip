@@ -26,6 +26,7 @@
 #define ZK_CHAIN_MAD 1  // fieldu.hpp u_mad: one dependent mad chain per column (measured faster in this TU)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -411,6 +412,12 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     scratch = (Fr*)sb.p;
   }
 
+  // tile size: 4096 elements (144 KiB of LDS: one workgroup per CU).  2048-element tiles (two workgroups per CU, whose load /
+  // compute / store phases could overlap) were measured -- env MI355ZK_NTT_TILE=2048 -- and are 2-5 % SLOWER at 2^16 / 2^20 / 2^24:
+  // the pass is bound by VALU issue, not by the serialised phases.
+  static const char* env_tile = std::getenv("MI355ZK_NTT_TILE");
+  uint64_t tile_elems = NTT_TILE_ELEMS;
+  if (env_tile && (std::atoi(env_tile) == 2048 || std::atoi(env_tile) == 4096 || std::atoi(env_tile) == 1024)) tile_elems = (uint64_t)std::atoi(env_tile);
   // S[p] = prod_{q>p} N_q ; Tm[p] = prod_{q<p} N_q
   uint64_t S[3], Tm[3];
   for (int p = 0; p < R; ++p) {
@@ -433,7 +440,8 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     uint64_t tiles;
     if (p < R - 1 || R == 1) {
       // columns: G adjacent low positions share a tile
-      uint64_t G = NTT_TILE_ELEMS / np;
+      uint64_t G = tile_elems / np;
+      if (G < 1) G = 1;
       if (G > S[p]) G = S[p];
       while (G > 1 && n / (np * G) < 256) G >>= 1;  // small transforms: prefer >= 256 tiles (one per CU) over wide tiles
       P.g = (uint32_t)G;
@@ -449,7 +457,8 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     } else {
       // last pass: G rows with adjacent k_1; hi = k_1 group, lo = middle digit (R == 3) else 0
       uint64_t N1 = 1ull << b[0];
-      uint64_t G = NTT_TILE_ELEMS / np;
+      uint64_t G = tile_elems / np;
+      if (G < 1) G = 1;
       if (G > N1) G = N1;
       while (G > 1 && n / (np * G) < 256) G >>= 1;
       P.g = (uint32_t)G;
