@@ -242,6 +242,10 @@ int mi355zk_bn254_g1_add(uint64_t acc_xyz[12], const uint64_t other_xyz[12]);
 int mi355zk_bn254_g2_add(uint64_t acc_xyz[24], const uint64_t other_xyz[24]);
 int mi355zk_bn254_g1_to_affine(uint64_t out_xy[8], const uint64_t xyz[12]);
 int mi355zk_bn254_g2_to_affine(uint64_t out_xy[16], const uint64_t xyz[24]);
+/* acc = scalar * acc on the host (CurveProjective::mul_assign, ec.rs:538-560), scalar = 4 canonical u64 limbs: the single-point
+ * products of a proof assembly (bellman/src/groth16/prover.rs:300-333). */
+int mi355zk_bn254_g1_mul(uint64_t acc_xyz[12], const uint64_t scalar[4]);
+int mi355zk_bn254_g2_mul(uint64_t acc_xyz[24], const uint64_t scalar[4]);
 
 /* ---- plain device-memory helpers so that a C / Rust caller needs no HIP bindings of its own */
 int mi355zk_malloc(void **d_ptr, size_t bytes);

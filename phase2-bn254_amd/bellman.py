@@ -69,39 +69,52 @@ class DensityTracker:
     ABI's bit order: bit i = word i/32, bit i%32)."""
 
     def __init__(self):
-        self._bits: list[bool] = []
+        self._bits = np.zeros(64, dtype=np.uint8)   # one byte per element, grown geometrically (add_element is called per variable)
+        self._n = 0
         self.total_density = 0
+        self._packed = None                         # words() of the current contents (a proof asks for the same map 2-3 times)
 
     def add_element(self):
-        self._bits.append(False)
+        if self._n == self._bits.size:
+            self._bits = np.concatenate([self._bits, np.zeros(self._bits.size, dtype=np.uint8)])
+        self._bits[self._n] = 0
+        self._n += 1
+        self._packed = None
 
     def inc(self, idx: int):
+        if idx >= self._n:
+            raise IndexError(idx)
         if not self._bits[idx]:
-            self._bits[idx] = True
+            self._bits[idx] = 1
             self.total_density += 1
+            self._packed = None
 
     def get_total_density(self) -> int:
         return self.total_density
 
     def get_query_size(self):
-        return len(self._bits)
+        return self._n
 
     @classmethod
     def from_bools(cls, bools) -> "DensityTracker":
         d = cls()
-        d._bits = [bool(b) for b in bools]
-        d.total_density = sum(d._bits)
+        d._bits = np.ascontiguousarray(np.asarray(bools, dtype=bool), dtype=np.uint8).reshape(-1)
+        d._n = d._bits.size
+        if d._n == 0:
+            d._bits = np.zeros(64, dtype=np.uint8)
+        d.total_density = int(d._bits[:d._n].sum())
         return d
 
     def words(self):
-        n = len(self._bits)
-        w = np.zeros((n + 31) // 32 or 1, dtype=np.uint32)
-        if n:
-            bits = np.asarray(self._bits, dtype=np.uint8)
-            pad = np.zeros(w.size * 32, dtype=np.uint8)
-            pad[:n] = bits
-            w[:] = np.packbits(pad.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
-        return w, n
+        if self._packed is None:
+            n = self._n
+            w = np.zeros((n + 31) // 32 or 1, dtype=np.uint32)
+            if n:
+                pad = np.zeros(w.size * 32, dtype=np.uint8)
+                pad[:n] = self._bits[:n]
+                w[:] = np.packbits(pad.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
+            self._packed = (w, n)
+        return self._packed
 
 
 def _is_torch(x) -> bool:

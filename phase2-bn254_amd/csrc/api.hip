@@ -12,6 +12,7 @@
 #include <utility>
 #include <string>
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mi355zk.h"
@@ -902,8 +903,8 @@ void host_entry_release_all() {
   }
 }
 
-constexpr uint64_t HOST_CHUNK = 1ull << 24;      // exponents per chunk of a streamed call
-constexpr uint64_t HOST_CHUNK_MIN = 1ull << 22;  // below 2 chunks of this size the call is not cut
+constexpr uint64_t HOST_CHUNK = 1ull << 24;      // exponents per chunk of a streamed call whose bases are already on the device
+constexpr uint64_t HOST_CHUNK_MIN = 1ull << 22;  // first chunk of a call whose bases are cached; below 2 of these the call is not cut
 
 template <int GROUP>
 int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
@@ -961,13 +962,26 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
     }
   } guard{entry, fill};
 
-  // ---- chunks (multiples of 32 exponents, so that density words are not shared between chunks)
-  uint64_t n_chunks = n >= 2 * HOST_CHUNK_MIN ? (n + HOST_CHUNK - 1) / HOST_CHUNK : 1;
-  if (n >= 2 * HOST_CHUNK_MIN && n_chunks < 2) n_chunks = 2;
-  uint64_t per = n_chunks ? ((n + n_chunks - 1) / n_chunks + 31) & ~31ull : 0;
-  if (per == 0) per = 32;
-  n_chunks = n ? (n + per - 1) / per : 0;
-  const size_t sc_bytes = (size_t)(n < per ? n : per) * 32;
+  // ---- chunks (cut at multiples of 32 exponents, so that density words are not shared between chunks)
+  std::vector<uint64_t> cuts{0};
+  if (n >= 2 * HOST_CHUNK_MIN) {
+    // bases cached: the kernels are the bottleneck, so one small chunk gets the device going early and large ones follow (a 2^24
+    // multiexp runs at 90 % of the 2^26 rate, a 2^22 one at 65 %).  Bases travelling too (96 B per exponent): even chunks -- small
+    // ones were measured and lose (16 chunks of 2^22: 243 ms for 2^26 against 137 ms with four: pageable copies of 100-MB pieces
+    // run far below the link rate)
+    const uint64_t head = upload_bases ? 0 : HOST_CHUNK_MIN;
+    if (head) cuts.push_back(head);
+    const uint64_t rest = n - head;
+    uint64_t k = (rest + HOST_CHUNK - 1) / HOST_CHUNK;
+    if (k < 2 && !head) k = 2;
+    const uint64_t per = ((rest + k - 1) / k + 31) & ~31ull;
+    for (uint64_t lo = head + per; lo < n; lo += per) cuts.push_back(lo);
+  }
+  if (n) cuts.push_back(n);
+  const uint64_t n_chunks = cuts.size() - 1;
+  uint64_t max_chunk = 0;
+  for (uint64_t c = 0; c < n_chunks; ++c) max_chunk = std::max(max_chunk, cuts[c + 1] - cuts[c]);
+  const size_t sc_bytes = (size_t)max_chunk * 32;
   if (n) {
     for (int k = 0; k < 2; ++k) {
       size_t have = S->sc_bytes;
@@ -993,7 +1007,7 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
         cv.wait(lk, [&] { return abort_copy || c < freed + 2; });
         if (abort_copy) return;
       }
-      const uint64_t lo = c * per, hi = lo + per < n ? lo + per : n;
+      const uint64_t lo = cuts[c], hi = cuts[c + 1];
       hipError_t e = hipMemcpyAsync(S->sc[c & 1], scalars + lo * 4, (hi - lo) * 32, hipMemcpyHostToDevice, S->copy);
       if (e == hipSuccess && upload_bases) {
         uint64_t b_hi = base_offset + rank_of(hi);
@@ -1031,7 +1045,7 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
         cv.wait(lk, [&] { return copy_failed || copied > c; });
         if (copy_failed) { result = ZK_ERR_DEVICE; break; }
       }
-      const uint64_t lo = c * per, hi = lo + per < n ? lo + per : n;
+      const uint64_t lo = cuts[c], hi = cuts[c + 1];
       uint64_t part[jac_words];
       // the chunk is a multiexp of its own: same base vector, source offset advanced by the bases the earlier chunks consumed
       int crc = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset + rank_of(lo), S->sc[c & 1], hi - lo, density ? density + (lo >> 5) : nullptr,
@@ -1383,6 +1397,25 @@ int mi355zk_bn254_g2_add(uint64_t acc_xyz[24], const uint64_t other_xyz[24]) {
   std::memcpy(acc_xyz, &a, sizeof a);
   return ZK_OK;
 }
+// acc = k * acc on the host (CurveProjective::mul_assign, ec.rs:538-560: most significant bit first, leading zeros skipped): the
+// handful of single-point products a proof assembly makes (prover.rs:300-333: vk.delta_g1.mul(r) ...)
+extern "C++" template <class J>
+static int host_scalar_mul(uint64_t* acc_xyz, const uint64_t k[4]) {
+  if (!acc_xyz || !k) return ZK_ERR_BAD_ARGS;
+  J base, res = J::zero();
+  std::memcpy(&base, acc_xyz, sizeof base);
+  bool found_one = false;
+  for (int i = 255; i >= 0; --i) {
+    const bool bit = (k[i >> 6] >> (i & 63)) & 1;
+    if (found_one) jac_double(res);
+    else found_one = bit;
+    if (bit) jac_add(res, base);
+  }
+  std::memcpy(acc_xyz, &res, sizeof res);
+  return ZK_OK;
+}
+int mi355zk_bn254_g1_mul(uint64_t acc_xyz[12], const uint64_t scalar[4]) { return host_scalar_mul<G1Jacobian>(acc_xyz, scalar); }
+int mi355zk_bn254_g2_mul(uint64_t acc_xyz[24], const uint64_t scalar[4]) { return host_scalar_mul<G2Jacobian>(acc_xyz, scalar); }
 // into_affine (ec.rs:596-629); infinity -> all-zero record
 int mi355zk_bn254_g1_to_affine(uint64_t out_xy[8], const uint64_t xyz[12]) {
   if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;

@@ -1028,15 +1028,15 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
 //     LDS tree) and a second kernel adds the segment sums of each bucket, so even a bucket holding a third
 //     of all points is spread over thousands of workgroups.  Because `order` is sorted by size, the heavy
 //     buckets are order[0..H): msm_heavy_plan_kernel scans ceil(size / SEG) over that prefix.
-constexpr uint32_t MSM_HEAVY_SEG = 4096;    // entries per segment
+constexpr uint32_t MSM_HEAVY_SEG = 4096;    // entries per segment at size; short calls cut finer (heavy_seg_for)
 constexpr uint32_t MSM_HEAVY_LANES = 64;   // one wave per segment: 64 strided partial sums of <= 64 points, then a 6-level tree
 
-__global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __restrict__ sizes_sorted, uint32_t hb, uint32_t heavy,
+__global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __restrict__ sizes_sorted, uint32_t hb, uint32_t heavy, uint32_t seg,
                                                              uint32_t* __restrict__ item_off /* hb + 1 */) {
   __shared__ uint32_t scratch[32];
   const uint32_t tot = block_scan_long(hb, scratch, [&](uint32_t i) {
     const uint32_t sz = sizes_sorted[i];
-    return sz > heavy ? (sz + MSM_HEAVY_SEG - 1) / MSM_HEAVY_SEG : 0u;
+    return sz > heavy ? (sz + seg - 1) / seg : 0u;
   }, [&](uint32_t i, uint32_t ex) { item_off[i] = ex; });
   if (threadIdx.x == 0) item_off[hb] = tot;
 }
@@ -1045,7 +1045,7 @@ template <class F>
 __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                                   const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_off,
-                                                                  uint32_t hb, XYZZ<F>* __restrict__ seg_sums, int skip_zero,
+                                                                  uint32_t hb, uint32_t seg, XYZZ<F>* __restrict__ seg_sums, int skip_zero,
                                                                   unsigned long long* __restrict__ err_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
@@ -1061,8 +1061,8 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
       else hi = mid;
     }
     const uint32_t b = order[lo];
-    const uint32_t j0 = first[b] + (item - item_off[lo]) * MSM_HEAVY_SEG;
-    const uint32_t e = j0 + MSM_HEAVY_SEG < last[b] ? j0 + MSM_HEAVY_SEG : last[b];
+    const uint32_t j0 = first[b] + (item - item_off[lo]) * seg;
+    const uint32_t e = j0 + seg < last[b] ? j0 + seg : last[b];
     sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0, err_base);
     __syncthreads();
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __
 //     further launches of the same kernel sum the slice sums.  The host applies the powers of two and of L.
 //     The grid is 1-D over the NON-EMPTY (window, job, slice) triples: jobs of one launch differ in length, and a
 //     (slices, jobs, windows) grid put every short job's only workgroup on the same XCD (block id = multiple of 8).
-constexpr uint32_t MSM_FINAL_MAX = 1024;
+constexpr uint32_t MSM_FINAL_MAX = 1024;  // (2048 and 8192 measured in round 2: the bit-decomposition trees cost more than the level they replace)
 constexpr uint32_t MSM_TREE_SLICE = 512;
 constexpr uint32_t MSM_MAX_LEVELS = 8;
 constexpr uint32_t MSM_MAX_JOBS = MSM_MAX_LEVELS + 24;
@@ -1227,43 +1227,84 @@ int ws_reserve(int dev, size_t bytes, void** out) {
   return 0;
 }
 
-// Calls whose workspace is small (<= WS_SMALL: up to ~2^21 points) do not share the device-wide workspace and its lock: every
-// host thread keeps its own buffer.  The prover queues eight multiexps from eight threads (prover.rs:250-298) -- the short ones
-// (inputs, B_G1 ...) then run concurrently on their callers' streams instead of waiting behind the long ones.
+// Calls whose workspace is small (<= WS_SMALL: up to ~2^21 points) do not share the device-wide workspace and its lock: each
+// leases a buffer from a pool for its duration.  The prover queues eight multiexps from eight threads (prover.rs:250-298) -- the
+// short ones (inputs, B_G1 ...) then run concurrently on their callers' streams instead of waiting behind the long ones.  (A pool
+// rather than a buffer per thread: callers come and go -- a thread pool per proof -- and their buffers must not pile up.)
 constexpr size_t WS_SMALL = (size_t)1 << 30;
-struct ThreadWs {
+struct SmallWs {
   int dev = -1;
   void* p = nullptr;
   size_t bytes = 0;
+  bool busy = false;
 };
 std::mutex g_tws_mu;
-std::vector<ThreadWs*> g_tws;  // every thread's buffer, for the shutdown
-int tws_reserve(int dev, size_t bytes, hipStream_t st, void** out) {
-  thread_local ThreadWs* mine = nullptr;
-  if (mine == nullptr) {
-    mine = new ThreadWs();
+std::vector<SmallWs*> g_tws;  // the pool: as many entries as there have been concurrent calls
+struct SmallWsLease {
+  SmallWs* w = nullptr;
+  hipStream_t st = nullptr;
+  bool idle = false;  // set once the caller has synchronised the stream after its last use of the buffer
+  ~SmallWsLease() {
+    if (w == nullptr) return;
+    if (!idle) (void)hipStreamSynchronize(st);  // an error path: kernels using the buffer may still be queued
     std::lock_guard<std::mutex> lk(g_tws_mu);
-    g_tws.push_back(mine);
+    w->busy = false;
   }
-  if (mine->dev != dev || mine->bytes < bytes) {
-    if (mine->p) {
-      ZK_HIP(hipStreamSynchronize(st));
-      ZK_HIP(hipFree(mine->p));
+};
+// Buffers come in power-of-two sizes (>= 16 MiB) and are never regrown: hipFree / hipMalloc synchronise the device, and eight
+// concurrent calls of eight different sizes would otherwise keep trading buffers.  Idle buffers are only given back when the pool
+// exceeds TWS_POOL_CAP.
+constexpr size_t TWS_POOL_CAP = (size_t)12 << 30;
+int tws_acquire(int dev, size_t bytes, hipStream_t st, SmallWsLease* lease, void** out) {
+  size_t cls = (size_t)16 << 20;
+  while (cls < bytes) cls <<= 1;
+  SmallWs* pick = nullptr;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_tws_mu);
+    size_t pool = 0;
+    for (SmallWs* w : g_tws) {  // the smallest idle buffer that fits
+      pool += w->bytes;
+      if (w->busy || w->dev != dev || w->p == nullptr || w->bytes < cls) continue;
+      if (pick == nullptr || w->bytes < pick->bytes) pick = w;
     }
-    mine->p = nullptr;
-    mine->bytes = 0;
-    ZK_HIP(hipMalloc(&mine->p, bytes));
-    mine->bytes = bytes;
-    mine->dev = dev;
+    if (pick == nullptr) {
+      for (SmallWs* w : g_tws) {  // an empty slot, and room under the cap
+        if (w->busy) continue;
+        if (w->p == nullptr) { if (pick == nullptr) pick = w; continue; }
+        if (pool + cls > TWS_POOL_CAP && w->dev == dev) {
+          drop.push_back(w->p);
+          pool -= w->bytes;
+          w->p = nullptr;
+          w->bytes = 0;
+          if (pick == nullptr) pick = w;
+        }
+      }
+      if (pick == nullptr) {
+        pick = new SmallWs();
+        g_tws.push_back(pick);
+      }
+      pick->dev = dev;
+    }
+    pick->busy = true;
   }
-  *out = mine->p;
+  lease->w = pick;
+  lease->st = st;
+  lease->idle = true;  // nothing queued on it yet
+  for (void* d : drop) (void)hipFree(d);  // idle: their last users synchronised before releasing them
+  if (pick->p == nullptr) {
+    ZK_HIP(hipMalloc(&pick->p, cls));
+    pick->bytes = cls;
+  }
+  lease->idle = false;
+  *out = pick->p;
   return 0;
 }
 
 void ws_release_all() {
   {
     std::lock_guard<std::mutex> lk(g_tws_mu);
-    for (ThreadWs* t : g_tws) {
+    for (SmallWs* t : g_tws) {
       if (t->p) {
         (void)hipSetDevice(t->dev);
         (void)hipFree(t->p);
@@ -1459,15 +1500,22 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   // slots (256 CUs x 4 SIMDs x 4 waves x 64), so a launch lasts about m / 2^18 additions per slot; a longer bucket is a straggler
   // (it starts first -- buckets run in size order -- but finishes alone).  Prover-like exponents produce such buckets by the
   // hundred (every byte-sized witness value lands in one of 255 buckets of window 0).
+  // Short calls are latency-bound instead: a lane adds a point to its bucket every ~8 us whatever else the device does (ten
+  // dependent field products), so a bucket of 100 entries among buckets of 6 holds the launch for 0.8 ms (measured at 2^18
+  // prover-like exponents: the 255 byte-valued buckets of window 0).  Hence a floor of 64, a margin of 16 over twice the mean,
+  // and segments short enough (heavy_seg) that a segment's 64 lanes add a handful of points each before the tree.
   const uint64_t mean_len = n / G.nb + 1;
   uint64_t heavy64 = mean_len * 8 + 1024;
   const uint64_t per_slot = m >> 18;
-  if (heavy64 > (per_slot > 256 ? per_slot : 256)) heavy64 = per_slot > 256 ? per_slot : 256;
-  if (heavy64 < 2 * mean_len + 64) heavy64 = 2 * mean_len + 64;   // never the ordinary buckets
+  const uint64_t heavy_cap = (m >> 17) > 64 ? (m >> 17) : 64;  // 8 us per entry against ~2^-17 x m x 8 us for the launch at full throughput
+  if (heavy64 > heavy_cap) heavy64 = heavy_cap;
+  if (heavy64 < 2 * mean_len + 16) heavy64 = 2 * mean_len + 16;   // never the ordinary buckets
   const uint32_t heavy = (uint32_t)(heavy64 > 0xffffffffull ? 0xffffffffull : heavy64);
+  uint32_t heavy_seg = 128;
+  while (heavy_seg < MSM_HEAVY_SEG && ((uint64_t)heavy_seg << 14) < m) heavy_seg <<= 1;
   uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
   if ((uint64_t)hb > m / heavy + 1) hb = (uint32_t)(m / heavy + 1);
-  const uint32_t max_items = (uint32_t)(m / MSM_HEAVY_SEG) + hb;  // every heavy bucket adds at most one partial segment
+  const uint32_t max_items = (uint32_t)(m / heavy_seg) + hb;  // every heavy bucket adds at most one partial segment
   size_t o_item_off = take((size_t)(hb + 1) * 4);
   size_t o_seg_sums = take((size_t)max_items * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
@@ -1486,8 +1534,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   const bool small_ws = off <= WS_SMALL;
   std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
   void* base = nullptr;
+  SmallWsLease lease;
   if (small_ws) {
-    rc = tws_reserve(dev, off, st, &base);
+    rc = tws_acquire(dev, off, st, &lease, &base);
   } else {
     lk.lock();
     rc = ws_reserve(dev, off, &base);
@@ -1612,13 +1661,16 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   if (checkpoint("partition")) return ZK_ERR_DEVICE;
 
   auto run_set = [&](const Affine<F>* bases_set, Jacobian<F>* result, bool last_set) -> int {
+    lease.idle = false;
     {
       prof_begin(slot_heavy, st);
-      hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
+      hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, heavy_seg, item_off);
       ZK_HIP(hipGetLastError());
-      const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
+      // (grid-stride over the segments that exist; a short call must not pay for thousands of empty workgroups)
+      uint32_t heavy_grid = (uint32_t)((m >> 12) < 1024 ? 1024 : (m >> 12) > 16384 ? 16384 : (m >> 12));
+      if (heavy_grid > max_items) heavy_grid = max_items;
       hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st,
-                         bases_set, vals_b, first, last, order, item_off, hb, seg_sums, dense ? 1 : 0, d_err);
+                         bases_set, vals_b, first, last, order, item_off, hb, heavy_seg, seg_sums, dense ? 1 : 0, d_err);
       ZK_HIP(hipGetLastError());
       hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off,
                          hb, buckets);
@@ -1693,6 +1745,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)WL * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipMemcpyAsync(h_errs, d_err, 16, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    lease.idle = true;
     const unsigned long long h_err = h_errs[0];
     // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
     // flight, prover.rs:250-298) start while this thread joins its partial sums
@@ -1814,10 +1867,10 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
   msm_order_by_size(first, last, n_rows, size_hist, order, sizes_b, st);
   ZK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, item_off);
+  hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, MSM_HEAVY_SEG, item_off);
   const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
   hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st, d_points,
-                     vals, first, last, order, item_off, hb, seg_sums, 1, (unsigned long long*)nullptr);
+                     vals, first, last, order, item_off, hb, MSM_HEAVY_SEG, seg_sums, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, hb,
                      buckets);
   hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "mi355zk_bn254_g2_add": (_i, [_vp, _vp]),
     "mi355zk_bn254_g1_to_affine": (_i, [_vp, _vp]),
     "mi355zk_bn254_g2_to_affine": (_i, [_vp, _vp]),
+    "mi355zk_bn254_g1_mul": (_i, [_vp, _vp]),
+    "mi355zk_bn254_g2_mul": (_i, [_vp, _vp]),
     "mi355zk_malloc": (_i, [C.POINTER(_vp), _sz]),
     "mi355zk_free": (_i, [_vp]),
     "mi355zk_memcpy_h2d": (_i, [_vp, _vp, _sz]),

@@ -12,11 +12,12 @@ Data: everything large is device resident (torch CUDA int64 tensors holding u64 
 assignments are MONTGOMERY Fr (the prover's `Vec<Scalar<E>>` / `Vec<E::Fr>`), the parameter vectors raw affine records.  The
 H polynomial goes ifft -> coset_fft -> mul / sub / divide_by_z_on_coset -> icoset_fft -> multiexp without a host round trip.
 What stays on the host is what the reference does once per proof on single points (vk.delta_g1.mul(r) ...): here through the
-library's host-side add / to_affine and one-point batch_exp calls.
+library's host-side add / mul / to_affine helpers.
 """
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -101,16 +102,43 @@ def _add(acc: np.ndarray, other: np.ndarray) -> np.ndarray:
     return acc
 
 
-def _mul(point, k: int, device) -> np.ndarray:
-    """k * point for one point (affine record or Jacobian), Jacobian out: CurveAffine::mul / CurveProjective::mul_assign"""
+def _mul(point, k: int, device=None) -> np.ndarray:
+    """k * point for one point (affine record or Jacobian), Jacobian out: CurveAffine::mul / CurveProjective::mul_assign, done
+    where the reference does it -- on the host, once per proof (the library's mi355zk_bn254_g{1,2}_mul)"""
+    point = np.ascontiguousarray(point, dtype=np.uint64)
+    jac = (_from_affine(point) if point.size in (8, 16) else point).copy()
+    fn = _lib.load().mi355zk_bn254_g1_mul if jac.size == 12 else _lib.load().mi355zk_bn254_g2_mul
+    kk = _limbs(k % _R_ORDER)
+    assert fn(jac.ctypes.data_as(C.c_void_p), kk.ctypes.data_as(C.c_void_p)) == 0
+    return jac
+
+
+# The eight multiexps of a proof are queued from eight host threads (the reference queues them on its CpuPool before the first
+# wait(), prover.rs:250-298).  The threads and their streams outlive the proof: starting threads and creating streams costs as much
+# as a small multiexp.
+_executor = None
+_executor_lock = threading.Lock()
+_tls = threading.local()
+
+
+def _pool8() -> ThreadPoolExecutor:
+    global _executor
+    with _executor_lock:
+        if _executor is None:
+            _executor = ThreadPoolExecutor(max_workers=8, thread_name_prefix="mi355zk-multiexp")
+    return _executor
+
+
+def _thread_stream(device):
     import torch
 
-    point = np.ascontiguousarray(point, dtype=np.uint64)
-    aff = point if point.size in (8, 16) else _to_affine(point)
-    d_p = torch.from_numpy(aff.reshape(1, -1).view(np.int64)).to(device)
-    d_k = torch.from_numpy(_limbs(k % _R_ORDER).reshape(1, 4).view(np.int64)).to(device)
-    out = ceremony.batch_exp(d_p, d_k)
-    return _from_affine(out.cpu().numpy().view(np.uint64).reshape(-1))
+    streams = getattr(_tls, "streams", None)
+    if streams is None:
+        streams = _tls.streams = {}
+    key = (device.type, device.index)
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=device)
+    return streams[key]
 
 
 def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r: int, s: int, concurrent: bool = True):
@@ -121,7 +149,7 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
 
     vk = params.get_vk(prover.input_assignment.shape[0])
     device = prover.a.device
-    ex = ThreadPoolExecutor(max_workers=8) if concurrent else None
+    ex = _pool8() if concurrent else None
 
     def submit(bases, density, exponents):
         if ex is None:
@@ -131,7 +159,7 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
         def call():
             # its own stream: small multiexps (per-thread workspace in the library) overlap with the long ones instead of
             # queueing behind them on one stream; inputs are complete (the caller synchronised), results come back on the host
-            with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
+            with torch.cuda.device(device), torch.cuda.stream(_thread_stream(device)):
                 return multiexp(pool, bases, density, exponents, scalars_montgomery=True)
 
         f = ex.submit(call)
@@ -174,26 +202,22 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
     b_g2_inputs = submit(b_g2_inputs_source, prover.b_input_density, input_assignment)
     b_g2_aux = submit(b_g2_aux_source, prover.b_aux_density, aux_assignment)
 
-    try:
-        if _is_zero(vk["delta_g1"]) or _is_zero(vk["delta_g2"]):      # prover.rs:300-304: subversion-CRS attack
-            raise SynthesisError(SynthesisError.UNEXPECTED_IDENTITY)
-        g_a = _add(_mul(vk["delta_g1"], r, device), _from_affine(vk["alpha_g1"]))
-        g_b = _add(_mul(vk["delta_g2"], s, device), _from_affine(vk["beta_g2"]))
-        g_c = _mul(vk["delta_g1"], r * s % _R_ORDER, device)
-        g_c = _add(g_c, _mul(vk["alpha_g1"], s, device))
-        g_c = _add(g_c, _mul(vk["beta_g1"], r, device))
-        a_answer = _add(a_inputs(), a_aux())
-        g_a = _add(g_a, a_answer)
-        a_answer = _mul(a_answer, s, device)
-        g_c = _add(g_c, a_answer)
-        b1_answer = _add(b_g1_inputs(), b_g1_aux())
-        b2_answer = _add(b_g2_inputs(), b_g2_aux())
-        g_b = _add(g_b, b2_answer)
-        b1_answer = _mul(b1_answer, r, device)
-        g_c = _add(g_c, b1_answer)
-        g_c = _add(g_c, h())
-        g_c = _add(g_c, l())
-    finally:
-        if ex is not None:
-            ex.shutdown(wait=True)
+    if _is_zero(vk["delta_g1"]) or _is_zero(vk["delta_g2"]):      # prover.rs:300-304: subversion-CRS attack
+        raise SynthesisError(SynthesisError.UNEXPECTED_IDENTITY)
+    g_a = _add(_mul(vk["delta_g1"], r, device), _from_affine(vk["alpha_g1"]))
+    g_b = _add(_mul(vk["delta_g2"], s, device), _from_affine(vk["beta_g2"]))
+    g_c = _mul(vk["delta_g1"], r * s % _R_ORDER, device)
+    g_c = _add(g_c, _mul(vk["alpha_g1"], s, device))
+    g_c = _add(g_c, _mul(vk["beta_g1"], r, device))
+    a_answer = _add(a_inputs(), a_aux())
+    g_a = _add(g_a, a_answer)
+    a_answer = _mul(a_answer, s, device)
+    g_c = _add(g_c, a_answer)
+    b1_answer = _add(b_g1_inputs(), b_g1_aux())
+    b2_answer = _add(b_g2_inputs(), b_g2_aux())
+    g_b = _add(g_b, b2_answer)
+    b1_answer = _mul(b1_answer, r, device)
+    g_c = _add(g_c, b1_answer)
+    g_c = _add(g_c, h())
+    g_c = _add(g_c, l())
     return _to_affine(g_a), _to_affine(g_b), _to_affine(g_c)

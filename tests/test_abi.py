@@ -75,6 +75,24 @@ def test_host_group_helpers_match_oracle():
             assert np.array_equal(aff, G.to_affine(G.add(x, y)))
 
 
+def test_host_scalar_mul_matches_oracle():
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    for G, mul, to_aff, gen in ((O.G1, lib.mi355zk_bn254_g1_mul, lib.mi355zk_bn254_g1_to_affine, inputs.G1_GEN_RAW),
+                                (O.G2, lib.mi355zk_bn254_g2_mul, lib.mi355zk_bn254_g2_to_affine, inputs.G2_GEN_RAW)):
+        p = G.mul(G.from_affine(gen), M.to_limbs(987654321))
+        zero = G.from_affine(np.zeros(G.aff, np.uint64))
+        for base in (p, zero):
+            for k in (0, 1, 2, 3, 0xFFFFFFFFFFFFFFFF, 1 << 64, M.R_ORDER - 1, M.R_ORDER, 0x2B5F3A1C9E7D46820F1E2D3C4B5A69788796A5B4C3D2E1F0123456789ABCDEF % M.R_ORDER):
+                acc = base.copy()
+                kk = np.array(M.to_limbs(k), dtype=np.uint64)
+                assert mul(acc.ctypes.data_as(C.c_void_p), kk.ctypes.data_as(C.c_void_p)) == 0
+                aff = np.zeros(G.aff, np.uint64)
+                assert to_aff(aff.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(aff, G.to_affine(G.mul(base, kk))), (G, k)
+
+
 def test_window_geometry_is_sane():
     import phase2_bn254_amd as zk
 
