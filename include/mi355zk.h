@@ -180,6 +180,8 @@ int mi355zk_selftest_u_sub(int which, int k, int s, const uint32_t a[9], const u
 int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9], const uint32_t in_u[9], uint64_t out_std[4]);
 int mi355zk_selftest_u_reduce32(int which, const uint32_t in_u[9], uint64_t out_std[4]);
 int mi355zk_selftest_g1_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[16]);
+int mi355zk_selftest_g1_record_sum(int mode, const uint64_t *affine_pts, const uint8_t *negate, const uint32_t *group, size_t n, size_t n_groups, uint64_t out_xyzz[16]);
+int mi355zk_selftest_g2_record_sum(int mode, const uint64_t *affine_pts, const uint8_t *negate, const uint32_t *group, size_t n, size_t n_groups, uint64_t out_xyzz[32]);
 int mi355zk_selftest_g2_scalar_mul_u(const uint64_t affine_pt[16], const uint64_t scalar[4], uint64_t out_xyz[24]);
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[32]);
 

@@ -150,6 +150,95 @@ ZK_HD XYZZ<Fp<PR>> xyzzu_to_std(const XYZZU<PR>& a) {
 }
 
 // =================================================================================================
+// XYZZ RECORDS IN THE R DOMAIN: what the bucket accumulation hands to the bucket reduction (msm_impl.hpp: the running sums, the
+// LDS trees, the heavy-bucket combine).  A record is the 128-byte XYZZ<Fp> of curve.hpp whose four coordinates are CANONICAL
+// (< p) values in the 2^261 domain -- Montgomery form for u_mul -- instead of the memory format's 2^256.  A full addition then
+// closes on U-form arithmetic without a single domain-fixing product (with the accumulator's mixed domains it would take four),
+// records load and store by re-packing bits only, and the accumulator saves two of its four closing products.  Because all four
+// coordinates carry the same extra factor 2^5, x = X/ZZ and y = Y/ZZZ are unchanged: xyzz_to_affine works on a record as it is;
+// anything else (the host join: xyzz_to_jacobian) converts with xyzzr_to_std first.  The all-zero record is infinity.
+//   Register form (XYZZU, all coordinates 2^261 domain): X < 6p, Y < 2p, ZZ < 2p, ZZZ < 2p, N-form; infinity: ZZ literal zero.
+
+// bucket accumulator (X, Y: 2^261; ZZ, ZZZ: 2^266) -> record
+template <class PR>
+ZK_HD XYZZ<Fp<PR>> xyzzu_to_r(const XYZZU<PR>& a) {
+  if (a.is_zero()) return XYZZ<Fp<PR>>::zero();
+  const FpU<PR> c256 = UPow2<PR, 256>::get();  // ZZ*2^266 * 2^256 / 2^261 = ZZ * 2^261
+  XYZZ<Fp<PR>> r;
+  r.x = u_to_std_lt32p(a.x);                   // < 6p
+  r.y = u_to_std_lt2p(a.y);
+  r.zz = u_to_std_lt2p(u_mul(a.zz, c256));
+  r.zzz = u_to_std_lt2p(u_mul(a.zzz, c256));
+  return r;
+}
+
+template <class PR>
+ZK_HD XYZZU<PR> xyzzr_load(const XYZZ<Fp<PR>>& s) {  // canonical coordinates: < p, N-form; the zero record gives ZZ == 0 limbs
+  return XYZZU<PR>{u_from_std(s.x), u_from_std(s.y), u_from_std(s.zz), u_from_std(s.zzz)};
+}
+
+template <class PR>
+ZK_HD XYZZ<Fp<PR>> xyzzr_store(const XYZZU<PR>& a) {
+  if (a.is_zero()) return XYZZ<Fp<PR>>::zero();
+  XYZZ<Fp<PR>> r;
+  r.x = u_to_std_lt32p(a.x);                   // < 6p
+  r.y = u_to_std_lt2p(a.y);
+  r.zz = u_to_std_lt2p(a.zz);
+  r.zzz = u_to_std_lt2p(a.zzz);
+  return r;
+}
+
+// record -> memory-format XYZZ (2^256 domain)
+template <class PR>
+ZK_HD XYZZ<Fp<PR>> xyzzr_to_std(const XYZZ<Fp<PR>>& s) {
+  if (s.is_zero()) return s;
+  const FpU<PR> c256 = UPow2<PR, 256>::get();  // v*2^261 * 2^256 / 2^261 = v * 2^256
+  XYZZ<Fp<PR>> r;
+  r.x = u_to_std_lt2p(u_mul(u_from_std(s.x), c256));
+  r.y = u_to_std_lt2p(u_mul(u_from_std(s.y), c256));
+  r.zz = u_to_std_lt2p(u_mul(u_from_std(s.zz), c256));
+  r.zzz = u_to_std_lt2p(u_mul(u_from_std(s.zzz), c256));
+  return r;
+}
+
+// acc += o, both in register form  [add-2008-s, with the P + P / P + (-P) / infinity cases of ec.rs:360-454]
+template <class PR>
+ZK_HD void xyzzr_add(XYZZU<PR>& acc, const XYZZU<PR>& o) {
+  if (o.is_zero()) return;
+  if (acc.is_zero()) {
+    acc = o;
+    return;
+  }
+  FpU<PR> u1 = u_mul(acc.x, o.zz);                          // 6*2 c + 1 < 1.08p
+  FpU<PR> u2 = u_mul(o.x, acc.zz);                          // < 1.08p
+  FpU<PR> s1 = u_mul(acc.y, o.zzz);                         // < 1.03p
+  FpU<PR> s2 = u_mul(o.y, acc.zzz);                         // < 1.03p
+  FpU<PR> p = u_sub<2, 1>(u2, u1);                          // U1 < 2p;  P < 4p, N
+  FpU<PR> r = u_sub<2, 1>(s2, s1);                          // S1 < 2p;  R < 4p, N
+  FpU<PR> pp = u_sqr(p);                                    // 16c + 1 < 1.1p
+  FpU<PR> ppp = u_mul(p, pp);                               // < 1.03p
+  FpU<PR> q = u_mul(u1, pp);                                // < 1.01p
+  FpU<PR> rr = u_sqr(r);                                    // < 1.1p
+  FpU<PR> t = u_add(ppp, u_dbl(q));                         // < 3.1p <= 4p, limbs < 3 * 2^29
+  FpU<PR> x3 = u_sub<4, 3>(rr, t);                          // < 5.1p  (invariant X < 6p)
+  FpU<PR> d = u_sub<8, 1>(q, x3);                           // < 9.1p
+  FpU<PR> ns1 = u_sub<2, 1>(FpU<PR>::zero(), s1);           // 2p - S1 in (0, 2p], N
+  FpU<PR> y3 = u_mul2(r, d, ns1, ppp);                      // R*D - S1*PPP: (4*9.1 + 2*1.03) c + 1 < 1.24p  (invariant Y < 2p)
+  FpU<PR> zz3 = u_mul(u_mul(acc.zz, o.zz), pp);             // < 2p
+  FpU<PR> zzz3 = u_mul(u_mul(acc.zzz, o.zzz), ppp);         // < 2p
+  if (u_is_zero_lt2p(zz3)) {
+    // P == 0 (ZZ1, ZZ2 != 0): the points have the same x.  Same point -> double; opposite -> infinity.
+    if (u_is_zero_lt8p(r)) acc = xyzzu_double(acc);         // (domain-agnostic in ZZ / ZZZ: they only pass through products)
+    else acc = XYZZU<PR>::zero();
+    return;
+  }
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = zz3;
+  acc.zzz = zzz3;
+}
+
+// =================================================================================================
 // Jacobian accumulator on U-form elements, for SCALAR MULTIPLICATION (batch_exp): a doubling is cheaper in
 // Jacobian coordinates (dbl-2009-l: 4 squarings + 3 products here, 1071 mads) than in XYZZ (1467), and a scalar
 // multiplication is doublings first of all.  Every coordinate lives in the same 2^261 domain (the base point is
@@ -400,6 +489,89 @@ ZK_HD void xyzzu2_add_mixed(XYZZU2& acc, const Fq2& x2s, const Fq2& y2s, bool ne
     } else {
       acc = XYZZU2::zero();
     }
+    return;
+  }
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = zz3;
+  acc.zzz = zzz3;
+}
+
+// ---- G2 records in the R domain (see the G1 section "XYZZ RECORDS IN THE R DOMAIN"): componentwise the same thing.
+//   Register form (XYZZU2, every component 2^261 domain): X < 6p, Y < 2p, ZZ < 2p, ZZZ < 2p, N-form.
+ZK_HD XYZZ<Fq2> xyzzu_to_r(const XYZZU2& a) {          // bucket accumulator (X, Y: 2^261; ZZ, ZZZ: 2^266) -> record
+  if (a.is_zero()) return XYZZ<Fq2>::zero();
+  const FqU c256 = UPow2<FqParams, 256>::get();
+  XYZZ<Fq2> r;
+  r.x = Fq2{u_to_std_lt32p(a.x.c0), u_to_std_lt32p(a.x.c1)};
+  r.y = Fq2{u_to_std_lt2p(a.y.c0), u_to_std_lt2p(a.y.c1)};
+  r.zz = Fq2{u_to_std_lt2p(u_mul(a.zz.c0, c256)), u_to_std_lt2p(u_mul(a.zz.c1, c256))};
+  r.zzz = Fq2{u_to_std_lt2p(u_mul(a.zzz.c0, c256)), u_to_std_lt2p(u_mul(a.zzz.c1, c256))};
+  return r;
+}
+ZK_HD XYZZU2 xyzzr_load(const XYZZ<Fq2>& s) {
+  return XYZZU2{f2u_from_std(s.x), f2u_from_std(s.y), f2u_from_std(s.zz), f2u_from_std(s.zzz)};
+}
+ZK_HD XYZZ<Fq2> xyzzr_store(const XYZZU2& a) {
+  if (a.is_zero()) return XYZZ<Fq2>::zero();
+  XYZZ<Fq2> r;
+  r.x = Fq2{u_to_std_lt32p(a.x.c0), u_to_std_lt32p(a.x.c1)};
+  r.y = Fq2{u_to_std_lt2p(a.y.c0), u_to_std_lt2p(a.y.c1)};
+  r.zz = Fq2{u_to_std_lt2p(a.zz.c0), u_to_std_lt2p(a.zz.c1)};
+  r.zzz = Fq2{u_to_std_lt2p(a.zzz.c0), u_to_std_lt2p(a.zzz.c1)};
+  return r;
+}
+ZK_HD XYZZ<Fq2> xyzzr_to_std(const XYZZ<Fq2>& s) {      // record -> memory-format XYZZ (2^256 domain)
+  if (s.is_zero()) return s;
+  const FqU c256 = UPow2<FqParams, 256>::get();
+  auto cv = [&](const Fq2& v) { return Fq2{u_to_std_lt2p(u_mul(u_from_std(v.c0), c256)), u_to_std_lt2p(u_mul(u_from_std(v.c1), c256))}; };
+  return XYZZ<Fq2>{cv(s.x), cv(s.y), cv(s.zz), cv(s.zzz)};
+}
+ZK_HD XYZZU2 xyzzr2_from_std(const XYZZ<Fq2>& s) {      // memory-format XYZZ -> register form (rare paths only)
+  if (s.is_zero()) return XYZZU2::zero();
+  const FqU c266 = UPow2<FqParams, 266>::get();           // v*2^256 * 2^266 / 2^261 = v * 2^261
+  auto cv = [&](const Fq2& v) { return Fq2U{u_mul(u_from_std(v.c0), c266), u_mul(u_from_std(v.c1), c266)}; };
+  return XYZZU2{cv(s.x), cv(s.y), cv(s.zz), cv(s.zzz)};
+}
+
+// acc += o, both in register form  [add-2008-s over Fq2; the component bounds follow xyzzu2_add_mixed]
+ZK_HD void xyzzr_add(XYZZU2& acc, const XYZZU2& o) {
+  if (o.is_zero()) return;
+  if (acc.is_zero()) {
+    acc = o;
+    return;
+  }
+  Fq2U u1 = f2u_mul<2>(acc.x, o.zz);                        // (6*2 + 6*2) c + 1 < 1.15p
+  Fq2U u2 = f2u_mul<2>(o.x, acc.zz);                        // < 1.15p
+  Fq2U s1 = f2u_mul<2>(acc.y, o.zzz);                       // (2*2 + 2*2) c + 1 < 1.05p
+  Fq2U s2 = f2u_mul<2>(o.y, acc.zzz);                       // < 1.05p
+  Fq2U p = f2u_sub<2>(u2, u1);                              // U1 < 2p;  P < 3.15p <= 4p, N
+  Fq2U r = f2u_sub<2>(s2, s1);                              // S1 < 2p;  R < 3.05p <= 4p, N
+  Fq2U pp;                                                  // P^2 = (P0^2 - P1^2) + 2 P0 P1 u
+  pp.c0 = u_mul2(p.c0, p.c0, p.c1, u_sub<4, 1>(FqU::zero(), p.c1));   // (16 + 4*4) c + 1 < 1.2p
+  pp.c1 = u_mul(u_dbl(p.c0), p.c1);                         // 32 c + 1 < 1.2p
+  Fq2U ppp = f2u_mul<2>(p, pp);                             // c0 < (4.8 + 8) c + 1 < 1.08p, c1 < 9.6 c + 1 < 1.06p
+  Fq2U q = f2u_mul<2>(u1, pp);                              // < 1.03p
+  Fq2U rr;                                                  // R^2 = (R0 + R1)(R0 - R1) + 2 R0 R1 u
+  rr.c0 = u_mul(u_carry(u_add(r.c0, r.c1)), u_sub<4, 1>(r.c0, r.c1));  // 8 * 8 c + 1 < 1.39p
+  rr.c1 = u_mul(u_dbl(r.c0), r.c1);                         // 32 c + 1 < 1.2p
+  Fq2U x3, d;
+  x3.c0 = u_sub<4, 3>(rr.c0, u_add(ppp.c0, u_dbl(q.c0)));   // PPP + 2Q < 3.2p <= 4p, limbs < 3 * 2^29;  X3 < 5.4p
+  x3.c1 = u_sub<4, 3>(rr.c1, u_add(ppp.c1, u_dbl(q.c1)));
+  d = f2u_sub<8>(q, x3);                                    // < 9.1p
+  FqU ns0 = u_sub<2, 1>(FqU::zero(), s1.c0);                // 2p - S1_0
+  FqU ns1 = u_sub<2, 1>(FqU::zero(), s1.c1);
+  FqU nd1 = u_sub<16, 1>(FqU::zero(), d.c1);                // 16p - D1
+  Fq2U y3;                                                  // R*D - S1*PPP
+  y3.c0 = u_mul4(r.c0, d.c0, r.c1, nd1, ns0, ppp.c0, s1.c1, ppp.c1);   // (36.4 + 64 + 2.2 + 1.2) c + 1 < 1.63p
+  y3.c1 = u_mul4(r.c0, d.c1, r.c1, d.c0, ns0, ppp.c1, ns1, ppp.c0);    // (36.4 + 36.4 + 2.2 + 2.2) c + 1 < 1.47p
+  Fq2U zz3 = f2u_mul<2>(f2u_mul<2>(acc.zz, o.zz), pp);      // inner < 1.05p;  < 1.03p
+  Fq2U zzz3 = f2u_mul<2>(f2u_mul<2>(acc.zzz, o.zzz), ppp);  // < 1.03p
+  if (u_is_zero_lt2p(zz3.c0) && u_is_zero_lt2p(zz3.c1)) {
+    // P == 0: same x.  Same point -> double; opposite -> infinity.  Rare: the doubling runs on the saturated-limb formulas of
+    // curve.hpp (they are not homogeneous, so through the memory format's own domain and back).
+    if (u_is_zero_lt8p(r.c0) && u_is_zero_lt8p(r.c1)) acc = xyzzr2_from_std(xyzz_double(xyzzr_to_std(xyzzr_store(acc))));
+    else acc = XYZZU2::zero();
     return;
   }
   acc.x = x3;

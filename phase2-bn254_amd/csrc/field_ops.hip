@@ -5,6 +5,8 @@
 // integer-ALU roofline the MSM / NTT kernels are priced against.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <cstring>
 
 #include "../../include/mi355zk.h"
@@ -180,6 +182,69 @@ int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const u
     }
     r = zk::xyzzu_to_std(acc);
   }
+  std::memcpy(out_xyzz, &r, sizeof r);
+  return ZK_OK;
+}
+
+// The R-domain records of the G1 bucket reduction (curveu.hpp) on the HOST: n signed affine points are accumulated into n_groups
+// buckets (group[i] < n_groups) by the U-form mixed addition, every bucket becomes a record (xyzzu_to_r), and the records are summed
+// in group order -- mode 0: one running sum kept in registers (xyzzr_add), mode 1: through a record after every addition
+// (xyzzr_load / xyzzr_store, what the LDS trees do).  out = memory-format XYZZ of the total (xyzzr_to_std).
+int mi355zk_selftest_g1_record_sum(int mode, const uint64_t* affine_pts, const uint8_t* negate, const uint32_t* group, size_t n, size_t n_groups,
+                                   uint64_t out_xyzz[16]) {
+  if ((!affine_pts || !negate || !group) && n) return ZK_ERR_BAD_ARGS;
+  if (!out_xyzz || n_groups == 0) return ZK_ERR_BAD_ARGS;
+  std::vector<zk::XYZZU<zk::FqParams>> acc(n_groups, zk::XYZZU<zk::FqParams>::zero());
+  for (size_t i = 0; i < n; ++i) {
+    if (group[i] >= n_groups) return ZK_ERR_BAD_ARGS;
+    zk::G1Affine p;
+    std::memcpy(&p, affine_pts + 8 * i, 64);
+    zk::xyzzu_add_mixed(acc[group[i]], p.x, p.y, negate[i] != 0);
+  }
+  zk::G1XYZZ total = zk::G1XYZZ::zero();
+  zk::XYZZU<zk::FqParams> run = zk::XYZZU<zk::FqParams>::zero();
+  for (size_t g = 0; g < n_groups; ++g) {
+    const zk::G1XYZZ rec = zk::xyzzu_to_r(acc[g]);
+    if (mode == 0) {
+      zk::xyzzr_add(run, zk::xyzzr_load(rec));
+    } else {
+      zk::XYZZU<zk::FqParams> t = zk::xyzzr_load(total);
+      zk::xyzzr_add(t, zk::xyzzr_load(rec));
+      total = zk::xyzzr_store(t);
+    }
+  }
+  if (mode == 0) total = zk::xyzzr_store(run);
+  const zk::G1XYZZ r = zk::xyzzr_to_std(total);
+  std::memcpy(out_xyzz, &r, sizeof r);
+  return ZK_OK;
+}
+
+// the same for G2 (16 u64 per affine point; out = memory-format XYZZ over Fq2: 32 u64)
+int mi355zk_selftest_g2_record_sum(int mode, const uint64_t* affine_pts, const uint8_t* negate, const uint32_t* group, size_t n, size_t n_groups,
+                                   uint64_t out_xyzz[32]) {
+  if ((!affine_pts || !negate || !group) && n) return ZK_ERR_BAD_ARGS;
+  if (!out_xyzz || n_groups == 0) return ZK_ERR_BAD_ARGS;
+  std::vector<zk::XYZZU2> acc(n_groups, zk::XYZZU2::zero());
+  for (size_t i = 0; i < n; ++i) {
+    if (group[i] >= n_groups) return ZK_ERR_BAD_ARGS;
+    zk::G2Affine p;
+    std::memcpy(&p, affine_pts + 16 * i, 128);
+    zk::xyzzu2_add_mixed(acc[group[i]], p.x, p.y, negate[i] != 0);
+  }
+  zk::G2XYZZ total = zk::G2XYZZ::zero();
+  zk::XYZZU2 run = zk::XYZZU2::zero();
+  for (size_t g = 0; g < n_groups; ++g) {
+    const zk::G2XYZZ rec = zk::xyzzu_to_r(acc[g]);
+    if (mode == 0) {
+      zk::xyzzr_add(run, zk::xyzzr_load(rec));
+    } else {
+      zk::XYZZU2 t = zk::xyzzr_load(total);
+      zk::xyzzr_add(t, zk::xyzzr_load(rec));
+      total = zk::xyzzr_store(t);
+    }
+  }
+  if (mode == 0) total = zk::xyzzr_store(run);
+  const zk::G2XYZZ r = zk::xyzzr_to_std(total);
   std::memcpy(out_xyzz, &r, sizeof r);
   return ZK_OK;
 }

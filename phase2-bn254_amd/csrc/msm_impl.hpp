@@ -955,6 +955,20 @@ inline void msm_order_by_size(const uint32_t* first, const uint32_t* last, uint3
 
 constexpr uint32_t MSM_HEAVY_BLOCKS = 65536;  // at most this many buckets take the segment-parallel path (the rest of a pathological input runs one lane per bucket)
 
+// Bucket sums and everything derived from them (segment sums, running sums, tree sums, window sums) are XYZZ records in the R
+// domain of curveu.hpp (canonical coordinates in the 2^261 domain, 128 B for G1 and 256 B for G2): additions run on U-form
+// arithmetic -- 1.33 x the product rate of the memory format (tools/ubench_fieldmul.hip) and one reduction per Fq2 component.
+template <class F>
+__host__ __device__ __forceinline__ void rec_add(XYZZ<F>& a, const XYZZ<F>& b) {
+  if (b.is_zero()) return;
+  if (a.is_zero()) { a = b; return; }
+  auto ua = xyzzr_load(a);
+  xyzzr_add(ua, xyzzr_load(b));
+  a = xyzzr_store(ua);
+}
+template <class F>
+__host__ __device__ __forceinline__ XYZZ<F> rec_to_std(const XYZZ<F>& r) { return xyzzr_to_std(r); }
+
 // A4: the index list starts on a multiple of 4 entries, is walked with stride 1 and its padding slots are readable (the
 // lists the partition writes): a lane reads its indices FOUR AT A TIME with one 16-byte load.  Read one by
 // one, a lane touches each 128-byte line of its list 32 times, ~10^4 instructions apart, and by then the line has usually
@@ -1006,7 +1020,7 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
       p = pn;
       j = jn;
     }
-    return xyzzu_to_std(acc);
+    return xyzzu_to_r(acc);  // an R-domain record (curveu.hpp): what every consumer of G1 bucket sums below works on
   } else {
     XYZZU2 acc = XYZZU2::zero();
     for (; j < e; j += stride) {
@@ -1018,7 +1032,7 @@ __device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ 
       }
       xyzzu2_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
     }
-    return xyzzu2_to_std(acc);
+    return xyzzu_to_r(acc);
   }
 }
 
@@ -1068,7 +1082,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
       if (threadIdx.x < s) {
         XYZZ<F> a = sh[threadIdx.x];
-        xyzz_add(a, sh[threadIdx.x + s]);
+        rec_add(a, sh[threadIdx.x + s]);
         sh[threadIdx.x] = a;
       }
       __syncthreads();
@@ -1088,13 +1102,13 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __
     const uint32_t lo = item_off[i], hi = item_off[i + 1];
     if (hi == lo) continue;  // not heavy (uniform per workgroup)
     XYZZ<F> acc = XYZZ<F>::zero();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) xyzz_add(acc, load_vec(seg_sums + k));
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) rec_add(acc, load_vec(seg_sums + k));
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
       if (threadIdx.x < s) {
         XYZZ<F> a = sh[threadIdx.x];
-        xyzz_add(a, sh[threadIdx.x + s]);
+        rec_add(a, sh[threadIdx.x + s]);
         sh[threadIdx.x] = a;
       }
       __syncthreads();
@@ -1136,20 +1150,21 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __
   uint32_t w = t / chunks, ch = t % chunks;
   uint32_t lo = ch * L, hi = lo + L < count ? lo + L : count;
   const XYZZ<F>* B = in + (uint64_t)w * count;
-  XYZZ<F> run = XYZZ<F>::zero(), acc = XYZZ<F>::zero();
   uint32_t steps = 2 * (hi - lo);
+  // R-domain records: both running sums stay in U-form registers, a bucket is re-packed (no product) when it is loaded
+  auto run = xyzzr_load(XYZZ<F>::zero()), acc = run;
   for (uint32_t it = 0; it < steps; ++it) {
     uint32_t x = hi - 1 - (it >> 1);
     // off == 1: run += B[x]; acc += run   (weights y+1)      off == 0: acc += run; run += B[x]   (weights y)
     bool do_acc = ((it & 1) != 0) == (off != 0);
-    XYZZ<F> a = do_acc ? acc : run;
-    XYZZ<F> b = do_acc ? run : load_vec(B + x);
-    xyzz_add(a, b);
+    auto a = do_acc ? acc : run;
+    auto b = do_acc ? run : xyzzr_load(load_vec(B + x));
+    xyzzr_add(a, b);
     if (do_acc) acc = a;
     else run = a;
   }
-  store_vec(outA + t, acc);
-  store_vec(outS + t, run);
+  store_vec(outA + t, xyzzr_store(acc));
+  store_vec(outS + t, xyzzr_store(run));
 }
 
 // 5b/5c. the tail of the reduction, by trees.  A running-sum level costs 2L dependent additions however few
@@ -1194,7 +1209,7 @@ __global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J, XYZZ
   // consume; the regions written in consecutive rounds are disjoint from the ones still being read, so one
   // barrier per round.
   for (uint32_t s = 256;;) {
-    xyzz_add(acc, other);
+    rec_add(acc, other);
     s >>= 1;
     if (s == 0) break;
     if (threadIdx.x >= s && threadIdx.x < 2 * s) sh[threadIdx.x] = acc;
@@ -1781,7 +1796,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       std::vector<Jacobian<F>> by_exp((size_t)G.shift[w_hi - 1] + e_k[n_out - 1] + 1, Jacobian<F>::zero());
       for (uint32_t wl = 0; wl < WL; ++wl)
         for (uint32_t k = 0; k < n_out; ++k) {
-          const XYZZ<F>& pt = h_wsums[(size_t)wl * n_out + k];
+          const XYZZ<F> pt = rec_to_std(h_wsums[(size_t)wl * n_out + k]);
           if (!pt.is_zero()) jac_add(by_exp[G.shift[w_lo + wl] + e_k[k]], xyzz_to_jacobian(pt));
         }
       acc = horner(by_exp);
@@ -1801,7 +1816,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
         if (w < (int)w_lo) continue;
         std::vector<Jacobian<F>> by_exp((size_t)e_k[n_out - 1] + 1, Jacobian<F>::zero());
         for (uint32_t k = 0; k < n_out; ++k) {
-          const XYZZ<F>& pt = h_wsums[(size_t)(w - (int)w_lo) * n_out + k];
+          const XYZZ<F> pt = rec_to_std(h_wsums[(size_t)(w - (int)w_lo) * n_out + k]);
           if (!pt.is_zero()) jac_add(by_exp[e_k[k]], xyzz_to_jacobian(pt));
         }
         jac_add(acc, horner(by_exp));

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mi355zk_bn254_fr_divide_by_z_on_coset_dev": (_i, [_vp, _u32, _vp]),
     "mi355zk_bn254_fr_domain_z": (_i, [_u32, _vp, _vp]),
     "mi355zk_ubench_fp_mul": (_i, [_i, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_float)]),
+    "mi355zk_selftest_g1_record_sum": (_i, [_i, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "mi355zk_selftest_g2_record_sum": (_i, [_i, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_selftest_u_mul": (_i, [_i, _vp, _vp, _vp]),
     "mi355zk_selftest_u_sub": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "mi355zk_selftest_u_pack": (_i, [_i, _vp, _vp, _vp, _vp]),

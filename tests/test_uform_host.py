@@ -171,6 +171,44 @@ def test_u_accumulation_long_chain_keeps_invariants(lib):
     assert M.g1_jac_from_raw(acc) == outs[1]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_g1_record_sums_in_the_r_domain_on_host(lib, mode):
+    """The records of the G1 bucket reduction (curveu.hpp: 2^261-domain XYZZ): buckets accumulated by the mixed addition, turned
+    into records and summed by the FULL U-form addition -- kept in registers (mode 0) or stored and re-loaded after every
+    addition (mode 1) -- against the big-int model.  Covers: ordinary sums; empty buckets (infinity operands on either side);
+    the same point in two buckets, once with ZZ = 1 and once behind a cancelled detour so that ZZ != 1 (doubling branch); a
+    bucket and its negative (infinity); restarting from infinity; and a long chain (invariants)."""
+    n = 48
+    raw = inputs.bases_cpu(1, n, seed=777)
+    pts = [M.g1_affine_from_raw(r) for r in raw]
+    cases = [
+        [(0, 0, 0), (1, 0, 1), (2, 1, 1), (3, 0, 2)],                                  # P0 + (P1 - P2) + P3
+        [(0, 0, 1), (1, 0, 3)],                                                        # empty buckets 0 and 2
+        [(0, 0, 0), (0, 0, 1)],                                                        # P0 + P0, both ZZ = 1
+        [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1)],                                  # (P0 + P1 - P1) + P0: doubling with ZZ != 1
+        [(0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1)],                                  # (P0 + P1) + (-P0 - P1) = infinity
+        [(0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1), (2, 0, 2), (3, 1, 3)],            # ... and on from infinity
+        [(i, rnd.randrange(2), rnd.randrange(12)) for i in range(n)],                  # 12 buckets of ~4
+        [(i % n, rnd.randrange(2), j // 3) for j, i in enumerate(range(600))],         # 200 records in one chain
+    ]
+    for sub in cases:
+        n_groups = max(g for _, _, g in sub) + 1
+        arr = np.ascontiguousarray(np.stack([raw[i] for i, _, _ in sub]))
+        neg = np.array([s for _, s, _ in sub], dtype=np.uint8)
+        grp = np.array([g for _, _, g in sub], dtype=np.uint32)
+        out = np.zeros(16, np.uint64)
+        assert lib.mi355zk_selftest_g1_record_sum(mode, arr.ctypes.data, neg.ctypes.data, grp.ctypes.data, len(sub), n_groups, out.ctypes.data) == 0
+        want = None
+        for g in range(n_groups):                       # group order, as the library sums them (the group law is associative anyway)
+            b = None
+            for i, s, gg in sub:
+                if gg == g:
+                    b = M.ec_add(M.FQ_OPS, b, M.ec_neg(M.FQ_OPS, pts[i]) if s else pts[i])
+            want = M.ec_add(M.FQ_OPS, want, b)
+        assert _xyzz_to_affine(out) == want, (mode, sub[:6])
+        assert all(M.from_limbs(out[4 * i:4 * i + 4]) < M.Q for i in range(4))
+
+
 def _xyzz2_to_affine(x):
     c = [M.from_mont(M.from_limbs(x[4 * i:4 * i + 4]), M.Q) for i in range(8)]
     X, Y, ZZ, ZZZ = (c[0], c[1]), (c[2], c[3]), (c[4], c[5]), (c[6], c[7])
@@ -197,6 +235,40 @@ def test_g2_bucket_accumulation_on_host(lib, mode):
         for i, s in sub:
             want = M.ec_add(M.FQ2_OPS, want, M.ec_neg(M.FQ2_OPS, pts[i]) if s else pts[i])
         assert _xyzz2_to_affine(out) == want, (mode, prefix)
+        assert all(M.from_limbs(out[4 * i:4 * i + 4]) < M.Q for i in range(8))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_g2_record_sums_in_the_r_domain_on_host(lib, mode):
+    """G2 twin of test_g1_record_sums_in_the_r_domain_on_host (the full U-form addition over Fq2 and its rare branches)."""
+    n = 24
+    raw = inputs.bases_cpu(2, n, seed=778)
+    pts = [M.g2_affine_from_raw(r) for r in raw]
+    cases = [
+        [(0, 0, 0), (1, 0, 1), (2, 1, 1), (3, 0, 2)],
+        [(0, 0, 1), (1, 0, 3)],
+        [(0, 0, 0), (0, 0, 1)],
+        [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1)],
+        [(0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1)],
+        [(0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1), (2, 0, 2), (3, 1, 3)],
+        [(i, rnd.randrange(2), rnd.randrange(8)) for i in range(n)],
+        [(i % n, rnd.randrange(2), j // 3) for j, i in enumerate(range(240))],
+    ]
+    for sub in cases:
+        n_groups = max(g for _, _, g in sub) + 1
+        arr = np.ascontiguousarray(np.stack([raw[i] for i, _, _ in sub]))
+        neg = np.array([s for _, s, _ in sub], dtype=np.uint8)
+        grp = np.array([g for _, _, g in sub], dtype=np.uint32)
+        out = np.zeros(32, np.uint64)
+        assert lib.mi355zk_selftest_g2_record_sum(mode, arr.ctypes.data, neg.ctypes.data, grp.ctypes.data, len(sub), n_groups, out.ctypes.data) == 0
+        want = None
+        for g in range(n_groups):
+            b = None
+            for i, s, gg in sub:
+                if gg == g:
+                    b = M.ec_add(M.FQ2_OPS, b, M.ec_neg(M.FQ2_OPS, pts[i]) if s else pts[i])
+            want = M.ec_add(M.FQ2_OPS, want, b)
+        assert _xyzz2_to_affine(out) == want, (mode, sub[:6])
         assert all(M.from_limbs(out[4 * i:4 * i + 4]) < M.Q for i in range(8))
 
 
