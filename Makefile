@@ -9,12 +9,12 @@ HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-re
 OBJS := build/ntt.o build/msm_g1.o build/msm_g2.o build/api.o build/field_ops.o build/point_fft.o build/point_fft_g2.o build/codec.o
 HDRS := $(SRC)/field.hpp $(SRC)/mont_mul_gfx950.inc $(SRC)/curve.hpp $(SRC)/fieldu.hpp $(SRC)/curveu.hpp $(SRC)/device_util.hpp $(SRC)/msm_impl.hpp include/mi355zk.h
 
-all: $(PKG)/libmi355zk.so oracle tools/bin/ubench_valu tools/bin/ubench_gather
+all: $(PKG)/libmi355zk.so oracle tools/bin/ubench_valu tools/bin/ubench_gather tools/bin/ubench_fieldmul tools/bin/ubench_wave_bucket
 
 # standalone microbenchmarks (instruction issue rates; FETCH_SIZE calibration) used by tools/refresh_profiles.sh
-tools/bin/%: tools/%.hip
+tools/bin/%: tools/%.hip $(HDRS)
 	@mkdir -p tools/bin
-	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -Wno-unused-value -Wno-unused-result $< -o $@
 
 $(PKG)/libmi355zk.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)

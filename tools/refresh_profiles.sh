@@ -29,6 +29,10 @@ timeout 400 python $R/tools/bench_skew.py --log-n 26 --iters 2 > $O/skew_2e26.js
 timeout 400 $B --steps 5 --warmup 1 --bases tau --no-cpu-baseline > $O/bench_n1_tau.json 2>/dev/null
 $R/tools/bin/ubench_valu > $O/ubench_valu.txt 2>&1
 $R/tools/bin/ubench_gather > $O/ubench_gather.txt 2>&1
+$R/tools/bin/ubench_fieldmul > $O/ubench_fieldmul.txt 2>&1
+$R/tools/bin/ubench_wave_bucket > $O/ubench_wave_bucket.txt 2>&1
+for lm in 16 20; do timeout 200 python $R/tools/bench_prover.py --log-m $lm; done > $O/prover.json 2>/dev/null
+for ln in 16 20; do timeout 200 python $R/tools/bench_skew.py --log-n $ln --iters 10; done > $O/skew_small.json 2>/dev/null
 rm -rf /tmp/p_g; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_g -- $R/tools/bin/ubench_gather > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_g -name "*.db" | head -1) --pmc > $O/ubench_gather_fetch_size.txt
 ls -la $O
