@@ -965,17 +965,24 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   // ---- chunks (cut at multiples of 32 exponents, so that density words are not shared between chunks)
   std::vector<uint64_t> cuts{0};
   if (n >= 2 * HOST_CHUNK_MIN) {
-    // bases cached: the kernels are the bottleneck, so one small chunk gets the device going early and large ones follow (a 2^24
-    // multiexp runs at 90 % of the 2^26 rate, a 2^22 one at 65 %).  Bases travelling too (96 B per exponent): even chunks -- small
-    // ones were measured and lose (16 chunks of 2^22: 243 ms for 2^26 against 137 ms with four: pageable copies of 100-MB pieces
-    // run far below the link rate)
-    const uint64_t head = upload_bases ? 0 : HOST_CHUNK_MIN;
-    if (head) cuts.push_back(head);
-    const uint64_t rest = n - head;
-    uint64_t k = (rest + HOST_CHUNK - 1) / HOST_CHUNK;
-    if (k < 2 && !head) k = 2;
-    const uint64_t per = ((rest + k - 1) / k + 31) & ~31ull;
-    for (uint64_t lo = head + per; lo < n; lo += per) cuts.push_back(lo);
+    // Bases travelling too (96 B per exponent): the link is the bottleneck; even chunks of 2^24 -- small ones were measured and
+    // lose (16 chunks of 2^22: 243 ms for 2^26 against 137 ms with four: pageable copies of 100-MB pieces run far below the link
+    // rate).  Bases cached: the kernels are the bottleneck and a multiexp is the more efficient the larger it is (2^22: 65 % of the
+    // 2^26 rate, 2^24: 90 %), so the chunks DOUBLE: a small one gets the device going, and each chunk's upload hides behind the
+    // previous chunk's kernels (the link moves a chunk in half the time the kernels need for one of half the size).
+    if (upload_bases) {
+      uint64_t k = (n + HOST_CHUNK - 1) / HOST_CHUNK;
+      if (k < 2) k = 2;
+      const uint64_t per = ((n + k - 1) / k + 31) & ~31ull;
+      for (uint64_t lo = per; lo < n; lo += per) cuts.push_back(lo);
+    } else {
+      uint64_t lo = 0, sz = HOST_CHUNK_MIN;
+      while (n - lo > sz + sz / 2) {  // the last chunk takes what is left, up to 1.5 x the next size
+        lo += sz;
+        cuts.push_back(lo);
+        sz <<= 1;
+      }
+    }
   }
   if (n) cuts.push_back(n);
   const uint64_t n_chunks = cuts.size() - 1;
