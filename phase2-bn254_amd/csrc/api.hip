@@ -839,9 +839,11 @@ void bases_drop(const std::shared_ptr<BasesEntry>& e) {  // a failed upload
   e->d = nullptr;
 }
 
-// per (thread, device): two staging buffers for scalar chunks, a bases buffer for uncached calls, the two streams
+// two staging buffers for scalar chunks, a bases buffer for uncached calls, the two streams.  Leased from a pool for the duration
+// of a call (callers come and go -- the prover queues its multiexps from short-lived threads -- and their buffers must not pile up)
 struct HostStage {
   int dev = -1;
+  bool busy = false;
   void* sc[2] = {nullptr, nullptr};
   size_t sc_bytes = 0;
   void* bases = nullptr;
@@ -849,18 +851,40 @@ struct HostStage {
   hipStream_t copy = nullptr, compute = nullptr;
 };
 std::mutex g_stage_mu;
-std::vector<HostStage*> g_stages;  // every thread's stage, for mi355zk_shutdown
-HostStage* host_stage(int dev) {
-  thread_local HostStage* mine = nullptr;
-  if (mine == nullptr || mine->dev != dev) {
+std::vector<HostStage*> g_stages;  // the pool: as many stages as there have been concurrent host-buffer calls
+struct StageLease {
+  HostStage* s = nullptr;
+  ~StageLease() {
+    if (s == nullptr) return;
+    // every exit of msm_host_entry has joined its copy thread; the compute stream is idle after the last chunk's result came back,
+    // except on an error path
+    (void)hipStreamSynchronize(s->compute);
+    (void)hipStreamSynchronize(s->copy);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    s->busy = false;
+  }
+};
+HostStage* host_stage(int dev, StageLease* lease) {
+  HostStage* mine = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    for (HostStage* s : g_stages)  // the idle stage of this device with the largest staging buffers
+      if (!s->busy && s->dev == dev && (mine == nullptr || s->sc_bytes > mine->sc_bytes)) mine = s;
+    if (mine) mine->busy = true;
+  }
+  if (mine == nullptr) {
     mine = new HostStage();
     mine->dev = dev;
+    mine->busy = true;
     if (hipStreamCreateWithFlags(&mine->copy, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&mine->compute, hipStreamNonBlocking) != hipSuccess)
+        hipStreamCreateWithFlags(&mine->compute, hipStreamNonBlocking) != hipSuccess) {
+      delete mine;
       return nullptr;
+    }
     std::lock_guard<std::mutex> lk(g_stage_mu);
     g_stages.push_back(mine);
   }
+  lease->s = mine;
   return mine;
 }
 int stage_reserve(void** p, size_t* have, size_t want) {
@@ -917,7 +941,8 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   using Jac = typename std::conditional<GROUP == 1, G1Jacobian, G2Jacobian>::type;
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
-  HostStage* S = host_stage(dev);
+  StageLease stage_lease;
+  HostStage* S = host_stage(dev, &stage_lease);
   if (S == nullptr) return ZK_ERR_DEVICE;
 
   // the exponents this call evaluates and the bases they consume (source.rs:36-118)

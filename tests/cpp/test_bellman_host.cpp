@@ -10,6 +10,7 @@
 
 #include "../../phase2-bn254_amd/host/bellman.hpp"
 #include "../../phase2-bn254_amd/host/ceremony.hpp"
+#include "../../phase2-bn254_amd/host/prover.hpp"
 
 extern "C" {
 void oracle_g1_mul_many_affine(uint64_t* out_affine, const uint64_t base_affine[8], const uint64_t* ks, size_t n);
@@ -23,6 +24,14 @@ void oracle_g1_mul(uint64_t p[12], const uint64_t k[4]);
 void oracle_g1_from_affine(uint64_t r[12], const uint64_t p[8]);
 void oracle_g1_add(uint64_t p[12], const uint64_t o[12]);
 void oracle_g1_encode(uint8_t* out, const uint64_t* affine, size_t n, int compressed);
+void oracle_g2_mul_many_affine(uint64_t* out_affine, const uint64_t base_affine[16], const uint64_t* ks, size_t n);
+void oracle_g2_naive_multiexp(const uint64_t* bases, const uint64_t* scalars, size_t n, uint64_t out_xyz[24]);
+void oracle_g2_to_affine(uint64_t r[16], const uint64_t p[24]);
+void oracle_g2_from_affine(uint64_t r[24], const uint64_t p[16]);
+void oracle_g2_mul(uint64_t p[24], const uint64_t k[4]);
+void oracle_g2_add(uint64_t p[24], const uint64_t o[24]);
+void oracle_fe_to_canonical(int which, uint64_t r[4], const uint64_t a[4]);
+void oracle_fe_inv(int which, uint64_t r[4], const uint64_t a[4]);
 }
 
 using namespace bellman;
@@ -188,5 +197,127 @@ int main() {
     CHECK(std::memcmp(pts.data(), orig.data(), 16 * 64) == 0);
   }
   std::puts("ok ceremony_mirror");
+
+  {  // host/prover.hpp: groth16 create_proof (prover.rs:202-343) on a synthetic 2^8-constraint instance, against a proof assembled
+     // from the oracle's domain ops, field arithmetic, naive multiexps and group law
+    using namespace bellman::groth16;
+    static const uint64_t G2_GEN[16] = {0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL,
+                                        0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL, 0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL,
+                                        0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL,
+                                        0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL};
+    const uint32_t log_m = 8;
+    const size_t m = (size_t)1 << log_m, num_inputs = 5, num_aux = m - 11;
+    auto g1_pts = [&](size_t n) {
+      std::vector<FrRepr> ks(n);
+      for (auto& k : ks) k = rand_scalar(gen);
+      auto v = std::make_shared<std::vector<G1Affine>>(n);
+      oracle_g1_mul_many_affine(reinterpret_cast<uint64_t*>(v->data()), g1, reinterpret_cast<const uint64_t*>(ks.data()), n);
+      return v;
+    };
+    auto g2_pts = [&](size_t n) {
+      std::vector<FrRepr> ks(n);
+      for (auto& k : ks) k = rand_scalar(gen);
+      auto v = std::make_shared<std::vector<G2Affine>>(n);
+      oracle_g2_mul_many_affine(reinterpret_cast<uint64_t*>(v->data()), G2_GEN, reinterpret_cast<const uint64_t*>(ks.data()), n);
+      return v;
+    };
+    // witness-like canonical assignments (zeros, ones, random), kept in Montgomery form like the prover's Vec<Fr>
+    auto witness = [&](size_t n, std::vector<FrRepr>& canon) {
+      std::vector<Fr> mont(n);
+      canon.resize(n);
+      for (size_t i = 0; i < n; ++i) {
+        const uint64_t kind = gen() % 10;
+        canon[i] = kind < 2 ? FrRepr{0, 0, 0, 0} : kind < 5 ? FrRepr{1, 0, 0, 0} : rand_scalar(gen);
+        oracle_fe_from_canonical(1, mont[i].data(), canon[i].data());
+      }
+      return mont;
+    };
+    ProvingAssignment pa;
+    std::vector<FrRepr> inp_c, aux_c;
+    pa.input_assignment = witness(num_inputs, inp_c);
+    pa.aux_assignment = witness(num_aux, aux_c);
+    std::vector<char> a_bits(num_aux), bi_bits(num_inputs), ba_bits(num_aux);
+    for (size_t i = 0; i < num_aux; ++i) { pa.a_aux_density.add_element(); if ((a_bits[i] = gen() & 1)) pa.a_aux_density.inc(i); }
+    for (size_t i = 0; i < num_inputs; ++i) { pa.b_input_density.add_element(); if ((bi_bits[i] = gen() & 1)) pa.b_input_density.inc(i); }
+    for (size_t i = 0; i < num_aux; ++i) { pa.b_aux_density.add_element(); if ((ba_bits[i] = (gen() % 5) < 2)) pa.b_aux_density.inc(i); }
+    const size_t na = pa.a_aux_density.get_total_density(), nbi = pa.b_input_density.get_total_density(), nba = pa.b_aux_density.get_total_density();
+    std::vector<Fr> ev[3];
+    for (auto& v : ev) { v.resize(m); for (auto& x : v) x = rand_scalar(gen); }   // any value < r is a valid Montgomery element
+    pa.a = ev[0]; pa.b = ev[1]; pa.c = ev[2];
+    Parameters params;
+    params.h = g1_pts(m - 1); params.l = g1_pts(num_aux); params.a = g1_pts(num_inputs + na); params.b_g1 = g1_pts(nbi + nba); params.b_g2 = g2_pts(nbi + nba);
+    {
+      auto v1 = g1_pts(3); auto v2 = g2_pts(2);
+      params.vk = VerifyingKey{(*v1)[0], (*v1)[1], (*v1)[2], (*v2)[0], (*v2)[1]};
+    }
+    const FrRepr r = rand_scalar(gen), s = rand_scalar(gen);
+    const Proof proof = create_proof(worker, params, pa, r, s);
+
+    // ---- the same proof from the oracle
+    for (auto& v : ev) { CHECK(oracle_fr_domain_op(reinterpret_cast<uint64_t*>(v.data()), log_m, 1, 0) == 0); CHECK(oracle_fr_domain_op(reinterpret_cast<uint64_t*>(v.data()), log_m, 2, 0) == 0); }
+    uint64_t zg[4], zinv[4];
+    {
+      uint64_t seven_c[4] = {7, 0, 0, 0}, seven[4], one_c[4] = {1, 0, 0, 0}, one[4], acc[4];
+      oracle_fe_from_canonical(1, seven, seven_c);
+      oracle_fe_from_canonical(1, one, one_c);
+      std::memcpy(acc, seven, 32);
+      for (uint32_t i = 0; i < log_m; ++i) oracle_fe_mul(1, acc, acc, acc);   // 7^m
+      oracle_fe_sub(1, zg, acc, one);
+      oracle_fe_inv(1, zinv, zg);
+    }
+    std::vector<Fr> hq(m);
+    for (size_t i = 0; i < m; ++i) {
+      uint64_t ab[4], d[4];
+      oracle_fe_mul(1, ab, ev[0][i].data(), ev[1][i].data());
+      oracle_fe_sub(1, d, ab, ev[2][i].data());
+      oracle_fe_mul(1, hq[i].data(), d, zinv);
+    }
+    CHECK(oracle_fr_domain_op(reinterpret_cast<uint64_t*>(hq.data()), log_m, 3, 0) == 0);
+    std::vector<FrRepr> h_c(m - 1);
+    for (size_t i = 0; i + 1 < m; ++i) oracle_fe_to_canonical(1, h_c[i].data(), hq[i].data());
+    auto sum1 = [&](const std::vector<G1Affine>& bases, size_t off, const std::vector<FrRepr>& e, const std::vector<char>* bits, uint64_t out[12]) {
+      std::vector<G1Affine> b; std::vector<FrRepr> k;
+      size_t next = off;
+      for (size_t i = 0; i < e.size(); ++i) if (!bits || (*bits)[i]) { b.push_back(bases[next++]); k.push_back(e[i]); }
+      oracle_g1_naive_multiexp(reinterpret_cast<const uint64_t*>(b.data()), reinterpret_cast<const uint64_t*>(k.data()), b.size(), out);
+    };
+    auto sum2 = [&](const std::vector<G2Affine>& bases, size_t off, const std::vector<FrRepr>& e, const std::vector<char>* bits, uint64_t out[24]) {
+      std::vector<G2Affine> b; std::vector<FrRepr> k;
+      size_t next = off;
+      for (size_t i = 0; i < e.size(); ++i) if (!bits || (*bits)[i]) { b.push_back(bases[next++]); k.push_back(e[i]); }
+      oracle_g2_naive_multiexp(reinterpret_cast<const uint64_t*>(b.data()), reinterpret_cast<const uint64_t*>(k.data()), b.size(), out);
+    };
+    uint64_t h_o[12], l_o[12], a_in[12], a_ax[12], b1_in[12], b1_ax[12], b2_in[24], b2_ax[24];
+    sum1(*params.h, 0, h_c, nullptr, h_o);
+    sum1(*params.l, 0, aux_c, nullptr, l_o);
+    sum1(*params.a, 0, inp_c, nullptr, a_in);
+    sum1(*params.a, num_inputs, aux_c, &a_bits, a_ax);
+    sum1(*params.b_g1, 0, inp_c, &bi_bits, b1_in);
+    sum1(*params.b_g1, nbi, aux_c, &ba_bits, b1_ax);
+    sum2(*params.b_g2, 0, inp_c, &bi_bits, b2_in);
+    sum2(*params.b_g2, nbi, aux_c, &ba_bits, b2_ax);
+    auto mul1 = [&](const G1Affine& p, const FrRepr& k, uint64_t out[12]) { oracle_g1_from_affine(out, reinterpret_cast<const uint64_t*>(&p)); oracle_g1_mul(out, k.data()); };
+    uint64_t g_a[12], g_b[24], g_c[12], t[12], t2[24];
+    mul1(params.vk.delta_g1, r, g_a);
+    oracle_g1_from_affine(t, reinterpret_cast<const uint64_t*>(&params.vk.alpha_g1)); oracle_g1_add(g_a, t);
+    oracle_g2_from_affine(g_b, reinterpret_cast<const uint64_t*>(&params.vk.delta_g2)); oracle_g2_mul(g_b, s.data());
+    oracle_g2_from_affine(t2, reinterpret_cast<const uint64_t*>(&params.vk.beta_g2)); oracle_g2_add(g_b, t2);
+    mul1(params.vk.delta_g1, r, g_c); oracle_g1_mul(g_c, s.data());
+    mul1(params.vk.alpha_g1, s, t); oracle_g1_add(g_c, t);
+    mul1(params.vk.beta_g1, r, t); oracle_g1_add(g_c, t);
+    oracle_g1_add(a_in, a_ax); oracle_g1_add(g_a, a_in); oracle_g1_mul(a_in, s.data()); oracle_g1_add(g_c, a_in);
+    oracle_g1_add(b1_in, b1_ax); oracle_g2_add(b2_in, b2_ax); oracle_g2_add(g_b, b2_in);
+    oracle_g1_mul(b1_in, r.data()); oracle_g1_add(g_c, b1_in);
+    oracle_g1_add(g_c, h_o); oracle_g1_add(g_c, l_o);
+    uint64_t wa[8], wb[16], wc[8];
+    oracle_g1_to_affine(wa, g_a); oracle_g2_to_affine(wb, g_b); oracle_g1_to_affine(wc, g_c);
+    CHECK(std::memcmp(wa, &proof.a, 64) == 0);
+    CHECK(std::memcmp(wb, &proof.b, 128) == 0);
+    CHECK(std::memcmp(wc, &proof.c, 64) == 0);
+    // a second proof on the same parameters (bases served from the device cache) is the same proof
+    const Proof again = create_proof(worker, params, pa, r, s);
+    CHECK(std::memcmp(&again, &proof, sizeof proof) == 0);
+  }
+  std::puts("ok groth16_create_proof");
   return 0;
 }

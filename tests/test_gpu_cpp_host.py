@@ -1,5 +1,5 @@
 """Builds and runs the C++ host mirror's test program (tests/cpp/test_bellman_host.cpp against
-phase2-bn254_amd/host/{bellman,ceremony}.hpp -> libmi355zk.so, checked with the oracle) on the GPU box."""
+phase2-bn254_amd/host/{bellman,ceremony,prover}.hpp -> libmi355zk.so, checked with the oracle) on the GPU box."""
 import os
 import subprocess
 
@@ -30,5 +30,5 @@ def test_cpp_host_mirror_against_oracle():
     _build()
     out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    for name in ("multiexp_equals_naive", "density_and_source_errors", "evaluation_domain", "ceremony_mirror"):
+    for name in ("multiexp_equals_naive", "density_and_source_errors", "evaluation_domain", "ceremony_mirror", "groth16_create_proof"):
         assert "ok " + name in out.stdout
