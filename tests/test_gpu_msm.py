@@ -178,6 +178,45 @@ def test_batch_mul_matches_oracle(zk, worker):
     assert np.array_equal(bases.cpu().numpy().view(np.uint64), want)
 
 
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("n", [64, 4096, 1 << 16])
+def test_repeated_bases_collide_in_the_bucket_reduction(zk, worker, group, n):
+    """One point, and its negative, repeated n times under scalars that are small multiples of a few window-sized steps: the
+    buckets hold k*P for small k, so bucket sums, running sums and tree partial sums keep meeting EQUAL and OPPOSITE operands --
+    the doubling and infinity branches of the full addition the bucket reduction runs on R-domain records (curveu.hpp
+    xyzzr_add), and of the mixed addition in the accumulation (same point twice in a row in one bucket).  The sum has the closed
+    form (sum of +/- k_i mod r) * P."""
+    import bn254_model as M
+
+    G = O.G1 if group == 1 else O.G2
+    rng = np.random.default_rng(n + group)
+    gen = inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW
+    p_aff = G.mul_many_affine(gen, inputs.random_scalars(1, seed=99))[0]
+    neg = p_aff.copy()
+    w = p_aff.size // 2
+    for c in range(w // 4):                                           # -P: negate every Fq component of y
+        y = M.from_limbs(neg[w + 4 * c:w + 4 * c + 4])
+        neg[w + 4 * c:w + 4 * c + 4] = M.to_limbs((M.Q - y) % M.Q)
+    signs = rng.integers(0, 2, size=n)
+    bases = np.ascontiguousarray(np.stack([neg if sg else p_aff for sg in signs]))
+    for variant in range(3):
+        if variant == 0:      # tiny scalars: everything lands in the first few buckets of window 0
+            ks = [int(v) for v in rng.integers(1, 4, size=n)]
+        elif variant == 1:    # a handful of values spread over every window
+            vals = [1, 2, (1 << 13) + 1, (1 << 64) + (1 << 21), M.R_ORDER - 1, M.R_ORDER - 2, (M.R_ORDER - 1) // 2]
+            ks = [vals[int(v)] for v in rng.integers(0, len(vals), size=n)]
+        else:                 # pairs k, then the same k on the opposite point: total cancellation bucket by bucket
+            half = [int(v) for v in rng.integers(1, 1 << 20, size=n // 2)]
+            ks = half + half
+            bases = np.ascontiguousarray(np.stack([p_aff] * (n // 2) + [neg] * (n // 2)))
+            signs = np.array([0] * (n // 2) + [1] * (n // 2))
+        scalars = np.array([M.to_limbs(k) for k in ks], dtype=np.uint64)
+        total = sum((-k if sg else k) for k, sg in zip(ks, signs)) % M.R_ORDER
+        got = G.to_affine(zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait())
+        want = G.to_affine(G.mul(G.from_affine(p_aff), np.array(M.to_limbs(total), dtype=np.uint64)))
+        assert np.array_equal(got, want), (group, n, variant)
+
+
 @pytest.mark.parametrize("log_n", [20, 22])
 def test_full_size_device_resident_properties(zk, worker, log_n):
     """BASELINE config 2 (2^20) and beyond, inputs resident in HBM.  Size-independent checks:
