@@ -676,6 +676,54 @@ int plan_density(size_t n_bases, size_t base_offset, size_t n_scalars, const uin
   return ZK_OK;
 }
 
+// device copies of density maps (words + prefix popcounts): grow-only buffers, leased per call
+struct DensityPool {
+  struct Buf {
+    int dev = -1;
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool busy = false;
+  };
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static std::vector<Buf*>& all() { static std::vector<Buf*> v; return v; }
+  struct Lease {
+    Buf* b = nullptr;
+    hipStream_t st = nullptr;
+    int acquire(int dev, size_t bytes, hipStream_t stream) {
+      st = stream;
+      {
+        std::lock_guard<std::mutex> lk(mu());
+        for (Buf* x : all())  // the smallest idle buffer that fits, else the largest idle one (regrown below)
+          if (!x->busy && x->dev == dev) {
+            if (b == nullptr) { b = x; continue; }
+            const bool fits = x->bytes >= bytes, bfits = b->bytes >= bytes;
+            if (fits ? (!bfits || x->bytes < b->bytes) : (!bfits && x->bytes > b->bytes)) b = x;
+          }
+        if (b == nullptr) {
+          b = new Buf();
+          b->dev = dev;
+          all().push_back(b);
+        }
+        b->busy = true;
+      }
+      if (b->bytes < bytes) {
+        if (b->p) ZK_HIP(hipFree(b->p));  // idle: its last user's stream was synchronised before the release
+        b->p = nullptr;
+        b->bytes = 0;
+        ZK_HIP(hipMalloc(&b->p, bytes));
+        b->bytes = bytes;
+      }
+      return ZK_OK;
+    }
+    ~Lease() {
+      if (b == nullptr) return;
+      (void)hipStreamSynchronize(st);  // (idle already after a completed call: the result came back over this stream)
+      std::lock_guard<std::mutex> lk(mu());
+      b->busy = false;
+    }
+  };
+};
+
 template <int GROUP>
 int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                   const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0,
@@ -690,25 +738,16 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
   uint64_t n = P.eof_index >= 0 ? (uint64_t)P.eof_index : P.n;  // exponents before the first Eof
   uint32_t* d_density = nullptr;
   uint32_t* d_prefix = nullptr;
+  DensityPool::Lease density_lease;
   if (density != nullptr && n > 0) {
-    // a grow-only buffer per host thread: hipMalloc / hipFree per call would synchronise the whole device and with it every
-    // other thread's multiexp
-    struct DensityBuf { int dev = -1; void* p = nullptr; size_t bytes = 0; };
-    thread_local DensityBuf buf;
+    // leased from a small pool for the duration of the call: hipMalloc / hipFree per call would synchronise the whole device and
+    // with it every other thread's multiexp, and a buffer per host thread would outlive short-lived caller threads
     int dev = 0;
     ZK_HIP(hipGetDevice(&dev));
     size_t words = (n + 31) / 32;
-    if (buf.dev != dev || buf.bytes < words * 8) {
-      if (buf.p) {
-        ZK_HIP(hipStreamSynchronize(st));
-        ZK_HIP(hipFree(buf.p));
-      }
-      buf.p = nullptr;
-      buf.bytes = 0;
-      ZK_HIP(hipMalloc(&buf.p, words * 8));
-      buf.bytes = words * 8;
-      buf.dev = dev;
-    }
+    rc = density_lease.acquire(dev, words * 8, st);
+    if (rc) return rc;
+    DensityPool::Buf& buf = *density_lease.b;
     d_density = (uint32_t*)buf.p;
     d_prefix = d_density + words;
     ZK_HIP(hipMemcpyAsync(d_density, density, words * 4, hipMemcpyHostToDevice, st));
@@ -925,6 +964,13 @@ void host_entry_release_all() {
     s->sc[0] = s->sc[1] = s->bases = nullptr;
     s->sc_bytes = s->bases_bytes = 0;
   }
+  std::lock_guard<std::mutex> dl(DensityPool::mu());
+  for (DensityPool::Buf* b : DensityPool::all()) {
+    (void)hipSetDevice(b->dev);
+    (void)hipFree(b->p);
+    b->p = nullptr;
+    b->bytes = 0;
+  }
 }
 
 constexpr uint64_t HOST_CHUNK = 1ull << 24;      // exponents per chunk of a streamed call whose bases are already on the device
@@ -965,7 +1011,7 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
     return r;
   };
 
-  // ---- bases: cached, being cached by this call, or (cache off / full) a per-thread buffer
+  // ---- bases: cached, being cached by this call, or (cache off / full) the leased stage's buffer
   bool fill = false;
   std::shared_ptr<BasesEntry> entry = n_bases ? bases_lookup(bases, n_bases, GROUP, n_bases * bsz, dev, &fill) : nullptr;
   void* d_bases = entry ? entry->d : nullptr;

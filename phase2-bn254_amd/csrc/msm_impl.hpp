@@ -8,20 +8,21 @@
 // and the group law underneath (pairing/src/bn256/ec.rs:301-536).
 //
 // MI355X design (DESIGN.md "MSM"), not the reference's one-thread-per-window scan:
-//   1. msm_digits_kernel      every scalar -> W signed digits; one (key, base index | sign) pair per window, written
-//                             window-major.
-//   2. radix sort             rocPRIM onesweep on the LOW c key bits only (stable + window-major input keeps every
-//                             (window, bucket) run contiguous); HBM-bound, ~3 passes over 8 B/pair.
-//   3. msm_bounds_kernel      first/last position of every bucket in the sorted pair list;
-//      msm_size_*_kernel      counting sort of the buckets by size (wave-level load balance, heavy buckets first).
-//   4. msm_accumulate_kernel  ONE LANE PER BUCKET for all W * 2^(c-1) buckets at once (2^19 lanes at
-//                             2^20 points), in size order: gathers its affine bases and folds them into a U-form
-//                             XYZZ accumulator held in VGPRs (8M+2S per point) -- the dominant kernel; the
-//                             identity-base check (source.rs:50-52) is fused in;
-//      msm_accumulate_heavy / msm_heavy_combine   segment-parallel path for buckets far longer than the mean.
+//   1. msm_digits_plain_kernel  every scalar -> W signed digits (power-of-two or mixed-radix windows), written window-major as
+//      msm_tile_hist_kernel     4-byte keys; per (window, super-tile) a histogram of the keys over the coarse bins.
+//   2. partition (hand-written, no library sort): column scans of the tile histograms give every (super-tile, window, bin) run
+//      its exact position; msm_scatter_kernel moves (key, base index) pairs into their bin through LDS; msm_bucket_kernel sorts
+//      every bin by bucket in registers and writes the per-bucket index lists (bucket starts aligned to 4 entries) and bounds;
+//      msm_bigbin_* handle bins that skewed inputs overfill.  HBM-bound: 28 B per (point, window).
+//   3. msm_size_*_kernel        counting sort of the buckets by size (wave-level load balance, heavy buckets first).
+//   4. msm_accumulate_kernel    ONE LANE PER BUCKET for all W * nb buckets at once, in size order: gathers its affine bases and
+//                               folds them into a U-form XYZZ accumulator held in VGPRs (8M+2S per point) -- the dominant
+//                               kernel; the identity-base check (source.rs:50-52) is fused in;
+//      msm_accumulate_heavy / msm_heavy_combine   segment-parallel path for buckets that one lane would walk too long.
 //   5. msm_reduce_level_kernel  sum_k k*B_k per window by chunked running sums (levels), then
-//      msm_tree_kernel          pairwise trees: plain sums of the levels' A[] and the bit decomposition of the rest.
-//   6. host                   ONE Horner pass over all partial sums, grouped by their power of two (multiexp.rs:146-154).
+//      msm_tree_kernel          pairwise trees: plain sums of the levels' A[] and the bit decomposition of the rest;
+//                               both on R-domain XYZZ records (curveu.hpp: U-form full additions).
+//   6. host                     ONE Horner pass over all partial sums, grouped by their power of two (multiexp.rs:146-154).
 // The result is a group element; the reference compares/normalises projective points by value
 // (ec.rs:45-85, 596-629), so parity is defined on the affine normalisation.
 #include <hip/hip_runtime.h>

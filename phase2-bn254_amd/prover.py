@@ -157,7 +157,7 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
             return fut.wait
 
         def call():
-            # its own stream: small multiexps (per-thread workspace in the library) overlap with the long ones instead of
+            # its own stream: small multiexps (the library leases them a workspace of their own) overlap with the long ones instead of
             # queueing behind them on one stream; inputs are complete (the caller synchronised), results come back on the host
             with torch.cuda.device(device), torch.cuda.stream(_thread_stream(device)):
                 return multiexp(pool, bases, density, exponents, scalars_montgomery=True)
