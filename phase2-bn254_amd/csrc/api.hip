@@ -45,6 +45,8 @@ int segsum_g2_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_p
 void msm_release_g1();
 void msm_release_g2();
 void msm_geometry(uint64_t n, uint32_t wgroups, uint32_t* c, uint32_t* W);
+int msm_selftest_digits(uint64_t n, uint32_t wgroups, const uint32_t scalar[8], uint32_t w_start, uint32_t w_stop, int direct, int32_t* digits,
+                        uint32_t* geom);
 
 // ------------------------------------------------------------------------------------------------
 // profiling hooks
@@ -1346,6 +1348,11 @@ int mi355zk_msm_window_bits_groups(size_t n_scalars, uint32_t window_groups, int
   msm_geometry(n_scalars, window_groups, &c, &W);
   if (n_windows) *n_windows = (int)W;
   return (int)c;
+}
+// (test hook) digit extraction of one scalar on the host: see msm_selftest_digits in msm_g1.hip
+int mi355zk_selftest_msm_digits(size_t n_scalars, uint32_t window_groups, const uint32_t scalar[8], uint32_t w_start, uint32_t w_stop, int direct,
+                                int32_t* digits, uint32_t* geom) {
+  return msm_selftest_digits(n_scalars, window_groups, scalar, w_start, w_stop, direct, digits, geom);
 }
 
 int mi355zk_bn254_fr_ntt(uint64_t* a, uint32_t log_n, const uint64_t omega[4]) {

@@ -40,6 +40,30 @@ int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_p
   return segsum_device<Fq>((const G1Affine*)d_points, nnz, d_row_ptr, n_rows, st, (G1Affine*)d_out);
 }
 
+// host self-test hook for the digit extraction (tests/test_msm_digits_host.py): the signed digits of one scalar for the geometry
+// chosen for (n, wgroups), windows [w_start, w_stop) -- direct != 0: the way a window-group rank computes them (chain started one
+// window below w_start, fallback on the sign boundary), direct == 0: the plain chain from window 0.  digits[w] = signed digit
+// (0 = no bucket) for the windows produced, INT32_MIN elsewhere; geom = {c, W, nb, rmul, rshift, width[0..W), shift[0..W)}.
+int msm_selftest_digits(uint64_t n, uint32_t wgroups, const uint32_t scalar[8], uint32_t w_start, uint32_t w_stop, int direct, int32_t* digits,
+                        uint32_t* geom) {
+  const MsmGeom G = choose_geom(n, 1, wgroups ? wgroups : 1);
+  if (G.W == 0) return ZK_ERR_BAD_ARGS;
+  if (geom) {
+    geom[0] = G.c; geom[1] = G.W; geom[2] = G.nb; geom[3] = G.rmul; geom[4] = G.rshift;
+    for (uint32_t w = 0; w < G.W; ++w) { geom[5 + w] = G.width[w]; geom[5 + G.W + w] = G.shift[w]; }
+  }
+  if (!digits || !scalar) return ZK_OK;
+  if (w_stop > G.W) w_stop = G.W;
+  uint32_t s[9];
+  for (int l = 0; l < 8; ++l) s[l] = scalar[l];
+  s[8] = 0;
+  for (uint32_t w = 0; w < G.W; ++w) digits[w] = INT32_MIN;
+  auto emit = [&](uint32_t w, uint32_t d, uint32_t neg) { digits[w] = neg ? -(int32_t)d : (int32_t)d; };
+  if (direct) msm_scalar_digits(s, G, w_start, w_stop, emit);
+  else (void)msm_scalar_digits_from(s, G, 0, w_stop, [&](uint32_t w, uint32_t d, uint32_t neg) { if (w >= w_start) emit(w, d, neg); });
+  return ZK_OK;
+}
+
 void msm_release_g1() { ws_release_all(); }
 
 }  // namespace zk

@@ -102,7 +102,7 @@ __device__ __forceinline__ T load_vec(const T* p) {
 // uniform over the launch (it follows from the window number), so the skipped word steps are skipped by scalar branches: the
 // dividend loses ~42 bits with every pair of digits taken off, and the multiword work is what the digit extraction costs.
 template <uint32_t M>
-__device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8], int top) {
+__host__ __device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8], int top) {
   uint32_t rem = 0;
 #pragma unroll
   for (int l = 7; l >= 0; --l) {
@@ -117,7 +117,7 @@ __device__ __forceinline__ uint32_t msm_divmod_small(uint32_t q[8], int top) {
 // two mixed-radix digits at once: (r0 + B r1) = q mod B^2, q = q div B^2, B = M * 2^sh (sh <= 22).  One multiword division by
 // M^2 instead of two by M.
 template <uint32_t M>
-__device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint32_t& r0, uint32_t& r1, int top) {
+__host__ __device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint32_t& r0, uint32_t& r1, int top) {
   const uint64_t low = (((uint64_t)q[1] << 32) | q[0]) & ((1ull << (2 * sh)) - 1ull);
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
@@ -132,24 +132,64 @@ __device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t sh, uint3
   r0 = (uint32_t)(pv - hi * ((uint64_t)M << sh));
 }
 
-// Digits of one scalar (canonical limbs s[0..7], s[8] = 0): emit(w, d, neg) for every window w of the geometry, d = |digit|
-// (0 = no bucket), neg = SIGN_BIT for a negative digit.  The carry chain of the signed digits runs from window 0.
-// Only the windows below w_stop are produced (a multi-GPU rank that owns a group of windows needs the carry chain / the
-// division chain from window 0 up to its last window, not beyond).
+// q = q div M^k (M a small odd constant, k uniform over the launch), in steps of M^8 / M^4 / M^2 / M (15^8 < 2^32); nbits: q < 2^nbits.
+template <uint32_t M>
+__host__ __device__ __forceinline__ void msm_div_pow(uint32_t q[8], uint32_t k, int& nbits, int flog_m) {
+  constexpr uint32_t M2 = M * M, M4 = M2 * M2, M8 = M4 * M4;
+  auto top = [&] { return nbits > 0 ? (nbits - 1) >> 5 : 0; };
+  while (k >= 8) { (void)msm_divmod_small<M8>(q, top()); k -= 8; nbits -= 8 * flog_m; }
+  if (k >= 4) { (void)msm_divmod_small<M4>(q, top()); k -= 4; nbits -= 4 * flog_m; }
+  if (k >= 2) { (void)msm_divmod_small<M2>(q, top()); k -= 2; nbits -= 2 * flog_m; }
+  if (k >= 1) { (void)msm_divmod_small<M>(q, top()); nbits -= flog_m; }
+}
+
+// Digits of one scalar (canonical limbs s[0..7], s[8] = 0) from window w_first on: emit(w, d, neg) for w_first <= w < w_stop,
+// d = |digit| (0 = no bucket), neg = SIGN_BIT for a negative digit.  The carry chain of the signed digits starts at w_first
+// with carry 0: exact for w_first == 0; for w_first > 0 the carry OUT of window w_first is exact unless that window's raw digit
+// sits on the boundary (then it depends on the carry in, which was not computed): the function returns false BEFORE emitting
+// anything, and the caller starts again from window 0.  (The digit of window w_first itself may be off by the missing carry:
+// callers that start above 0 do not use it.)
 template <class Emit>
-__device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& G, uint32_t w_stop, Emit emit) {
+__host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s[9], const MsmGeom& G, uint32_t w_first, uint32_t w_stop, Emit emit) {
   uint32_t carry = 0;
   if (G.rmul != 1) {
     // mixed radix: repeatedly  low = q mod 2^rshift;  q >>= rshift;  (q, r) = divmod(q, rmul);  digit = low + 2^rshift * r
     uint32_t q[8];
-#pragma unroll
-    for (int l = 0; l < 8; ++l) q[l] = s[l];
     const uint32_t sh = G.rshift, B = G.rmul << sh;
     const int flog_m = G.rmul >= 8 ? 3 : G.rmul >= 4 ? 2 : 1;  // floor(log2 rmul): a digit takes at least sh + flog_m bits off q
     int nbits = 254;                                           // q < 2^nbits (exponents are < r < 2^254)
+    if (w_first == 0) {
+#pragma unroll
+      for (int l = 0; l < 8; ++l) q[l] = s[l];
+    } else {
+      // q = s div B^w_first = (s >> (sh * w_first)) div rmul^w_first: one multiword shift and one or two multiword divisions
+      // instead of w_first digit steps (uniform over the launch: scalar branches, static register indices)
+      const uint32_t bits = sh * w_first, ls = bits >> 5, bs = bits & 31;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (ls == (uint32_t)c) {
+            lo = l + c < 8 ? s[l + c < 8 ? l + c : 0] : 0u;
+            hi = l + c + 1 < 8 ? s[l + c + 1 < 8 ? l + c + 1 : 0] : 0u;
+          }
+        q[l] = bs ? (lo >> bs) | (hi << (32 - bs)) : lo;
+      }
+      nbits -= (int)bits;
+      switch (G.rmul) {
+        case 3: msm_div_pow<3>(q, w_first, nbits, flog_m); break;
+        case 5: msm_div_pow<5>(q, w_first, nbits, flog_m); break;
+        case 7: msm_div_pow<7>(q, w_first, nbits, flog_m); break;
+        case 9: msm_div_pow<9>(q, w_first, nbits, flog_m); break;
+        case 11: msm_div_pow<11>(q, w_first, nbits, flog_m); break;
+        case 13: msm_div_pow<13>(q, w_first, nbits, flog_m); break;
+        default: msm_div_pow<15>(q, w_first, nbits, flog_m); break;
+      }
+    }
     uint32_t pending = 0;
     bool have_pending = false;
-    for (uint32_t w = 0; w < w_stop; ++w) {
+    for (uint32_t w = w_first; w < w_stop; ++w) {
       const int top = nbits > 0 ? (nbits - 1) >> 5 : 0;
       uint32_t d, neg = 0;
       if (w + 1 < G.W) {
@@ -186,6 +226,7 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
           }
           raw = low + (rem << sh);
         }
+        if (w == w_first && w_first != 0 && raw == G.nb) return false;  // carry out = carry in: not known here
         d = raw + carry;
         carry = 0;
         if (d > G.nb) {          // d in (B/2, B]  ->  d - B in (-B/2, 0]
@@ -198,9 +239,9 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
       }
       emit(w, d, neg);
     }
-    return;
+    return true;
   }
-  for (uint32_t w = 0; w < w_stop; ++w) {
+  for (uint32_t w = w_first; w < w_stop; ++w) {
     const uint32_t width = G.width[w], bit = G.shift[w];
     const uint32_t limb = bit >> 5, off = bit & 31;
     // (static indices under a uniform condition: a dynamic s[limb] would move the whole array, in every path of the
@@ -210,7 +251,9 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
     for (int l = 0; l < 8; ++l)
       if (limb == (uint32_t)l) { lo = s[l]; hi = s[l + 1]; }
     const uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
-    uint32_t d = ((uint32_t)(two >> off) & ((1u << width) - 1u)) + carry;
+    const uint32_t raw = (uint32_t)(two >> off) & ((1u << width) - 1u);
+    if (w == w_first && w_first != 0 && w + 1 < G.W && raw == (1u << (width - 1))) return false;  // carry out = carry in
+    uint32_t d = raw + carry;
     uint32_t neg = 0;
     carry = 0;
     if (w + 1 < G.W && d > (1u << (width - 1))) {  // d in (2^(width-1), 2^width]  ->  d - 2^width in (-2^(width-1), 0]
@@ -220,6 +263,20 @@ __device__ __forceinline__ void msm_scalar_digits(uint32_t s[9], const MsmGeom& 
     }
     emit(w, d, neg);
   }
+  return true;
+}
+
+// The digits of windows w_start <= w < w_stop (a multi-GPU rank that owns a group of windows; the whole range on one GPU): the
+// chain starts ONE window below w_start -- the carry into w_start is all the lower windows contribute -- and only the rare
+// scalar whose digit there sits exactly on the sign boundary (one in B) walks the chain from window 0.
+template <class Emit>
+__host__ __device__ __forceinline__ void msm_scalar_digits(const uint32_t s[9], const MsmGeom& G, uint32_t w_start, uint32_t w_stop, Emit emit) {
+  const uint32_t w_first = w_start >= 2 ? w_start - 1 : 0;
+  auto windowed = [&](uint32_t w, uint32_t d, uint32_t neg) {
+    if (w >= w_start) emit(w, d, neg);
+  };
+  if (w_first != 0 && msm_scalar_digits_from(s, G, w_first, w_stop, windowed)) return;
+  (void)msm_scalar_digits_from(s, G, 0, w_stop, windowed);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -370,7 +427,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
       }
       // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is
       // loaded anyway, in accumulate_run)
-      msm_scalar_digits(s, G, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
+      msm_scalar_digits(s, G, w_lo, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
         if (w >= w_lo && w < w_hi) {
           const uint32_t wl = w - w_lo;
           keys[(uint64_t)wl * kstride + i] = d ? ((d - 1) | neg) : G.nb;
@@ -423,7 +480,7 @@ __global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* _
     for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * kstride + i] = G.nb;
     return;
   }
-  msm_scalar_digits(s, G, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
+  msm_scalar_digits(s, G, w_lo, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
     if (w >= w_lo && w < w_hi) keys[(uint64_t)(w - w_lo) * kstride + i] = d ? ((d - 1) | neg) : G.nb;
   });
 }

@@ -39,11 +39,15 @@ full = timed(lambda: zk.multiexp(w, (b, 0), zk.FullDensity(), s).wait())
 out = {"log_n": a.log_n, "one_gpu_ms": round(full, 2)}
 for world in (2, 4, 8):
     pg, wg = zk.shard.plan(world); nl = n // pg
-    cell_fn = lambda: zk.multiexp(w, (b[:nl], 0), zk.FullDensity(), s[:nl], window_group=(wg, wg - 1)).wait()  # the top group walks every window
-    cell = timed(cell_fn)
+    # every window group is timed; the slowest one is the rank the others wait for (the groups differ in their digit chains and in
+    # the top window's short digits)
+    cells = {g: timed(lambda g=g: zk.multiexp(w, (b[:nl], 0), zk.FullDensity(), s[:nl], window_group=(wg, g)).wait()) for g in range(wg)}
+    slow = max(cells, key=cells.get)
+    cell_fn = lambda: zk.multiexp(w, (b[:nl], 0), zk.FullDensity(), s[:nl], window_group=(wg, slow)).wait()
+    cell = cells[slow]
     pts = timed(lambda: zk.multiexp(w, (b[:n // world], 0), zk.FullDensity(), s[:n // world]).wait())
     nw = C.c_int(); c = L.mi355zk_msm_window_bits_groups(nl, wg, C.byref(nw))
-    out[f"n{world}"] = {"plan": f"{pg} point range(s) x {wg} window group(s)", "windows": nw.value, "field_bits": c, "cell_ms": round(cell, 2),
+    out[f"n{world}"] = {"plan": f"{pg} point range(s) x {wg} window group(s)", "windows": nw.value, "field_bits": c, "cell_ms": round(cell, 2), "cell_ms_by_group": [round(cells[g], 2) for g in range(wg)],
                         "speedup": round(full / cell, 2), "efficiency": round(full / cell / world, 3), "cell_kernel_ms": kernels(cell_fn),
                         "point_ranges_only_ms": round(pts, 2), "point_ranges_only_efficiency": round(full / pts / world, 3)}
 print(json.dumps(out))
