@@ -59,8 +59,9 @@ int msm_selftest_digits(uint64_t n, uint32_t wgroups, const uint32_t scalar[8], 
   s[8] = 0;
   for (uint32_t w = 0; w < G.W; ++w) digits[w] = INT32_MIN;
   auto emit = [&](uint32_t w, uint32_t d, uint32_t neg) { digits[w] = neg ? -(int32_t)d : (int32_t)d; };
-  if (direct) msm_scalar_digits(s, G, w_start, w_stop, emit);
-  else (void)msm_scalar_digits_from(s, G, 0, w_stop, [&](uint32_t w, uint32_t d, uint32_t neg) { if (w >= w_start) emit(w, d, neg); });
+  auto from0 = [&](uint32_t w, uint32_t d, uint32_t neg) { if (w >= w_start) emit(w, d, neg); };
+  if (direct) { ZK_DISPATCH_RMUL(G.rmul, msm_scalar_digits<RM>(s, G, w_start, w_stop, emit)); }
+  else { ZK_DISPATCH_RMUL(G.rmul, (void)msm_scalar_digits_from<RM>(s, G, 0, w_stop, from0)); }
   return ZK_OK;
 }
 

@@ -132,15 +132,21 @@ __host__ __device__ __forceinline__ void msm_two_digits(uint32_t q[8], uint32_t 
   r0 = (uint32_t)(pv - hi * ((uint64_t)M << sh));
 }
 
-// q = q div M^k (M a small odd constant, k uniform over the launch), in steps of M^8 / M^4 / M^2 / M (15^8 < 2^32); nbits: q < 2^nbits.
+// q = q div M^k (M a small odd constant, k uniform over the launch), in steps of M^4 and M (two instantiations per multiplier: the
+// digit kernels carry seven multipliers and must stay inside the instruction cache); nbits: q < 2^nbits.
 template <uint32_t M>
 __host__ __device__ __forceinline__ void msm_div_pow(uint32_t q[8], uint32_t k, int& nbits, int flog_m) {
-  constexpr uint32_t M2 = M * M, M4 = M2 * M2, M8 = M4 * M4;
-  auto top = [&] { return nbits > 0 ? (nbits - 1) >> 5 : 0; };
-  while (k >= 8) { (void)msm_divmod_small<M8>(q, top()); k -= 8; nbits -= 8 * flog_m; }
-  if (k >= 4) { (void)msm_divmod_small<M4>(q, top()); k -= 4; nbits -= 4 * flog_m; }
-  if (k >= 2) { (void)msm_divmod_small<M2>(q, top()); k -= 2; nbits -= 2 * flog_m; }
-  if (k >= 1) { (void)msm_divmod_small<M>(q, top()); nbits -= flog_m; }
+  constexpr uint32_t M4 = M * M * M * M;
+#pragma unroll 1
+  for (; k >= 4; k -= 4) {
+    (void)msm_divmod_small<M4>(q, nbits > 0 ? (nbits - 1) >> 5 : 0);
+    nbits -= 4 * flog_m;
+  }
+#pragma unroll 1
+  for (; k >= 1; k -= 1) {
+    (void)msm_divmod_small<M>(q, nbits > 0 ? (nbits - 1) >> 5 : 0);
+    nbits -= flog_m;
+  }
 }
 
 // Digits of one scalar (canonical limbs s[0..7], s[8] = 0) from window w_first on: emit(w, d, neg) for w_first <= w < w_stop,
@@ -149,14 +155,16 @@ __host__ __device__ __forceinline__ void msm_div_pow(uint32_t q[8], uint32_t k, 
 // sits on the boundary (then it depends on the carry in, which was not computed): the function returns false BEFORE emitting
 // anything, and the caller starts again from window 0.  (The digit of window w_first itself may be off by the missing carry:
 // callers that start above 0 do not use it.)
-template <class Emit>
+// RM: the geometry's multiplier G.rmul as a compile-time constant (1 = power-of-two windows): every digit kernel is instantiated
+// per multiplier, so that it carries ONE set of constant divisions instead of seven behind a switch (instruction cache).
+template <uint32_t RM, class Emit>
 __host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s[9], const MsmGeom& G, uint32_t w_first, uint32_t w_stop, Emit emit) {
   uint32_t carry = 0;
-  if (G.rmul != 1) {
+  if constexpr (RM != 1) {
     // mixed radix: repeatedly  low = q mod 2^rshift;  q >>= rshift;  (q, r) = divmod(q, rmul);  digit = low + 2^rshift * r
     uint32_t q[8];
-    const uint32_t sh = G.rshift, B = G.rmul << sh;
-    const int flog_m = G.rmul >= 8 ? 3 : G.rmul >= 4 ? 2 : 1;  // floor(log2 rmul): a digit takes at least sh + flog_m bits off q
+    const uint32_t sh = G.rshift, B = RM << sh;
+    constexpr int flog_m = RM >= 8 ? 3 : RM >= 4 ? 2 : 1;  // floor(log2 rmul): a digit takes at least sh + flog_m bits off q
     int nbits = 254;                                           // q < 2^nbits (exponents are < r < 2^254)
     if (w_first == 0) {
 #pragma unroll
@@ -177,15 +185,7 @@ __host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s
         q[l] = bs ? (lo >> bs) | (hi << (32 - bs)) : lo;
       }
       nbits -= (int)bits;
-      switch (G.rmul) {
-        case 3: msm_div_pow<3>(q, w_first, nbits, flog_m); break;
-        case 5: msm_div_pow<5>(q, w_first, nbits, flog_m); break;
-        case 7: msm_div_pow<7>(q, w_first, nbits, flog_m); break;
-        case 9: msm_div_pow<9>(q, w_first, nbits, flog_m); break;
-        case 11: msm_div_pow<11>(q, w_first, nbits, flog_m); break;
-        case 13: msm_div_pow<13>(q, w_first, nbits, flog_m); break;
-        default: msm_div_pow<15>(q, w_first, nbits, flog_m); break;
-      }
+      msm_div_pow<RM>(q, w_first, nbits, flog_m);
     }
     uint32_t pending = 0;
     bool have_pending = false;
@@ -198,15 +198,7 @@ __host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s
           raw = pending;
           have_pending = false;
         } else if (w + 2 < G.W) {  // this window and the next one, neither of them the top window
-          switch (G.rmul) {  // division by compile-time constants (multiply-high), not by runtime values
-            case 3: msm_two_digits<3>(q, sh, raw, pending, top); break;
-            case 5: msm_two_digits<5>(q, sh, raw, pending, top); break;
-            case 7: msm_two_digits<7>(q, sh, raw, pending, top); break;
-            case 9: msm_two_digits<9>(q, sh, raw, pending, top); break;
-            case 11: msm_two_digits<11>(q, sh, raw, pending, top); break;
-            case 13: msm_two_digits<13>(q, sh, raw, pending, top); break;
-            default: msm_two_digits<15>(q, sh, raw, pending, top); break;
-          }
+          msm_two_digits<RM>(q, sh, raw, pending, top);  // division by compile-time constants (multiply-high)
           have_pending = true;
           nbits -= 2 * (int)(sh + flog_m);
         } else {
@@ -214,16 +206,7 @@ __host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s
 #pragma unroll
           for (int l = 0; l < 8; ++l) q[l] = (q[l] >> sh) | (l < 7 ? q[l + 1] << (32 - sh) : 0u);
           nbits -= (int)(sh + flog_m);
-          uint32_t rem = 0;
-          switch (G.rmul) {
-            case 3: rem = msm_divmod_small<3>(q, top); break;
-            case 5: rem = msm_divmod_small<5>(q, top); break;
-            case 7: rem = msm_divmod_small<7>(q, top); break;
-            case 9: rem = msm_divmod_small<9>(q, top); break;
-            case 11: rem = msm_divmod_small<11>(q, top); break;
-            case 13: rem = msm_divmod_small<13>(q, top); break;
-            default: rem = msm_divmod_small<15>(q, top); break;
-          }
+          const uint32_t rem = msm_divmod_small<RM>(q, top);
           raw = low + (rem << sh);
         }
         if (w == w_first && w_first != 0 && raw == G.nb) return false;  // carry out = carry in: not known here
@@ -240,7 +223,7 @@ __host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s
       emit(w, d, neg);
     }
     return true;
-  }
+  } else {
   for (uint32_t w = w_first; w < w_stop; ++w) {
     const uint32_t width = G.width[w], bit = G.shift[w];
     const uint32_t limb = bit >> 5, off = bit & 31;
@@ -264,20 +247,43 @@ __host__ __device__ __forceinline__ bool msm_scalar_digits_from(const uint32_t s
     emit(w, d, neg);
   }
   return true;
+  }
 }
 
 // The digits of windows w_start <= w < w_stop (a multi-GPU rank that owns a group of windows; the whole range on one GPU): the
 // chain starts ONE window below w_start -- the carry into w_start is all the lower windows contribute -- and only the rare
 // scalar whose digit there sits exactly on the sign boundary (one in B) walks the chain from window 0.
-template <class Emit>
+template <uint32_t RM, class Emit>
 __host__ __device__ __forceinline__ void msm_scalar_digits(const uint32_t s[9], const MsmGeom& G, uint32_t w_start, uint32_t w_stop, Emit emit) {
+  if (w_start == 0) {  // the whole range (one GPU): its own copy of the chain, specialised for a start at window 0
+    (void)msm_scalar_digits_from<RM>(s, G, 0, w_stop, emit);
+    return;
+  }
   const uint32_t w_first = w_start >= 2 ? w_start - 1 : 0;
   auto windowed = [&](uint32_t w, uint32_t d, uint32_t neg) {
     if (w >= w_start) emit(w, d, neg);
   };
-  if (w_first != 0 && msm_scalar_digits_from(s, G, w_first, w_stop, windowed)) return;
-  (void)msm_scalar_digits_from(s, G, 0, w_stop, windowed);
+  // (one inlined copy of the chain for every start above 0: the second trip only runs for the boundary scalars)
+  uint32_t from = w_first;
+#pragma unroll 1
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (msm_scalar_digits_from<RM>(s, G, from, w_stop, windowed)) return;
+    from = 0;
+  }
 }
+
+// run `stmt` with RM bound to G.rmul as a compile-time constant
+#define ZK_DISPATCH_RMUL(rmul, stmt)                      \
+  switch (rmul) {                                          \
+    case 1: { constexpr uint32_t RM = 1; stmt; } break;    \
+    case 3: { constexpr uint32_t RM = 3; stmt; } break;    \
+    case 5: { constexpr uint32_t RM = 5; stmt; } break;    \
+    case 7: { constexpr uint32_t RM = 7; stmt; } break;    \
+    case 9: { constexpr uint32_t RM = 9; stmt; } break;    \
+    case 11: { constexpr uint32_t RM = 11; stmt; } break;  \
+    case 13: { constexpr uint32_t RM = 13; stmt; } break;  \
+    default: { constexpr uint32_t RM = 15; stmt; } break;  \
+  }
 
 // ------------------------------------------------------------------------------------------------
 // 2. PARTITION: the (window, bucket) grouping of the n * WL digits, hand-written (no library sort on the path).
@@ -370,6 +376,7 @@ __device__ __forceinline__ uint32_t block_scan_long(uint32_t len, uint32_t* scra
 // pass A.  density == nullptr: FullDensity (source.rs:80-99).  Otherwise bit i of `density` selects exponent i
 // (source.rs:101-118).  scalars_mont != 0: the exponents are Fr elements in Montgomery form (what the prover holds before
 // scalars_into_representations, prover.rs:89-129): the conversion into_repr() is one Montgomery reduction, fused here.
+template <uint32_t RM>
 __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uint32_t* __restrict__ scalars, uint64_t n,
                                                                        const uint32_t* __restrict__ density, MsmGeom G, uint32_t w_lo,
                                                                        uint32_t w_hi, int scalars_mont, PartGeom P, uint64_t kstride,
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
       }
       // (a selected base with a non-zero exponent must not be the identity, source.rs:50-52: checked where the base is
       // loaded anyway, in accumulate_run)
-      msm_scalar_digits(s, G, w_lo, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
+      msm_scalar_digits<RM>(s, G, w_lo, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
         if (w >= w_lo && w < w_hi) {
           const uint32_t wl = w - w_lo;
           keys[(uint64_t)wl * kstride + i] = d ? ((d - 1) | neg) : G.nb;
@@ -451,6 +458,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
 // window) the histogram pass reads again, but its 1024-lane workgroups with a 61 KiB LDS histogram stream the scalars at under
 // half the rate of the plain kernel (2.75 ms against 1.1 + 0.7 ms at 2^26), and a multi-GPU rank that owns a few windows pays
 // the slow scalar stream in full.
+template <uint32_t RM>
 __global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* __restrict__ scalars, uint64_t n, const uint32_t* __restrict__ density,
                                                               MsmGeom G, uint32_t w_lo, uint32_t w_hi, int scalars_mont, uint64_t kstride,
                                                               uint32_t* __restrict__ keys, unsigned long long* __restrict__ err_scalar) {
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* _
     for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * kstride + i] = G.nb;
     return;
   }
-  msm_scalar_digits(s, G, w_lo, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
+  msm_scalar_digits<RM>(s, G, w_lo, w_hi < G.W ? w_hi : G.W, [&](uint32_t w, uint32_t d, uint32_t neg) {
     if (w >= w_lo && w < w_hi) keys[(uint64_t)(w - w_lo) * kstride + i] = d ? ((d - 1) | neg) : G.nb;
   });
 }
@@ -1492,8 +1500,9 @@ int part_configure(int dev) {
   auto it = g_part_cfg.find(dev);
   if (it != g_part_cfg.end()) return it->second;
   int rc = ZK_OK;
-  const void* fns[4] = {reinterpret_cast<const void*>(msm_digits_hist_kernel), reinterpret_cast<const void*>(msm_scatter_kernel),
-                        reinterpret_cast<const void*>(msm_bucket_kernel), reinterpret_cast<const void*>(msm_bigbin_place_kernel)};
+  std::vector<const void*> fns = {reinterpret_cast<const void*>(msm_scatter_kernel), reinterpret_cast<const void*>(msm_bucket_kernel),
+                                  reinterpret_cast<const void*>(msm_bigbin_place_kernel)};
+  for (uint32_t rmul : {1u, 3u, 5u, 7u, 9u, 11u, 13u, 15u}) ZK_DISPATCH_RMUL(rmul, fns.push_back(reinterpret_cast<const void*>(msm_digits_hist_kernel<RM>)));
   for (const void* fn : fns) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -1664,16 +1673,16 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   prof_begin(slot_digits, st);
   static const bool fused_a = std::getenv("MI355ZK_PART_FUSED_A") != nullptr;  // (the one-kernel pass A, kept for the comparison in DESIGN.md)
   if (!fused_a) {
-    hipLaunchKernelGGL(msm_digits_plain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, d_density, G, w_lo, w_hi,
-                       scalars_mont ? 1 : 0, kstride, keys, d_err + 1);
+    ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_plain_kernel<RM>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, d_density, G,
+                                                w_lo, w_hi, scalars_mont ? 1 : 0, kstride, keys, d_err + 1));
     hipLaunchKernelGGL(msm_tile_hist_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)P.nbin * 4, st, keys, n, kstride, G.nb, WL, P, tile_hist);
   } else {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t per_cu = (size_t)((ncell + 1) / 2) * 4 <= PART_LDS_A ? 2u : 1u;     // 1024-lane workgroups per CU (LDS histograms)
     const uint32_t grid = P.n_st < per_cu * (uint32_t)cus ? P.n_st : per_cu * (uint32_t)cus;
-    hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_scalars, n, d_density, G, w_lo,
-                       w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist, d_err + 1);
+    ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_hist_kernel<RM>, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_scalars, n,
+                                                d_density, G, w_lo, w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist, d_err + 1));
   }
   ZK_HIP(hipGetLastError());
   prof_end(slot_digits, st);
