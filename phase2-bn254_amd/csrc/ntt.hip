@@ -111,14 +111,15 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 __device__ __forceinline__ uint32_t swz(uint32_t x) { return x ^ ((x >> 5) & 31u); }
 
 // One pass over one tile.  roots[x] = w_p^x for x < N_p/2 (w_p = omega^(N/N_p)).
+template <uint32_t LOG_NP>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, NttPassParams P,
                                                               const UTab* __restrict__ roots, const UTab* __restrict__ twA,
                                                               const UTab* __restrict__ twB, const UTab* __restrict__ preA,
                                                               const UTab* __restrict__ preB, const UTab* __restrict__ postA,
                                                               const UTab* __restrict__ postB, FrU post_c) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const uint32_t np = 1u << P.log_np;
-  const uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
+  constexpr uint32_t np = 1u << LOG_NP;
+  constexpr uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
   const uint32_t plane = P.g * pitch;
   const uint32_t elems = P.g * np;
   const uint64_t tile = blockIdx.x;
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   // load (bit-reversed placement inside each row: the DIT stages below then finish in natural order)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
     uint32_t x, g;
-    if (P.load_x_fastest) { x = e & (np - 1); g = e >> P.log_np; }
+    if (P.load_x_fastest) { x = e & (np - 1); g = e >> LOG_NP; }
     else { g = e % P.g; x = e / P.g; }
     const uint64_t gi = in_base + x * P.in_xs + g * P.in_gs;
     FrU v = u_from_std(gload(in + gi));                                   // < p, N
@@ -137,29 +138,32 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       FrU w = u_mul(tab_load(preA + (gi >> P.pre_h)), tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));  // g^i, < 2p
       v = u_mul(v, w);                                                    // < 2p, N
     }
-    lds_store(lds, plane, g * pitch + swz(bitrev(x, P.log_np)), v);
+    lds_store(lds, plane, g * pitch + swz(bitrev(x, LOG_NP)), v);
   }
   __syncthreads();
 
   // DIT stages.  Entering stage s every element has limbs < ((s & 3) + 1) * 2^29 and is < (4 + 2s) p, or < 16p + 2(s - 3)p when
   // the twiddle-one products of stages 1 and 2 are skipped (see j_slow).
   const uint32_t half = elems >> 1;
-  for (uint32_t s = 0; s < P.log_np; ++s) {
-    const uint32_t m = 1u << s;
-    const bool carry_now = (s & 3) == 3;
+  // (LOG_NP is a template parameter and the stage loop a static one: the stage number, the skip / carry decisions and the shift
+  // amounts of the index arithmetic are compile-time constants in every stage)
+  for_limbs<(int)LOG_NP>([&](auto sc) {
+    constexpr uint32_t s = (uint32_t) decltype(sc)::value;
+    constexpr uint32_t m = 1u << s;
+    constexpr bool carry_now = (s & 3) == 3;
     // Stages 1 and 2 (when a row has at least 64 blocks of 2m): the butterflies of a row are dealt to the lanes with the
     // twiddle index j SLOWEST (lane = j * blocks + block), so j is uniform over a wave and the waves with j == 0 -- twiddle
     // one: 1/2 and 1/4 of the butterflies of these stages -- skip the product.  Later stages: j fastest (unit-stride LDS).
     // Bounds: a skipped product leaves t as large as u, so values DOUBLE on that path: V_1 < 4p, V_2 < 8p, V_3 < 16p, and
     // with + 2p for each of the stages 3..9: < 30p at the end (u_to_std_lt32p / the closing product allow < 32p); the
     // subtraction constant follows (u_sub<4,1> / <8,1>).  Stage 3 is not skipped: it would take the bound past 32p.
-    const bool j_slow = (s == 1 || s == 2) && (np >> (s + 1)) >= 64;
+    constexpr bool j_slow = (s == 1 || s == 2) && (np >> (s + 1)) >= 64;
     for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
-      uint32_t g = b >> (P.log_np - 1);
+      uint32_t g = b >> (LOG_NP - 1);
       uint32_t bf = b & ((np >> 1) - 1);
       uint32_t j, x0;
       if (j_slow) {
-        const uint32_t blocks_log = P.log_np - 1 - s;                     // blocks of 2m per row
+        const uint32_t blocks_log = LOG_NP - 1 - s;                     // blocks of 2m per row
         j = bf >> blocks_log;
         x0 = ((bf & ((1u << blocks_log) - 1u)) << (s + 1)) + j;
       } else {
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       FrU u = lds_load(lds, plane, i0);
       FrU t = lds_load(lds, plane, i1);
       // (t < 24p with limbs < 4*2^29 either way: the skipped product only leaves t as large as u may be)
-      if (s != 0 && !(j_slow && j == 0)) t = u_mul(t, tab_load(roots + ((uint64_t)j << (P.log_np - 1 - s))));  // limbs < 4*2^29 times N: ok; < 2p, N
+      if (s != 0 && !(j_slow && j == 0)) t = u_mul(t, tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s))));  // limbs < 4*2^29 times N: ok; < 2p, N
       else t = u_carry(t);                                                // w = 1 (stage 0; j == 0): no product
       FrU sum = u_add(u, t);                                              // limbs grow by 2^29, value by 2p
       if (carry_now) sum = u_carry(sum);
@@ -182,7 +186,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       lds_store(lds, plane, i1, dif);
     }
     __syncthreads();
-  }
+  });
 
   // store: one more product brings the value below 2p (inter-pass twiddle, or the post scale / one on the last pass)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
@@ -334,10 +338,16 @@ int ntt_configure() {
   auto it = g_cfg.find(dev);
   if (it != g_cfg.end()) return it->second;
   int rc = ZK_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) {
-    std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(ntt_pass_kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
-    rc = ZK_ERR_DEVICE;
+  const void* fns[NTT_MAX_LOG_NP + 1] = {};
+#define ZK_NTT_FN(L) fns[L] = reinterpret_cast<const void*>(ntt_pass_kernel<L>);
+  ZK_NTT_FN(1) ZK_NTT_FN(2) ZK_NTT_FN(3) ZK_NTT_FN(4) ZK_NTT_FN(5) ZK_NTT_FN(6) ZK_NTT_FN(7) ZK_NTT_FN(8) ZK_NTT_FN(9) ZK_NTT_FN(10)
+#undef ZK_NTT_FN
+  for (int l = 1; l <= NTT_MAX_LOG_NP; ++l) {
+    hipError_t e = hipFuncSetAttribute(fns[l], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(ntt_pass_kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
+      rc = ZK_ERR_DEVICE;
+    }
   }
   g_cfg[dev] = rc;
   return rc;
@@ -484,8 +494,18 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     if (threads > NTT_THREADS) threads = NTT_THREADS;
     if (threads < 64) threads = 64;
     prof_begin(slot_pass, st);
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, T->B,
-                       Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr, post_cu);
+    // (one instantiation per row length: the stage loop is unrolled with compile-time stage numbers)
+#define ZK_NTT_LAUNCH(L)                                                                                                                   \
+  case L:                                                                                                                                  \
+    hipLaunchKernelGGL(ntt_pass_kernel<L>, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, T->B,   \
+                       Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr, post_cu); \
+    break;
+    switch (b[p]) {
+      ZK_NTT_LAUNCH(1) ZK_NTT_LAUNCH(2) ZK_NTT_LAUNCH(3) ZK_NTT_LAUNCH(4) ZK_NTT_LAUNCH(5) ZK_NTT_LAUNCH(6) ZK_NTT_LAUNCH(7) ZK_NTT_LAUNCH(8)
+      ZK_NTT_LAUNCH(9) ZK_NTT_LAUNCH(10)
+      default: return ZK_ERR_BAD_ARGS;
+    }
+#undef ZK_NTT_LAUNCH
     ZK_HIP(hipGetLastError());
     prof_end(slot_pass, st);
   }
