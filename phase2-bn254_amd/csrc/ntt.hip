@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 __device__ __forceinline__ uint32_t swz(uint32_t x) { return x ^ ((x >> 5) & 31u); }
 
 // One pass over one tile.  roots[x] = w_p^x for x < N_p/2 (w_p = omega^(N/N_p)).
-template <uint32_t LOG_NP>
+template <uint32_t LOG_NP, bool R4>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, NttPassParams P,
                                                               const UTab* __restrict__ roots, const UTab* __restrict__ twA,
                                                               const UTab* __restrict__ twB, const UTab* __restrict__ preA,
@@ -144,6 +144,91 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
 
   // DIT stages.  Entering stage s every element has limbs < ((s & 3) + 1) * 2^29 and is < (4 + 2s) p, or < 16p + 2(s - 3)p when
   // the twiddle-one products of stages 1 and 2 are skipped (see j_slow).
+  if constexpr (R4) {
+  // (LOG_NP is a template parameter and the stage loops are static: the stage number, the skip / carry decisions and the shift amounts
+  // of the index arithmetic are compile-time constants in every stage)
+  // One butterfly of stage ST on registers: (u, t) -> (u + w t, u - w t); skip: w = 1 (stage 0; twiddle index 0 of stages 1 and 2).
+  // Bounds with skipping: a skipped product leaves t as large as u, so values DOUBLE on that path: V_1 < 4p, V_2 < 8p, V_3 < 16p, and
+  // with + 2p for each of the stages 3..9: < 30p at the end (u_to_std_lt32p / the closing product allow < 32p); the subtraction
+  // constant follows (u_sub<4,1> / <8,1>).  Stage 3 is not skipped: it would take the bound past 32p.
+  auto bf = [&](auto stc, FrU& u, FrU& t, const FrU& w, bool skip) {
+    constexpr uint32_t ST = (uint32_t) decltype(stc)::value;
+    // (t < 24p with limbs < 4*2^29 either way: the skipped product only leaves t as large as u may be)
+    if (!skip) t = u_mul(t, w);                                            // limbs < 4*2^29 times N: ok; < 2p, N
+    else t = u_carry(t);
+    FrU sum = u_add(u, t);                                                 // limbs grow by 2^29, value by 2p
+    if constexpr ((ST & 3) == 3) sum = u_carry(sum);
+    FrU dif;                                                               // t N; u limbs < 4*2^29 < 2^32 - 2^30 - 16: ok.  N out
+    if constexpr (ST == 1) dif = skip ? u_sub<4, 1>(u, t) : u_sub<2, 1>(u, t);        // skipped: t < 4p
+    else if constexpr (ST == 2) dif = skip ? u_sub<8, 1>(u, t) : u_sub<2, 1>(u, t);   // skipped: t < 8p
+    else dif = u_sub<2, 1>(u, t);                                          // t < 2p
+    u = sum;
+    t = dif;
+  };
+  constexpr uint32_t S0 = LOG_NP & 1;  // an odd number of stages: stage 0 alone (all twiddles one), then pairs
+  if constexpr (S0 == 1) {
+    const uint32_t half = elems >> 1;
+    for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
+      const uint32_t g = b >> (LOG_NP - 1), x0 = (b & ((np >> 1) - 1)) << 1;
+      const uint32_t i0 = g * pitch + swz(x0), i1 = g * pitch + swz(x0 + 1);
+      FrU u = lds_load(lds, plane, i0), t = lds_load(lds, plane, i1);
+      bf(std::integral_constant<int, 0>{}, u, t, u, true);
+      lds_store(lds, plane, i0, u);
+      lds_store(lds, plane, i1, t);
+    }
+    __syncthreads();
+  }
+  // Two stages per LDS round trip: a lane holds the four elements x0 + {0, m, 2m, 3m} (m = 2^s), runs the two butterflies of stage s
+  // (same twiddle w^j) and the two of stage s + 1 (twiddle indices j and j + m) on registers.  For the pair that starts at stage 1
+  // or 2 the groups of a row are dealt to the lanes with the twiddle index j SLOWEST (lane = j * blocks + block), so j is uniform
+  // over a wave and the waves with j == 0 -- twiddle one -- skip those products; later pairs: j fastest (unit-stride LDS).
+  const uint32_t quarter = elems >> 2;
+  for_limbs<(int)(LOG_NP / 2)>([&](auto pc) {
+    constexpr uint32_t s = S0 + 2u * (uint32_t) decltype(pc)::value;
+    constexpr uint32_t m = 1u << s;
+    constexpr bool j_slow = (s == 1 || s == 2) && (np >> (s + 2)) >= 64;
+    for (uint32_t q = threadIdx.x; q < quarter; q += blockDim.x) {
+      const uint32_t g = q >> (LOG_NP - 2);
+      const uint32_t qf = q & ((np >> 2) - 1);
+      uint32_t j, x0;
+      if constexpr (j_slow) {
+        constexpr uint32_t blocks_log = LOG_NP - 2 - s;                    // blocks of 4m per row
+        j = qf >> blocks_log;
+        x0 = ((qf & ((1u << blocks_log) - 1u)) << (s + 2)) + j;
+      } else {
+        j = qf & (m - 1);
+        x0 = ((qf >> s) << (s + 2)) + j;
+      }
+      const uint32_t row = g * pitch;
+      const uint32_t ia = row + swz(x0), ib = row + swz(x0 + m), ic = row + swz(x0 + 2 * m), id = row + swz(x0 + 3 * m);
+      FrU a = lds_load(lds, plane, ia), b = lds_load(lds, plane, ib), c = lds_load(lds, plane, ic), d = lds_load(lds, plane, id);
+      const bool one = s <= 2 && j == 0;                                   // stage s (s == 0: j == 0 always)
+      {
+        FrU w1 = a;
+        if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));
+        bf(std::integral_constant<int, (int)s>{}, a, b, w1, one);
+        bf(std::integral_constant<int, (int)s>{}, c, d, w1, one);
+      }
+      const bool one2 = s + 1 <= 2 && j == 0;                              // stage s + 1, pair (a, c): index j
+      {
+        FrU w2 = a;
+        if (!one2) w2 = tab_load(roots + ((uint64_t)j << (LOG_NP - 2 - s)));
+        bf(std::integral_constant<int, (int)s + 1>{}, a, c, w2, one2);
+      }
+      {
+        const FrU w3 = tab_load(roots + ((uint64_t)(j + m) << (LOG_NP - 2 - s)));   // pair (b, d): index j + m, never zero
+        bf(std::integral_constant<int, (int)s + 1>{}, b, d, w3, false);
+      }
+      lds_store(lds, plane, ia, a);
+      lds_store(lds, plane, ib, b);
+      lds_store(lds, plane, ic, c);
+      lds_store(lds, plane, id, d);
+    }
+    __syncthreads();
+  });
+  } else {
+  // radix-2 stages (short transforms run narrow tiles, at least 256 of them: a pass is latency-bound there, and two independent
+  // butterflies per lane and stage beat one group of four on half the lanes: 2^16 0.048 ms against 0.053)
   const uint32_t half = elems >> 1;
   // (LOG_NP is a template parameter and the stage loop a static one: the stage number, the skip / carry decisions and the shift
   // amounts of the index arithmetic are compile-time constants in every stage)
@@ -187,6 +272,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     }
     __syncthreads();
   });
+  }
 
   // store: one more product brings the value below 2p (inter-pass twiddle, or the post scale / one on the last pass)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
@@ -338,11 +424,11 @@ int ntt_configure() {
   auto it = g_cfg.find(dev);
   if (it != g_cfg.end()) return it->second;
   int rc = ZK_OK;
-  const void* fns[NTT_MAX_LOG_NP + 1] = {};
-#define ZK_NTT_FN(L) fns[L] = reinterpret_cast<const void*>(ntt_pass_kernel<L>);
+  const void* fns[2 * NTT_MAX_LOG_NP + 2] = {};
+#define ZK_NTT_FN(L) fns[L] = reinterpret_cast<const void*>(ntt_pass_kernel<L, false>); fns[NTT_MAX_LOG_NP + L] = reinterpret_cast<const void*>(ntt_pass_kernel<L, true>);
   ZK_NTT_FN(1) ZK_NTT_FN(2) ZK_NTT_FN(3) ZK_NTT_FN(4) ZK_NTT_FN(5) ZK_NTT_FN(6) ZK_NTT_FN(7) ZK_NTT_FN(8) ZK_NTT_FN(9) ZK_NTT_FN(10)
 #undef ZK_NTT_FN
-  for (int l = 1; l <= NTT_MAX_LOG_NP; ++l) {
+  for (int l = 1; l <= 2 * NTT_MAX_LOG_NP; ++l) {
     hipError_t e = hipFuncSetAttribute(fns[l], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       std::fprintf(stderr, "[mi355zk] hipFuncSetAttribute(ntt_pass_kernel, 160 KiB LDS) failed: %s\n", hipGetErrorString(e));
@@ -494,11 +580,21 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     if (threads > NTT_THREADS) threads = NTT_THREADS;
     if (threads < 64) threads = 64;
     prof_begin(slot_pass, st);
-    // (one instantiation per row length: the stage loop is unrolled with compile-time stage numbers)
+    // (one instantiation per row length: static stage loops.  Radix-4 register butterflies for full tiles (transforms of 2^20 and
+    // more), radix-2 for the narrow tiles of short transforms, whose passes are latency-bound and want two butterflies per lane
+    // rather than half the lanes idle; env MI355ZK_NTT_RADIX = 2 / 4 forces one)
+    static const char* radix_env = std::getenv("MI355ZK_NTT_RADIX");
+    const bool r4 = radix_env ? std::atoi(radix_env) == 4 : (uint64_t)P.g * np >= 4ull * NTT_THREADS;  // a full tile: a group of four per lane
 #define ZK_NTT_LAUNCH(L)                                                                                                                   \
   case L:                                                                                                                                  \
-    hipLaunchKernelGGL(ntt_pass_kernel<L>, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, T->B,   \
-                       Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr, post_cu); \
+    if (r4)                                                                                                                                \
+      hipLaunchKernelGGL((ntt_pass_kernel<L, true>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
+                         T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,  \
+                         post_cu);                                                                                                         \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((ntt_pass_kernel<L, false>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
+                         T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,  \
+                         post_cu);                                                                                                         \
     break;
     switch (b[p]) {
       ZK_NTT_LAUNCH(1) ZK_NTT_LAUNCH(2) ZK_NTT_LAUNCH(3) ZK_NTT_LAUNCH(4) ZK_NTT_LAUNCH(5) ZK_NTT_LAUNCH(6) ZK_NTT_LAUNCH(7) ZK_NTT_LAUNCH(8)
