@@ -76,6 +76,39 @@ def test_device_resident_roundtrips(zk, worker, log_n):
         assert np.array_equal(f_a.cpu().numpy().view(np.uint64), want)
 
 
+@pytest.mark.parametrize("log_n", [23, 26])
+def test_large_transforms_roundtrip_and_halve(zk, worker, log_n):
+    """Sizes the oracle cannot reach in seconds (three passes with 9-bit rows at 2^26: the radix-4 kernel with a lone first stage),
+    by size-independent properties: ifft(fft(a)) == a, icoset_fft(coset_fft(a)) == a, and the decimation identity that ties a
+    transform to the one of half its size -- the even outputs of fft_n(a) are fft_{n/2}(a[:n/2] + a[n/2:]) (omega_{n/2} =
+    omega_n^2 in bellman's domains, domain.rs:60-75) -- so that, level by level, the large sizes hang on the oracle-checked ones."""
+    import ctypes as C
+
+    import torch
+
+    import bench
+
+    L = zk.lib.load()
+    n = 1 << log_n
+    d = bench.gen_scalars(n, 4200 + log_n, torch.device("cuda", 0))      # canonical values < r are valid Montgomery elements
+    dom = zk.EvaluationDomain(d.clone(), log_n)
+    dom.fft(worker)
+    f = dom.coeffs.clone()
+    dom.ifft(worker)
+    assert torch.equal(dom.coeffs, d)
+    dom.coset_fft(worker)
+    dom.icoset_fft(worker)
+    assert torch.equal(dom.coeffs, d)
+    del dom
+    lo, hi = d[:n // 2].clone(), d[n // 2:].clone()
+    neg = torch.zeros_like(hi)
+    assert L.mi355zk_bn254_fr_sub_assign_dev(C.c_void_p(neg.data_ptr()), C.c_void_p(hi.data_ptr()), n // 2, None) == 0      # -hi
+    assert L.mi355zk_bn254_fr_sub_assign_dev(C.c_void_p(lo.data_ptr()), C.c_void_p(neg.data_ptr()), n // 2, None) == 0      # lo + hi
+    half = zk.EvaluationDomain(lo, log_n - 1)
+    half.fft(worker)
+    assert torch.equal(half.coeffs, f[0::2].contiguous())
+
+
 @pytest.mark.parametrize("op", ["ifft", "coset_fft"])
 def test_2e24_three_pass_uneven_split_matches_oracle(zk, worker, op):
     """2^24 elements (512 MiB): three passes with an uneven digit split, the fused scalings on the first / last pass; all
