@@ -7,7 +7,7 @@
 // order in, natural order out, in place.
 //
 // Algorithm (not the reference's): a size-N transform is factored N = N_1 * ... * N_R (R <= 3,
-// N_p <= 1024) Cooley-Tukey style.  Pass p transforms digit p of the index for G adjacent
+// N_p <= 4096, normally 1024) Cooley-Tukey style.  Pass p transforms digit p of the index for G adjacent
 // "columns" at once: a workgroup stages a G x N_p tile (<= 4096 elements) in LDS as NINE 29-bit limb
 // planes (U-form, fieldu.hpp; unit-stride lanes -> conflict-free ds_read_b32), runs log2(N_p) DIT stages
 // there, multiplies by the inter-pass twiddle omega^(T_p*k_p*rest) and writes back in the 32-byte
@@ -39,7 +39,8 @@ namespace zk {
 
 namespace {
 
-constexpr int NTT_MAX_LOG_NP = 10;   // 1024-point sub-transform per tile row
+constexpr int NTT_MAX_LOG_NP = 12;   // longest sub-transform a tile row can be (kernel instantiations, root tables)
+constexpr int NTT_LOG_NP = 10;       // the pass planner's default: 1024-point rows (longer ones for 2^21 .. 2^23; env MI355ZK_NTT_LOGNP = 10 / 11 / 12 forces)
 constexpr int NTT_TILE_ELEMS = 4096; // G * N_p
 constexpr int NTT_THREADS = 1024;
 
@@ -119,6 +120,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
                                                               const UTab* __restrict__ postB, FrU post_c) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr uint32_t np = 1u << LOG_NP;
+  // twiddle-one products are skipped in stages 0 .. SKIP_MAX: rows longer than 2^10 give up stage 2 (a skipped stage doubles the
+  // value bound instead of adding 2p: 16p + 2 (LOG_NP - 3) p would pass the 32p the closing reduction allows; 10p + 2 (LOG_NP - 3) p does not)
+  constexpr uint32_t SKIP_MAX = LOG_NP > 10 ? 1 : 2;
   constexpr uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
   const uint32_t plane = P.g * pitch;
   const uint32_t elems = P.g * np;
@@ -202,14 +206,14 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       const uint32_t row = g * pitch;
       const uint32_t ia = row + swz(x0), ib = row + swz(x0 + m), ic = row + swz(x0 + 2 * m), id = row + swz(x0 + 3 * m);
       FrU a = lds_load(lds, plane, ia), b = lds_load(lds, plane, ib), c = lds_load(lds, plane, ic), d = lds_load(lds, plane, id);
-      const bool one = s <= 2 && j == 0;                                   // stage s (s == 0: j == 0 always)
+      const bool one = s <= SKIP_MAX && j == 0;                            // stage s (s == 0: j == 0 always)
       {
         FrU w1 = a;
         if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));
         bf(std::integral_constant<int, (int)s>{}, a, b, w1, one);
         bf(std::integral_constant<int, (int)s>{}, c, d, w1, one);
       }
-      const bool one2 = s + 1 <= 2 && j == 0;                              // stage s + 1, pair (a, c): index j
+      const bool one2 = s + 1 <= SKIP_MAX && j == 0;                       // stage s + 1, pair (a, c): index j
       {
         FrU w2 = a;
         if (!one2) w2 = tab_load(roots + ((uint64_t)j << (LOG_NP - 2 - s)));
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     // Bounds: a skipped product leaves t as large as u, so values DOUBLE on that path: V_1 < 4p, V_2 < 8p, V_3 < 16p, and
     // with + 2p for each of the stages 3..9: < 30p at the end (u_to_std_lt32p / the closing product allow < 32p); the
     // subtraction constant follows (u_sub<4,1> / <8,1>).  Stage 3 is not skipped: it would take the bound past 32p.
-    constexpr bool j_slow = (s == 1 || s == 2) && (np >> (s + 1)) >= 64;
+    constexpr bool j_slow = s >= 1 && s <= SKIP_MAX && (np >> (s + 1)) >= 64;
     for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
       uint32_t g = b >> (LOG_NP - 1);
       uint32_t bf = b & ((np >> 1) - 1);
@@ -427,6 +431,7 @@ int ntt_configure() {
   const void* fns[2 * NTT_MAX_LOG_NP + 2] = {};
 #define ZK_NTT_FN(L) fns[L] = reinterpret_cast<const void*>(ntt_pass_kernel<L, false>); fns[NTT_MAX_LOG_NP + L] = reinterpret_cast<const void*>(ntt_pass_kernel<L, true>);
   ZK_NTT_FN(1) ZK_NTT_FN(2) ZK_NTT_FN(3) ZK_NTT_FN(4) ZK_NTT_FN(5) ZK_NTT_FN(6) ZK_NTT_FN(7) ZK_NTT_FN(8) ZK_NTT_FN(9) ZK_NTT_FN(10)
+  ZK_NTT_FN(11) ZK_NTT_FN(12)
 #undef ZK_NTT_FN
   for (int l = 1; l <= 2 * NTT_MAX_LOG_NP; ++l) {
     hipError_t e = hipFuncSetAttribute(fns[l], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -472,7 +477,15 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   const uint64_t n = 1ull << log_n;
   // factor the index: R passes of b[p] bits, b[0] most significant digit (DESIGN.md "NTT")
   uint32_t b[3];
-  int R = (int)((log_n + NTT_MAX_LOG_NP - 1) / NTT_MAX_LOG_NP);
+  static const char* lognp_env = std::getenv("MI355ZK_NTT_LOGNP");
+  // rows of 2^10 by default; 2^11 / 2^12 where that saves a whole pass AND the long-row pass still moves >= 64-byte runs for most
+  // of the transform: 2^21 and 2^22 in two passes (0.372 -> 0.312 ms, 0.715 -> 0.612 ms), 2^23 as 12 + 11 (1.36 -> 1.30 ms); 2^24 as
+  // 12 + 12 (32-byte runs in both passes) loses to three passes of 8 bits (2.67 against 2.58 ms)
+  int row_bits = NTT_LOG_NP;
+  if (log_n == 21 || log_n == 22) row_bits = 11;
+  if (log_n == 23) row_bits = 12;
+  if (lognp_env && std::atoi(lognp_env) >= 10 && std::atoi(lognp_env) <= 12) row_bits = std::atoi(lognp_env);
+  int R = (int)((log_n + row_bits - 1) / row_bits);
   for (int p = 0; p < R; ++p) b[p] = log_n / R + ((uint32_t)p < log_n % R ? 1 : 0);
 
   int rc = ntt_configure();
@@ -598,7 +611,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     break;
     switch (b[p]) {
       ZK_NTT_LAUNCH(1) ZK_NTT_LAUNCH(2) ZK_NTT_LAUNCH(3) ZK_NTT_LAUNCH(4) ZK_NTT_LAUNCH(5) ZK_NTT_LAUNCH(6) ZK_NTT_LAUNCH(7) ZK_NTT_LAUNCH(8)
-      ZK_NTT_LAUNCH(9) ZK_NTT_LAUNCH(10)
+      ZK_NTT_LAUNCH(9) ZK_NTT_LAUNCH(10) ZK_NTT_LAUNCH(11) ZK_NTT_LAUNCH(12)
       default: return ZK_ERR_BAD_ARGS;
     }
 #undef ZK_NTT_LAUNCH

@@ -34,7 +34,9 @@ def test_domain_ops_match_oracle(zk, worker, log_n, op):
 
 
 @pytest.mark.parametrize("log_n", [21, 22])
-def test_three_pass_transform_matches_oracle(zk, worker, log_n):
+def test_long_row_transforms_match_oracle(zk, worker, log_n):
+    """2^21 and 2^22 run as two passes of 2048-point rows (11 + 10, 11 + 11: the radix-4 kernel with a lone first stage and the
+    stage-2 product skip given up for the value bound); the three-pass plans are covered at 2^24 and 2^26 below."""
     a = inputs.random_fr_mont(1 << log_n, seed=200 + log_n)
     want = O.fr_domain_op(a, log_n, "fft", log_cpus=3).reshape(-1, 4)  # parallel_fft shape == serial_fft (domain.rs:465-496)
     dom = zk.EvaluationDomain.from_coeffs(a)
