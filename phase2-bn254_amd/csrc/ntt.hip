@@ -61,6 +61,7 @@ struct NttPassParams {
   uint32_t pre_h;
   uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h)
   uint32_t post_h;
+  uint32_t xcd_pair;        // 1: tiles 2j and 2j + 1 run on the same XCD, one dispatch round apart (see the kernel)
 };
 
 // table entry: U-form element in the 2^261 domain, padded to 48 B for three 16-byte loads
@@ -126,7 +127,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   constexpr uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
   const uint32_t plane = P.g * pitch;
   const uint32_t elems = P.g * np;
-  const uint64_t tile = blockIdx.x;
+  // One- and two-row tiles move 32- / 64-byte runs at a large stride: a fraction of every DRAM burst and page, the rest belonging to
+  // the neighbouring tiles.  Workgroup ids go round the eight XCDs, so neighbours would sit behind different L2s; instead the 32 tiles
+  // an XCD runs at a time (ids b + 8k) are made NEIGHBOURS, so that the XCD's L2 sees kilobyte runs.
+  uint64_t tile = blockIdx.x;
+  if (P.xcd_pair == 1) tile = (tile & ~15ull) | ((tile & 7ull) << 1) | ((tile >> 3) & 1ull);
+  else if (P.xcd_pair == 5) tile = (tile & ~255ull) | ((tile & 7ull) << 5) | ((tile >> 3) & 31ull);  // 32 neighbours per XCD: what it runs at a time
   const uint64_t hi = tile / P.tiles_lo, lo = tile % P.tiles_lo;
   const uint64_t in_base = hi * P.in_hi_stride + lo * P.in_lo_stride;
   const uint64_t out_base = hi * P.out_hi_stride + lo * P.out_lo_stride;
@@ -478,12 +484,12 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   // factor the index: R passes of b[p] bits, b[0] most significant digit (DESIGN.md "NTT")
   uint32_t b[3];
   static const char* lognp_env = std::getenv("MI355ZK_NTT_LOGNP");
-  // rows of 2^10 by default; 2^11 / 2^12 where that saves a whole pass AND the long-row pass still moves >= 64-byte runs for most
-  // of the transform: 2^21 and 2^22 in two passes (0.372 -> 0.312 ms, 0.715 -> 0.612 ms), 2^23 as 12 + 11 (1.36 -> 1.30 ms); 2^24 as
-  // 12 + 12 (32-byte runs in both passes) loses to three passes of 8 bits (2.67 against 2.58 ms)
+  // rows of 2^10 by default; 2^11 / 2^12 where that saves a whole pass: 2^21 and 2^22 in two passes (0.372 -> 0.305 ms, 0.715 ->
+  // 0.59 ms), 2^23 as 12 + 11 (1.36 -> 1.23 ms), 2^24 as 12 + 12 (2.58 -> 2.41 ms).  The one- and two-row tiles of those passes move
+  // 32- / 64-byte runs; the kernel's XCD grouping of neighbouring tiles is what makes them pay (2^24 without it: 2.72 ms).
   int row_bits = NTT_LOG_NP;
   if (log_n == 21 || log_n == 22) row_bits = 11;
-  if (log_n == 23) row_bits = 12;
+  if (log_n == 23 || log_n == 24) row_bits = 12;
   if (lognp_env && std::atoi(lognp_env) >= 10 && std::atoi(lognp_env) <= 12) row_bits = std::atoi(lognp_env);
   int R = (int)((log_n + row_bits - 1) / row_bits);
   for (int p = 0; p < R; ++p) b[p] = log_n / R + ((uint32_t)p < log_n % R ? 1 : 0);
@@ -585,6 +591,11 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       P.tw_mul = 0;
       tiles = (N1 / G) * mid;
     }
+    static const bool no_pair = std::getenv("MI355ZK_NTT_NOPAIR") != nullptr;
+    static const char* pair_env = std::getenv("MI355ZK_NTT_PAIR");
+    static const bool pair_all = std::getenv("MI355ZK_NTT_PAIR_ALL") != nullptr;
+    // (narrow tiles only: with 128-byte runs and more the grouping is neutral -- measured with MI355ZK_NTT_PAIR_ALL)
+    P.xcd_pair = ((P.g <= 2 || pair_all) && tiles % 256 == 0 && !no_pair) ? (pair_env ? (uint32_t)std::atoi(pair_env) : 5u) : 0u;
     if (p == 0 && Tpre) { P.pre = 1; P.pre_h = Tpre->h; }
     if (p == R - 1) { P.post = Tpost ? 2 : (post_c ? 1 : 3); P.post_h = Tpost ? Tpost->h : 0; }
     uint32_t pitch = np >= 32 ? (uint32_t)np + 1 : (uint32_t)np;
