@@ -14,7 +14,7 @@ put("bench_n1.json", "bench_n1.json"); put("bench_2e20.json", "bench_2e20.json")
 put("next_rows_2e20.json", "next_rows_2e20.json"); put("ntt20.json", "ntt20.json")
 put("contribute_2e20.json", "contribute_2e20.json"); put("host_entry.json", "host_entry.json"); put("shard_cells_2e26.json", "shard_cells_2e26.json")
 put("ntt_16_20_24.json", "ntt_16_20_24.json"); put("skew_2e26.json", "skew_2e26.json"); put("bench_n1_tau.json", "bench_n1_tau.json")
-put("ubench_valu.txt", "ubench_valu.txt"); put("ubench_fieldmul.txt", "ubench_fieldmul.txt"); put("ubench_wave_bucket.txt", "ubench_wave_bucket.txt"); put("prover.json", "prover.json"); put("skew_small.json", "skew_16_20.json")
+put("ubench_valu.txt", "ubench_valu.txt"); put("ntt_other_sizes.json", "ntt_other_sizes.json"); put("ubench_fieldmul.txt", "ubench_fieldmul.txt"); put("ubench_wave_bucket.txt", "ubench_wave_bucket.txt"); put("prover.json", "prover.json"); put("skew_small.json", "skew_16_20.json")
 put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
     "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, 2^26-point G1 MSM)\n"
     "# summarised from the rocpd database with tools/rocpd_summary.py (ROCm 7.2 rocprofv3 writes rocpd; same numbers as --stats)\n"
