@@ -17,6 +17,7 @@
 
 #include "../../include/mi355zk.h"
 #include "curveu.hpp"
+#include "glv.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -153,33 +154,24 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
   if constexpr (std::is_same<F, Fq>::value) {
     JacU<FqParams> acc = JacU<FqParams>::zero();
     if (!base.is_zero()) {
-      // NAF digits d_j = bit_{j+1}(3k) - bit_{j+1}(k):  pos = (3k >> 1) & ~(k >> 1),  neg = (k >> 1) & ~(3k >> 1)
-      uint32_t k3[9];
-      uint64_t carry = 0;
-#pragma unroll
-      for (int l = 0; l < 8; ++l) {
-        uint64_t t = (uint64_t)s[l] * 3u + carry;
-        k3[l] = (uint32_t)t;
-        carry = t >> 32;
-      }
-      k3[8] = (uint32_t)carry;
-      uint32_t pos[8], neg[8];
-#pragma unroll
-      for (int l = 0; l < 8; ++l) {
-        uint32_t a = (k3[l] >> 1) | (k3[l + 1] << 31);
-        uint32_t b = (s[l] >> 1) | (l < 7 ? s[l + 1] << 31 : 0u);
-        pos[l] = a & ~b;
-        neg[l] = b & ~a;
-      }
+      // GLV (glv.hpp): k P = k1 P + k2 phi(P), |k1|, |k2| < 2^128, phi(x, y) = (beta x, y): 129 doublings instead of 254.  Both
+      // halves in non-adjacent form (one addition per three bits each): digit j = bit_{j+1}(3m) - bit_{j+1}(m).
+      const GlvSplit g = glv_split(s);
+      uint32_t p1[6], n1[6], p2[6], n2[6];
+      glv_naf(g.k1, p1, n1);
+      glv_naf(g.k2, p2, n2);
       const FqU C = UPow2<FqParams, 266>::get();           // x*2^256 * 2^266 / 2^261 = x * 2^261
       const FqU x2 = u_mul(u_from_std(base.x), C);          // < 2p, N
       const FqU y2 = u_mul(u_from_std(base.y), C);
+      const FqU xb = u_mul(x2, u_mul(u_from_std(glv_beta()), C));   // beta x, 2^261 domain, < 2p
       bool found = false;
-      for (int bit = 255; bit >= 0; --bit) {
-        const bool p = (pos[bit >> 5] >> (bit & 31)) & 1, m = (neg[bit >> 5] >> (bit & 31)) & 1;
+      for (int bit = 129; bit >= 0; --bit) {
+        const bool a1 = (p1[bit >> 5] >> (bit & 31)) & 1, m1 = (n1[bit >> 5] >> (bit & 31)) & 1;
+        const bool a2 = (p2[bit >> 5] >> (bit & 31)) & 1, m2 = (n2[bit >> 5] >> (bit & 31)) & 1;
         if (found) acc = jacu_double(acc);
-        else found = p;                                     // the leading NAF digit of a positive number is +1
-        if (p | m) jacu_add_mixed(acc, x2, y2, m);
+        if (a1 | m1) jacu_add_mixed(acc, x2, y2, m1 != g.neg1);
+        if (a2 | m2) jacu_add_mixed(acc, xb, y2, m2 != g.neg2);
+        found = found | a1 | m1 | a2 | m2;
       }
     }
     const Jacobian<F> r = jacu_to_std(acc);
@@ -201,7 +193,8 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
 }
 
 // G1, per-point scalars: NAF gives every LANE an addition on a third of the bits, but a WAVE then adds on nearly every
-// bit (some lane always has a non-zero digit).  With fixed signed 4-bit windows all lanes add at the same 64 places:
+// bit (some lane always has a non-zero digit).  With fixed signed 4-bit windows all lanes add at the same places (64 for a
+// 254-bit scalar; 2 x 33 after the GLV split, which halves the doublings):
 // each lane builds its own table {1..8} * P (Jacobian + Z^2, Z^3: JacTabU, 192 B) in a scratch array laid out
 // [entry][lane], then runs 4 doublings + one table addition per window.  254 x 1071 + 60 x 2079 + table ~ 408k mads per
 // scalar against 254 x (1071 + 1593) on the NAF path when lanes diverge.
@@ -237,30 +230,44 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
       else q = jacu_double(q);
       tab[(uint64_t)(e - 1) * n_chunk + t] = jacu_tab_entry(q);
     }
-    // signed digits d_j in [-8, 8]: k = sum d_j 16^j
-    uint32_t mag[8], sgn[2] = {0, 0};
-    uint32_t carry = 0;
+    // GLV (glv.hpp): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128 -- 33 windows of 4 doublings instead of 64; phi of a table
+    // entry is the entry with X multiplied by beta (Y, Z, Z^2, Z^3 unchanged), one more product per addition.
+    // signed digits d_j in [-8, 8] of both halves: m = sum d_j 16^j
+    const GlvSplit g = glv_split(s);
+    uint32_t mag1[5], mag2[5], sgn1[2] = {0, 0}, sgn2[2] = {0, 0};
+    auto digits = [](const uint32_t m[5], uint32_t mag[5], uint32_t sgn[2]) {
+      uint32_t carry = 0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      uint32_t m = 0;
+      for (int w = 0; w < 5; ++w) {
+        uint32_t o = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        uint32_t d = ((s[w] >> (4 * q)) & 15u) + carry;
-        carry = d > 8u ? 1u : 0u;
-        if (carry) {
-          d = 16u - d;
-          sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+        for (int q = 0; q < 8; ++q) {
+          uint32_t d = ((m[w] >> (4 * q)) & 15u) + carry;
+          carry = d > 8u ? 1u : 0u;
+          if (carry) {
+            d = 16u - d;
+            sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+          }
+          o |= d << (4 * q);
         }
-        m |= d << (4 * q);
+        mag[w] = o;
       }
-      mag[w] = m;
-    }
+    };
+    digits(g.k1, mag1, sgn1);   // (magnitudes < 2^128: the carry out of nibble 31 lands in nibble 32, nothing beyond)
+    digits(g.k2, mag2, sgn2);
+    const FqU betaU = u_mul(u_from_std(glv_beta()), C);     // beta, 2^261 domain
 #pragma unroll 1
-    for (int j = 63; j >= 0; --j) {
+    for (int j = 32; j >= 0; --j) {
 #pragma unroll 1
       for (int rep = 0; rep < 4; ++rep) acc = jacu_double(acc);
-      const uint32_t d = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
-      if (d) jacu_add_tab(acc, tab[(uint64_t)(d - 1) * n_chunk + t], (sgn[j >> 5] >> (j & 31)) & 1u);
+      const uint32_t d1 = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
+      if (d1) jacu_add_tab(acc, tab[(uint64_t)(d1 - 1) * n_chunk + t], (((sgn1[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg1);
+      const uint32_t d2 = (mag2[j >> 3] >> (4 * (j & 7))) & 15u;
+      if (d2) {
+        JacTabU<FqParams> e = tab[(uint64_t)(d2 - 1) * n_chunk + t];
+        e.x = u_mul(e.x, betaU);                            // X < 6p: < 1.08p
+        jacu_add_tab(acc, e, (((sgn2[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg2);
+      }
     }
   }
   const Jacobian<Fq> r = jacu_to_std(acc);

@@ -11,6 +11,7 @@
 
 #include "../../include/mi355zk.h"
 #include "curveu.hpp"
+#include "glv.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -246,6 +247,16 @@ int mi355zk_selftest_g2_record_sum(int mode, const uint64_t* affine_pts, const u
   if (mode == 0) total = zk::xyzzr_store(run);
   const zk::G2XYZZ r = zk::xyzzr_to_std(total);
   std::memcpy(out_xyzz, &r, sizeof r);
+  return ZK_OK;
+}
+
+// GLV split of a canonical scalar (glv.hpp) on the HOST: out = k1 magnitude (5 u32), k2 magnitude (5 u32), sign of k1, sign of k2
+int mi355zk_selftest_glv_split(const uint32_t k[8], uint32_t out[12]) {
+  if (!k || !out) return ZK_ERR_BAD_ARGS;
+  const zk::GlvSplit g = zk::glv_split(k);
+  for (int i = 0; i < 5; ++i) { out[i] = g.k1[i]; out[5 + i] = g.k2[i]; }
+  out[10] = g.neg1 ? 1u : 0u;
+  out[11] = g.neg2 ? 1u : 0u;
   return ZK_OK;
 }
 

@@ -1,0 +1,143 @@
+// GLV scalar decomposition for BN254 G1, used by the per-point scalar multiplications (batch_exp and what is built on it: the
+// terms of the QAP sums, the butterflies of the point FFT).  The curve y^2 = x^3 + 3 over Fq has the endomorphism
+//     phi(x, y) = (beta x, y) = lambda (x, y),      beta^3 = 1 in Fq,  lambda^2 + lambda + 1 = 0 mod r,
+// so k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128: half the doublings of a 254-bit ladder.  The group element -- hence the affine
+// output the reference's batch_exp / batch_normalization leave (ec.rs:251-299) -- does not depend on the chain that produced it.
+//   lambda = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd,  beta = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
+//   lattice basis of {(x, y): x + y lambda = 0 mod r}:  v1 = (a1, -|b1|),  v2 = (a2, b2)
+//   k1 = k - c1 a1 - c2 a2,   k2 = c1 |b1| - c2 b2,   c1 = floor(k g1 / 2^256),  c2 = floor(k g2 / 2^256),
+//   g1 = floor(2^256 b2 / r),  g2 = floor(2^256 |b1| / r).
+// ANY integers c1, c2 give k1 + k2 lambda = k (mod r) exactly; the floors (instead of roundings) only cost a bit of size:
+// |k1|, |k2| < 2^128 (tests/test_glv_host.py: identity and size on random and edge scalars against big integers).
+#pragma once
+
+#include "field.hpp"
+
+namespace zk {
+
+struct GlvSplit {
+  uint32_t k1[5], k2[5];  // magnitudes, < 2^128 (the fifth limb is headroom)
+  bool neg1, neg2;
+};
+
+namespace glv_detail {
+// out[0 .. NA+NB) = a * b   (32-bit limbs, little endian)
+template <int NA, int NB>
+ZK_HD void mul_limbs(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+#pragma unroll
+  for (int i = 0; i < NA + NB; ++i) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+      out[i + j] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    out[i + NB] = (uint32_t)carry;
+  }
+}
+// r = a - b on N limbs (two's complement); returns the sign (1: negative) and leaves |a - b| in r
+template <int N>
+ZK_HD bool sub_abs(const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const uint64_t t = (uint64_t)a[i] - b[i] - borrow;
+    r[i] = (uint32_t)t;
+    borrow = (t >> 32) & 1u;
+  }
+  const bool neg = borrow != 0;
+  if (neg) {
+    uint64_t carry = 1;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint64_t t = (uint64_t)(~r[i]) + carry;
+      r[i] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+  return neg;
+}
+}  // namespace glv_detail
+
+// beta in the memory format (beta * 2^256 mod q)
+ZK_HD Fq glv_beta() {
+  Fq b;
+  const uint32_t l[8] = {0xd782e155u, 0x71930c11u, 0xffbe3323u, 0xa6bb947cu, 0xd4741444u, 0xaa303344u, 0x26594943u, 0x2c3b3f0du};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b.l[i] = l[i];
+  return b;
+}
+
+// k: canonical scalar (< r), 8 x 32-bit limbs
+ZK_HD GlvSplit glv_split(const uint32_t k[8]) {
+  using namespace glv_detail;
+  const uint32_t G1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};
+  const uint32_t G2[5] = {0x391eb18du, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x00000002u};
+  const uint32_t A1[2] = {0x94d213e3u, 0x89d32568u};                                  // = b2
+  const uint32_t A2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+  const uint32_t B1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};        // |b1|
+  uint32_t t11[11], t13[13];
+  mul_limbs<8, 3>(k, G1, t11);
+  mul_limbs<8, 5>(k, G2, t13);
+  const uint32_t* c1 = t11 + 8;   // 3 limbs
+  const uint32_t* c2 = t13 + 8;   // 5 limbs
+  // k1 = k - (c1 a1 + c2 a2) on 9 limbs
+  uint32_t p1[5], p2[9], sum[9], kk[9], d[9];
+  mul_limbs<3, 2>(c1, A1, p1);
+  mul_limbs<5, 4>(c2, A2, p2);
+  {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const uint64_t t = (uint64_t)p2[i] + (i < 5 ? p1[i] : 0u) + carry;
+      sum[i] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) kk[i] = i < 8 ? k[i] : 0u;
+  GlvSplit s;
+  s.neg1 = sub_abs<9>(kk, sum, d);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s.k1[i] = d[i];
+  // k2 = c1 |b1| - c2 b2 on 8 limbs
+  uint32_t q1[7], q2[7], e1[8], e2[8], e[8];
+  mul_limbs<3, 4>(c1, B1, q1);
+  mul_limbs<5, 2>(c2, A1, q2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    e1[i] = i < 7 ? q1[i] : 0u;
+    e2[i] = i < 7 ? q2[i] : 0u;
+  }
+  s.neg2 = sub_abs<8>(e1, e2, e);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s.k2[i] = e[i];
+  return s;
+}
+
+// non-adjacent form of a magnitude m < 2^159 (5 limbs): digit j = bit_{j+1}(3m) - bit_{j+1}(m);  pos / neg: 5 limbs + 1 bit (6 words)
+ZK_HD void glv_naf(const uint32_t m[5], uint32_t pos[6], uint32_t neg[6]) {
+  uint32_t m3[7], mm[7];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int l = 0; l < 6; ++l) {
+    const uint64_t t = (uint64_t)(l < 5 ? m[l] : 0u) * 3u + carry;
+    m3[l] = (uint32_t)t;
+    carry = t >> 32;
+    mm[l] = l < 5 ? m[l] : 0u;
+  }
+  m3[6] = 0;
+  mm[6] = 0;
+#pragma unroll
+  for (int l = 0; l < 6; ++l) {
+    const uint32_t a = (m3[l] >> 1) | (m3[l + 1] << 31);
+    const uint32_t b = (mm[l] >> 1) | (mm[l + 1] << 31);
+    pos[l] = a & ~b;
+    neg[l] = b & ~a;
+  }
+}
+
+}  // namespace zk

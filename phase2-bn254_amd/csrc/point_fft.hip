@@ -5,7 +5,8 @@
 // driven by powersoftau/src/bin/prepare_phase2.rs:68-131 (affine tau-powers -> ifft -> batch_normalization ->
 // Lagrange-basis points) -- the dominant cost of `prepare_phase2`.
 //
-// Every butterfly is a 254-bit scalar multiplication, so the work is n/2 * log n * ~400k integer mads: pure ALU.
+// Every butterfly is a 254-bit scalar multiplication (split in two 128-bit halves by the curve's endomorphism, glv.hpp), so the
+// work is n/2 * log n * ~300k integer mads: pure ALU.
 // Layout: a working array of U-form JACOBIAN points (curveu.hpp JacU, every coordinate in the 2^261 domain, 112 B per
 // point) in HBM; one lane per butterfly per stage, DIT after a bit-reversed load.  The twiddle multiplication uses
 // fixed signed 4-bit windows over a per-lane table {1..8} * t in a scratch array laid out [entry][lane] (JacTabU:
@@ -21,6 +22,7 @@
 
 #include "../../include/mi355zk.h"
 #include "curveu.hpp"
+#include "glv.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -74,12 +76,12 @@ __global__ void __launch_bounds__(256) pfft_load_kernel(const G1Affine* __restri
   pt_store(work + r, v);
 }
 
-// signed 4-bit digits of a canonical scalar: k = sum d_j 16^j, d_j in [-8, 8]; magnitudes as nibbles, signs as bits
-__device__ __forceinline__ void recode16(const uint32_t* k, uint32_t mag[8], uint32_t sgn[2]) {
+// signed 4-bit digits of a magnitude m < 2^128 (5 limbs): m = sum d_j 16^j, d_j in [-8, 8], j <= 32; magnitudes as nibbles, signs as bits
+__device__ __forceinline__ void recode16(const uint32_t* k, uint32_t mag[5], uint32_t sgn[2]) {
   sgn[0] = sgn[1] = 0;
   uint32_t carry = 0;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) {
+  for (int w = 0; w < 5; ++w) {
     uint32_t m = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -95,10 +97,13 @@ __device__ __forceinline__ void recode16(const uint32_t* k, uint32_t mag[8], uin
   }
 }
 
-// The shared program.  Entries 1..8 of the lane's table hold 1t..8t (entry 1 is rewritten with the product at the end).
-//   steps 0..6    table:  2t = 2*1t, 3t = 2t + 1t, 4t = 2*2t, 5t = 4t + 1t, 6t = 2*3t, 7t = 6t + 1t, 8t = 2*4t
-//   steps 7..262  256 doublings; after every 4th the window's digit entry is added
-//   step  263     (mode butterfly) entry 1 := product;  steps 264 / 265: a[i0] = u + product, a[i1] = u - product
+// The shared program.  Entries 1..8 of the lane's table hold 1t..8t (entry 1 is rewritten with the product at the end).  The twiddle is
+// split by the GLV endomorphism (glv.hpp): w t = k1 t + k2 phi(t), |k1|, |k2| < 2^128, phi(X, Y, Z) = (beta X, Y, Z) -- 132 doublings
+// instead of 256.
+//   steps 0..6      table:  2t = 2*1t, 3t = 2t + 1t, 4t = 2*2t, 5t = 4t + 1t, 6t = 2*3t, 7t = 6t + 1t, 8t = 2*4t
+//   steps 7..171    33 windows of five steps: four doublings (the fourth adds the window's k1 digit entry), then the k2 digit entry
+//                   with X multiplied by beta
+//   step  172       (mode butterfly) entry 1 := product;  steps 173 / 174: a[i0] = u + product, a[i1] = u - product
 // mode 0: butterfly of stage s (domain.rs:303-309);  mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173)
 __global__ void __launch_bounds__(256) pfft_stage_kernel(PtJ* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
                                                         uint32_t s, uint64_t b0, uint64_t n_chunk, TU* __restrict__ tab, int mode, Fr c) {
@@ -123,39 +128,49 @@ __global__ void __launch_bounds__(256) pfft_stage_kernel(PtJ* __restrict__ work,
   }
   const JU u = mode == 0 ? pt_load(work + i0) : JU::zero();
   JU acc = pt_load(work + i1);
-  uint32_t mag[8], sgn[2];
-  recode16(kk, mag, sgn);
+  const GlvSplit g = glv_split(kk);
+  uint32_t mag1[5], sgn1[2], mag2[5], sgn2[2];
+  recode16(g.k1, mag1, sgn1);
+  recode16(g.k2, mag2, sgn2);
+  const FqU betaU = u_mul(u_from_std(glv_beta()), UPow2<FqParams, 266>::get());   // beta, 2^261 domain
   const bool t_inf = acc.is_zero();
   if (t_inf && mode == 1) return;
   TU e1 = jacu_tab_entry(acc);  // 1t (an infinity t keeps z == 0: every sum below then returns the other operand)
   tab[t] = e1;
   constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};  // nibbles: load, double, add, store
-  const int first = (unit || t_inf) ? 263 : 0;
-  const int last = mode == 0 ? 265 : 262;
+  constexpr int MAIN0 = 7, WINDOWS = 33, STEP_STORE = MAIN0 + 5 * WINDOWS, STEP_SUM = STEP_STORE + 1, STEP_DIF = STEP_STORE + 2;
+  const int first = (unit || t_inf) ? STEP_STORE : 0;
+  const int last = mode == 0 ? STEP_DIF : STEP_STORE - 1;
 #pragma unroll 1
   for (int step = first; step <= last; ++step) {
-    uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0;
-    if (step < 7) {
+    uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0, phi = 0;
+    if (step < MAIN0) {
       const uint32_t pr = PROG[step];
       load = pr >> 12;
       dbl_it = (pr >> 8) & 15u;
       add = (pr >> 4) & 15u;
       store = pr & 15u;
-    } else if (step < 263) {
-      const int m = step - 7;
+    } else if (step < STEP_STORE) {
+      const int m = step - MAIN0;
       if (m == 0) acc = JU::zero();
-      dbl_it = 1;
-      if ((m & 3) == 3) {
-        const int j = 63 - (m >> 2);
-        add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
-        negate = (sgn[j >> 5] >> (j & 31)) & 1u;
+      const int win = m / 5, sub = m - 5 * win, j = WINDOWS - 1 - win;
+      if (sub < 4) {
+        dbl_it = 1;
+        if (sub == 3) {
+          add = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
+          negate = (((sgn1[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg1;
+        }
+      } else {
+        add = (mag2[j >> 3] >> (4 * (j & 7))) & 15u;
+        negate = (((sgn2[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg2;
+        phi = 1;
       }
-    } else if (step == 263) {
+    } else if (step == STEP_STORE) {
       store = 1;                       // the product (or t itself when the twiddle is 1) becomes entry 1
     } else {
       acc = u;
       add = 1;
-      negate = step == 265;
+      negate = step == STEP_DIF;
     }
     if (load) {
       const TU e = tab[(uint64_t)(load - 1) * n_chunk + t];
@@ -163,12 +178,13 @@ __global__ void __launch_bounds__(256) pfft_stage_kernel(PtJ* __restrict__ work,
     }
     if (dbl_it) acc = jacu_double(acc);
     if (add) {
-      const TU e = tab[(uint64_t)(add - 1) * n_chunk + t];
+      TU e = tab[(uint64_t)(add - 1) * n_chunk + t];
+      if (phi) e.x = u_mul(e.x, betaU);                  // X < 6p: < 1.08p
       if (!e.z.limbs_all_zero()) jacu_add_tab(acc, e, negate != 0);
     }
     if (store) tab[(uint64_t)(store - 1) * n_chunk + t] = jacu_tab_entry(acc);
-    if (step == 264) pt_store(work + i0, acc);
-    if (step == 265) pt_store(work + i1, acc);
+    if (step == STEP_SUM) pt_store(work + i0, acc);
+    if (step == STEP_DIF) pt_store(work + i1, acc);
   }
   if (mode == 1) pt_store(work + i0, acc);
 }
