@@ -315,28 +315,40 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
   JacU2 acc = JacU2::zero();
   if (!base.is_zero()) {
     tabu2_store(tab + t, jacu2_tab_from_affine(base.x, base.y));
-    uint32_t mag[8], sgn[2] = {0, 0};  // signed digits d_j in [-8, 8]: k = sum d_j 16^j
-    uint32_t carry = 0;
+    // The scalar is split by the twist's endomorphism psi (glv.hpp): k P = k1 P + k2 psi(P), k1, k2 < 2^128 -- 33 windows of four
+    // doublings instead of 64; psi of a table entry costs two Fq2 products by constants and five negations.
+    const Glv2Split g = glv2_split(s);
+    uint32_t mag1[5], mag2[5], sgn1[2] = {0, 0}, sgn2[2] = {0, 0};  // signed digits d_j in [-8, 8]: m = sum d_j 16^j
+    auto digits = [](const uint32_t m[5], uint32_t mag[5], uint32_t sgn[2]) {
+      uint32_t carry = 0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      uint32_t m = 0;
+      for (int w = 0; w < 5; ++w) {
+        uint32_t o = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        uint32_t d = ((s[w] >> (4 * q)) & 15u) + carry;
-        carry = d > 8u ? 1u : 0u;
-        if (carry) {
-          d = 16u - d;
-          sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+        for (int q = 0; q < 8; ++q) {
+          uint32_t d = ((m[w] >> (4 * q)) & 15u) + carry;
+          carry = d > 8u ? 1u : 0u;
+          if (carry) {
+            d = 16u - d;
+            sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+          }
+          o |= d << (4 * q);
         }
-        m |= d << (4 * q);
+        mag[w] = o;
       }
-      mag[w] = m;
-    }
+    };
+    digits(g.k1, mag1, sgn1);
+    digits(g.k2, mag2, sgn2);
+    const FqU C266 = UPow2<FqParams, 266>::get();
+    const Fq2 cxs = glv2_cx(), cys = glv2_cy();
+    const Fq2U cxU{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};   // 2^261 domain, < 2p
+    const Fq2U cyU{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
     // table program, one nibble per field (load, double, add, store):  2P = 2*1P, 3P = 2P + 1P, 4P = 2*2P, 5P = 4P + 1P, ...
     constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};
+    constexpr int WINDOWS = 33;
 #pragma unroll 1
-    for (int step = 0; step < 7 + 256; ++step) {
-      uint32_t load = 0, dbl_it = 1, add = 0, store = 0, negate = 0;
+    for (int step = 0; step < 7 + 5 * WINDOWS; ++step) {
+      uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0, psi = 0;
       if (step < 7) {
         const uint32_t pr = PROG[step];
         load = pr >> 12;
@@ -344,12 +356,19 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
         add = (pr >> 4) & 15u;
         store = pr & 15u;
       } else {
-        const int m = step - 7;        // 256 doublings; after the 4th of each window the window's digit is added
+        const int m = step - 7;        // per window: four doublings (the fourth adds the k1 digit), then the k2 digit through psi
         if (m == 0) acc = JacU2::zero();
-        if ((m & 3) == 3) {
-          const int j = 63 - (m >> 2);
-          add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
-          negate = (sgn[j >> 5] >> (j & 31)) & 1u;
+        const int win = m / 5, sub = m - 5 * win, j = WINDOWS - 1 - win;
+        if (sub < 4) {
+          dbl_it = 1;
+          if (sub == 3) {
+            add = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
+            negate = (sgn1[j >> 5] >> (j & 31)) & 1u;
+          }
+        } else {
+          add = (mag2[j >> 3] >> (4 * (j & 7))) & 15u;
+          negate = (sgn2[j >> 5] >> (j & 31)) & 1u;
+          psi = 1;
         }
       }
       if (load) {
@@ -357,7 +376,11 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
         acc = JacU2{e.x, e.y, e.z};
       }
       if (dbl_it) acc = jacu2_double(acc);
-      if (add) jacu2_add_tab(acc, tabu2_load(tab + (uint64_t)(add - 1) * n_chunk + t), negate != 0);
+      if (add) {
+        JacTabU2 e = tabu2_load(tab + (uint64_t)(add - 1) * n_chunk + t);
+        if (psi) e = jacu2_tab_psi(e, cxU, cyU);
+        jacu2_add_tab(acc, e, negate != 0);
+      }
       if (store) tabu2_store(tab + (uint64_t)(store - 1) * n_chunk + t, jacu2_tab_entry(acc));
     }
   }

@@ -691,6 +691,20 @@ ZK_HD void jacu2_add_tab(JacU2& acc, const JacTabU2& t, bool negate) {
   acc.z = z3;
 }
 
+// psi of a table entry (glv.hpp): (cx conj(X), cy conj(Y), conj(Z), conj(Z^2), conj(Z^3)) -- conj negates the u-component.
+// cx, cy: the constants in U-form, 2^261 domain, components < 2p.  Result within the entry invariants
+// (X < 1.2p, Y < 1.1p, Z_1 <= 3p, ZZ_1, ZZZ_1 <= 2p).
+ZK_HD JacTabU2 jacu2_tab_psi(const JacTabU2& e, const Fq2U& cx, const Fq2U& cy) {
+  JacTabU2 t;
+  t.x = f2u_mul<2>(Fq2U{e.x.c0, u_sub<8, 1>(FqU::zero(), e.x.c1)}, cx);    // X < 7p:  (7*2 + 8*2)c + 1 < 1.2p
+  t.y = f2u_mul<2>(Fq2U{e.y.c0, u_sub<4, 1>(FqU::zero(), e.y.c1)}, cy);    // Y <= 3p: (3*2 + 4*2)c + 1 < 1.1p
+  t.z = Fq2U{e.z.c0, u_sub<3, 1>(FqU::zero(), e.z.c1)};                    // Z < 3p
+  t.zz = Fq2U{e.zz.c0, u_sub<2, 1>(FqU::zero(), e.zz.c1)};                 // ZZ, ZZZ < 2p
+  t.zzz = Fq2U{e.zzz.c0, u_sub<2, 1>(FqU::zero(), e.zzz.c1)};
+  t.pad[0] = t.pad[1] = 0;
+  return t;
+}
+
 // raw affine point (memory format, not infinity) -> table entry of 1 * P in the 2^261 domain
 ZK_HD JacTabU2 jacu2_tab_from_affine(const Fq2& x, const Fq2& y) {
   const FqU C = UPow2<FqParams, 266>::get();                 // x*2^256 * 2^266 / 2^261 = x * 2^261

@@ -260,6 +260,30 @@ int mi355zk_selftest_glv_split(const uint32_t k[8], uint32_t out[12]) {
   return ZK_OK;
 }
 
+// the G2 split k = k1 + k2 mu (glv.hpp) on the HOST: out = k1 (5 u32), k2 (5 u32)
+int mi355zk_selftest_glv2_split(const uint32_t k[8], uint32_t out[10]) {
+  if (!k || !out) return ZK_ERR_BAD_ARGS;
+  const zk::Glv2Split g = zk::glv2_split(k);
+  for (int i = 0; i < 5; ++i) { out[i] = g.k1[i]; out[5 + i] = g.k2[i]; }
+  return ZK_OK;
+}
+// psi of an affine G2 point through the table-entry path the kernels use (jacu2_tab_from_affine -> jacu2_tab_psi), Jacobian out
+int mi355zk_selftest_g2_psi(const uint64_t affine_pt[16], uint64_t out_xyz[24]) {
+  if (!affine_pt || !out_xyz) return ZK_ERR_BAD_ARGS;
+  zk::G2Affine p;
+  std::memcpy(&p, affine_pt, sizeof p);
+  const zk::FqU C266 = zk::UPow2<zk::FqParams, 266>::get();
+  const zk::Fq2 cxs = zk::glv2_cx(), cys = zk::glv2_cy();
+  const zk::Fq2U cxU{zk::u_mul(zk::u_from_std(cxs.c0), C266), zk::u_mul(zk::u_from_std(cxs.c1), C266)};
+  const zk::Fq2U cyU{zk::u_mul(zk::u_from_std(cys.c0), C266), zk::u_mul(zk::u_from_std(cys.c1), C266)};
+  const zk::JacTabU2 e = zk::jacu2_tab_psi(zk::jacu2_tab_from_affine(p.x, p.y), cxU, cyU);
+  zk::JacU2 acc = zk::JacU2::zero();
+  zk::jacu2_add_tab(acc, e, false);
+  const zk::G2Jacobian r = zk::jacu2_to_std(acc);
+  std::memcpy(out_xyz, &r, sizeof r);
+  return ZK_OK;
+}
+
 // same for G2 (16 u64 per affine point; out = X, Y, ZZ, ZZZ over Fq2: 32 u64)
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const uint8_t* negate, size_t n, uint64_t out_xyzz[32]) {
   if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;

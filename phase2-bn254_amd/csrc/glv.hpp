@@ -118,6 +118,48 @@ ZK_HD GlvSplit glv_split(const uint32_t k[8]) {
   return s;
 }
 
+// ---- G2: the twist has psi = (untwist) o Frobenius o (twist),  psi(x, y) = (cx conj(x), cy conj(y)),  cx = xi^((q-1)/3),
+// cy = xi^((q-1)/2), xi = 9 + u, which acts on the order-r subgroup as multiplication by  mu = q mod r = 6 x^2 (127 bits; x the BN
+// parameter).  mu^2 ~ r, so the split is a division:  k = k1 + k2 mu,  k2 = floor(k g / 2^256) with g = floor(2^256 / mu) (the true
+// quotient or one less),  k1 = k - k2 mu:  both NON-NEGATIVE and < 2^128 (tests/test_glv_host.py).
+struct Glv2Split {
+  uint32_t k1[5], k2[5];
+};
+ZK_HD Glv2Split glv2_split(const uint32_t k[8]) {
+  using namespace glv_detail;
+  const uint32_t MU[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};
+  const uint32_t G[5] = {0xc8e01941u, 0x2cb62031u, 0xa773d2d5u, 0x4ccef014u, 0x00000002u};
+  uint32_t t13[13], prod[9], kk[9], d[9];
+  mul_limbs<8, 5>(k, G, t13);
+  Glv2Split s;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s.k2[i] = t13[8 + i];
+  mul_limbs<5, 4>(s.k2, MU, prod);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) kk[i] = i < 8 ? k[i] : 0u;
+  (void)sub_abs<9>(kk, prod, d);   // never negative: k2 <= floor(k / mu)
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s.k1[i] = d[i];
+  return s;
+}
+// the constants of psi in the memory format (c * 2^256 mod q, per Fq2 component)
+ZK_HD Fq2 glv2_cx() {
+  const uint32_t a[8] = {0x4563ab30u, 0xb5773b10u, 0xa9aa6454u, 0x347f91c8u, 0x242e0991u, 0x7a007127u, 0x118214ecu, 0x1956bcd8u};
+  const uint32_t b[8] = {0xa0aa4757u, 0x6e849f1eu, 0x89f89141u, 0xaa1c7b6du, 0xfae0ca3au, 0xb6e713cdu, 0x4e82ebc3u, 0x26694fbbu};
+  Fq2 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { r.c0.l[i] = a[i]; r.c1.l[i] = b[i]; }
+  return r;
+}
+ZK_HD Fq2 glv2_cy() {
+  const uint32_t a[8] = {0x2936b629u, 0xe4bbdd0cu, 0xe133bacbu, 0xbb30f162u, 0xf9645366u, 0x31a9d1b6u, 0xa500f8ddu, 0x253570beu};
+  const uint32_t b[8] = {0x5ffe77c7u, 0xa1d77ce4u, 0x7826d1dbu, 0x07affd11u, 0xbb7edc6bu, 0x6d16bd27u, 0x85defeccu, 0x2c872002u};
+  Fq2 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { r.c0.l[i] = a[i]; r.c1.l[i] = b[i]; }
+  return r;
+}
+
 // non-adjacent form of a magnitude m < 2^159 (5 limbs): digit j = bit_{j+1}(3m) - bit_{j+1}(m);  pos / neg: 5 limbs + 1 bit (6 words)
 ZK_HD void glv_naf(const uint32_t m[5], uint32_t pos[6], uint32_t neg[6]) {
   uint32_t m3[7], mm[7];

@@ -14,6 +14,7 @@
 
 #include "../../include/mi355zk.h"
 #include "curveu.hpp"
+#include "glv.hpp"
 #include "device_util.hpp"
 
 namespace zk {
@@ -66,8 +67,8 @@ __global__ void __launch_bounds__(256) pfft2_load_kernel(const G2Affine* __restr
 }
 
 // The program of point_fft.hip's pfft_stage_kernel, on U-form Jacobian points:
-//   steps 0..6 table (2t .. 8t), steps 7..262 the 256 doublings with a digit addition after every 4th,
-//   step 263 entry 1 := product, steps 264 / 265: a[i0] = u + product, a[i1] = u - product   (mode 0, domain.rs:303-309)
+//   steps 0..6 table (2t .. 8t), steps 7..171 the 33 windows of the split twiddle (four doublings, the k1 digit, the k2 digit through psi),
+//   step 172 entry 1 := product, steps 173 / 174: a[i0] = u + product, a[i1] = u - product   (mode 0, domain.rs:303-309)
 //   mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173)
 __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
                                                          uint32_t s, uint64_t b0, uint64_t n_chunk, JacTabU2* __restrict__ tab, int mode, Fr c) {
@@ -92,65 +93,85 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
   }
   const JacU2 u = mode == 0 ? v_load(work + i0).p : JacU2::zero();
   JacU2 acc = v_load(work + i1).p;
-  // signed 4-bit digits: k = sum d_j 16^j, d_j in [-8, 8]
-  uint32_t mag[8], sgn[2] = {0, 0};
-  uint32_t carry = 0;
+  // the twiddle split by the twist's endomorphism (glv.hpp): w t = k1 t + k2 psi(t), k1, k2 < 2^128; signed 4-bit digits of both
+  const Glv2Split g = glv2_split(kk);
+  uint32_t mag1[5], mag2[5], sgn1[2] = {0, 0}, sgn2[2] = {0, 0};
+  auto digits = [](const uint32_t m[5], uint32_t mag[5], uint32_t sgn[2]) {
+    uint32_t carry = 0;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    uint32_t m = 0;
+    for (int w = 0; w < 5; ++w) {
+      uint32_t o = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      uint32_t d = ((kk[w] >> (4 * q)) & 15u) + carry;
-      carry = d > 8u ? 1u : 0u;
-      if (carry) {
-        d = 16u - d;
-        sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+      for (int q = 0; q < 8; ++q) {
+        uint32_t d = ((m[w] >> (4 * q)) & 15u) + carry;
+        carry = d > 8u ? 1u : 0u;
+        if (carry) {
+          d = 16u - d;
+          sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+        }
+        o |= d << (4 * q);
       }
-      m |= d << (4 * q);
+      mag[w] = o;
     }
-    mag[w] = m;
-  }
+  };
+  digits(g.k1, mag1, sgn1);
+  digits(g.k2, mag2, sgn2);
+  const FqU C266 = UPow2<FqParams, 266>::get();
+  const Fq2 cxs = glv2_cx(), cys = glv2_cy();
+  const Fq2U cxU{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};   // 2^261 domain, < 2p
+  const Fq2U cyU{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
   const bool t_inf = acc.is_zero();
   if (t_inf && mode == 1) return;
   if (!t_inf) v_store(tab + t, jacu2_tab_entry(acc));
   constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};  // nibbles: load, double, add, store
-  const int first = (unit || t_inf) ? 264 : 0;   // twiddle one, or t = infinity: the product is t itself (entry 1 already holds it)
-  const int last = mode == 0 ? 265 : 262;
+  constexpr int MAIN0 = 7, WINDOWS = 33, STEP_STORE = MAIN0 + 5 * WINDOWS, STEP_SUM = STEP_STORE + 1, STEP_DIF = STEP_STORE + 2;
+  const int first = (unit || t_inf) ? STEP_SUM : 0;   // twiddle one, or t = infinity: the product is t itself (entry 1 already holds it)
+  const int last = mode == 0 ? STEP_DIF : STEP_STORE - 1;
 #pragma unroll 1
   for (int step = first; step <= last; ++step) {
-    uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0;
-    if (step < 7) {
+    uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0, psi = 0;
+    if (step < MAIN0) {
       const uint32_t pr = PROG[step];
       load = pr >> 12;
       dbl_it = (pr >> 8) & 15u;
       add = (pr >> 4) & 15u;
       store = pr & 15u;
-    } else if (step < 263) {
-      const int m = step - 7;
+    } else if (step < STEP_STORE) {
+      const int m = step - MAIN0;   // per window: four doublings (the fourth adds the k1 digit), then the k2 digit through psi
       if (m == 0) acc = JacU2::zero();
-      dbl_it = 1;
-      if ((m & 3) == 3) {
-        const int j = 63 - (m >> 2);
-        add = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
-        negate = (sgn[j >> 5] >> (j & 31)) & 1u;
+      const int win = m / 5, sub = m - 5 * win, j = WINDOWS - 1 - win;
+      if (sub < 4) {
+        dbl_it = 1;
+        if (sub == 3) {
+          add = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
+          negate = (sgn1[j >> 5] >> (j & 31)) & 1u;
+        }
+      } else {
+        add = (mag2[j >> 3] >> (4 * (j & 7))) & 15u;
+        negate = (sgn2[j >> 5] >> (j & 31)) & 1u;
+        psi = 1;
       }
-    } else if (step == 263) {
+    } else if (step == STEP_STORE) {
       store = acc.is_zero() ? 0u : 1u;   // (an infinite product: nothing to add below)
       if (!store) { v_store(work + i0, j2_of(u)); v_store(work + i1, j2_of(u)); break; }
     } else {
       acc = u;
       add = t_inf ? 0u : 1u;             // u +- infinity = u
-      negate = step == 265;
+      negate = step == STEP_DIF;
     }
     if (load) {
       const JacTabU2 e = v_load(tab + (uint64_t)(load - 1) * n_chunk + t);
       acc = JacU2{e.x, e.y, e.z};
     }
     if (dbl_it) acc = jacu2_double(acc);
-    if (add) jacu2_add_tab(acc, v_load(tab + (uint64_t)(add - 1) * n_chunk + t), negate != 0);
+    if (add) {
+      JacTabU2 e = v_load(tab + (uint64_t)(add - 1) * n_chunk + t);
+      if (psi) e = jacu2_tab_psi(e, cxU, cyU);
+      jacu2_add_tab(acc, e, negate != 0);
+    }
     if (store) v_store(tab + (uint64_t)(store - 1) * n_chunk + t, jacu2_tab_entry(acc));
-    if (step == 264) v_store(work + i0, j2_of(acc));
-    if (step == 265) v_store(work + i1, j2_of(acc));
+    if (step == STEP_SUM) v_store(work + i0, j2_of(acc));
+    if (step == STEP_DIF) v_store(work + i1, j2_of(acc));
   }
   if (mode == 1) v_store(work + i0, j2_of(acc));
 }

@@ -37,3 +37,33 @@ def test_glv_split_identity_and_size():
         if out[11]:
             k2 = -k2
         assert (k1 + k2 * LAMBDA - k) % R == 0, hex(k)
+
+
+MU = 0x6F4D8248EEB859FBF83E9682E87CFD46
+
+
+def test_g2_split_and_psi():
+    """G2: k = k1 + k2 mu with both halves non-negative and < 2^128, and psi(P) -- through the table-entry path of the kernels --
+    equals mu * P (oracle group law) on random points of the order-r subgroup."""
+    import inputs
+    import oracle_lib as O
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    assert MU == M.Q % M.R_ORDER
+    rnd = random.Random(6)
+    R = M.R_ORDER
+    for k in [0, 1, MU - 1, MU, MU + 1, R - 1, (1 << 253), MU * MU % R] + [rnd.randrange(R) for _ in range(3000)]:
+        sc = np.array([(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+        out = np.zeros(10, np.uint32)
+        assert lib.mi355zk_selftest_glv2_split(sc.ctypes.data, out.ctypes.data) == 0
+        k1 = sum(int(out[i]) << (32 * i) for i in range(5))
+        k2 = sum(int(out[5 + i]) << (32 * i) for i in range(5))
+        assert k1 < (1 << 128) and k2 < (1 << 128) and k1 + k2 * MU == k, hex(k)
+    pts = inputs.bases_cpu(2, 6, seed=41)
+    mu_limbs = np.array(M.to_limbs(MU), dtype=np.uint64)
+    for p in pts:
+        out = np.zeros(24, np.uint64)
+        assert lib.mi355zk_selftest_g2_psi(np.ascontiguousarray(p).ctypes.data, out.ctypes.data) == 0
+        want = O.G2.to_affine(O.G2.mul(O.G2.from_affine(p), mu_limbs))
+        assert np.array_equal(O.G2.to_affine(out), want)
