@@ -275,6 +275,43 @@ def test_batch_exp_matches_oracle(zk, worker, group, same_scalar):
         assert np.array_equal(got[i], want), i
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group):
+    """The per-point scalar multiplications split the scalar by the curve's endomorphism (glv.hpp: k = k1 + k2 lambda on G1,
+    k = k1 + k2 mu on G2).  Scalars on and around the eigenvalue and its multiples, around 2^128, and with one half of the split
+    equal to zero, per point and as the one shared scalar, against the oracle's plain double-and-add."""
+    import torch
+
+    import bn254_model as M
+
+    G = O.G1 if group == 1 else O.G2
+    R = M.R_ORDER
+    ev = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD if group == 1 else M.Q % R
+    vals = [ev, ev + 1, ev - 1, R - ev, 2 * ev % R, 3 * ev % R, (ev * ev) % R, (ev * ev + 1) % R, (1 << 128) - 1, 1 << 128, (1 << 128) + 1,
+            (1 << 127), (ev << 64) % R, 7, 8, 9, 15, 16, 17, R - 2, (R - 1) // 2, (R + 1) // 2, 0x8888888888888888888888888888888888888888 % R,
+            0x0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F % R]
+    n = len(vals)
+    bases = inputs.bases_progression_cpu(group, n, seed=190 + group)
+    ks = np.array([M.to_limbs(v) for v in vals], dtype=np.uint64)
+    fn = zk.lib.load().mi355zk_bn254_g1_batch_exp_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_batch_exp_dev
+    d_b = torch.from_numpy(bases.view(np.int64)).cuda()
+    d_o = torch.empty_like(d_b)
+    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+    assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(d_k.data_ptr()), n, 0, None) == 0
+    torch.cuda.synchronize()
+    got = d_o.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), ks[i]))), hex(vals[i])
+    for v in vals[:8]:                                                   # the same values as the ONE scalar of a phase2-style call
+        one = torch.from_numpy(np.array([M.to_limbs(v)], dtype=np.uint64).view(np.int64)).cuda()
+        assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(one.data_ptr()), n, 1, None) == 0
+        torch.cuda.synchronize()
+        got = d_o.cpu().numpy().view(np.uint64)
+        k = np.array(M.to_limbs(v), dtype=np.uint64)
+        for i in range(0, n, 5):
+            assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), k))), hex(v)
+
+
 def test_concurrent_calls_from_several_host_threads(zk, worker):
     """The prover queues 8 multiexps before the first wait() (prover.rs:250-298): the entry points must be
     re-entrant.  4 host threads run G1 / G2 multiexps and domain ops at the same time; every result is checked."""
