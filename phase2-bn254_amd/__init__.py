@@ -12,7 +12,7 @@ Layout:
 The directory name carries a hyphen (it is the reference's name); import it through the
 repo-root shim module `phase2_bn254_amd`.
 """
-from . import bellman, ceremony, lib, prover, shard  # noqa: F401
+from . import bellman, ceremony, circom, lib, prover, shard  # noqa: F401
 from .bellman import (  # noqa: F401
     DensityTracker,
     EvaluationDomain,

@@ -28,6 +28,7 @@ class SynthesisError(Exception):
     UNEXPECTED_IDENTITY = "UnexpectedIdentity"          # source.rs:50-52
     IO_UNEXPECTED_EOF = "IoError(UnexpectedEof)"        # source.rs:46-48,62-64
     POLYNOMIAL_DEGREE_TOO_LARGE = "PolynomialDegreeTooLarge"  # domain.rs:66-79
+    UNCONSTRAINED_VARIABLE = "UnconstrainedVariable"    # phase2/src/parameters.rs:340-346 (MPCParameters::new)
 
     def __init__(self, kind: str, index: int = -1):
         super().__init__(kind if index < 0 else f"{kind} at exponent {index}")

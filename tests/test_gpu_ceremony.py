@@ -163,6 +163,64 @@ def test_prepare_phase2_flow_closed_form(zk, worker):
     assert all(torch.equal(back[k], params[k]) for k in params)
 
 
+def test_mpc_parameters_new_from_a_circom_circuit(zk, worker):
+    """MPCParameters::new (phase2/src/parameters.rs:99-400) end to end: circom circuit.json -> KeypairAssembly -> the QAP sums over
+    the Lagrange bases of a phase1radix2m file -> Groth16 parameters, cs_hash, container round trip.  The radix file comes from a
+    power-3 accumulator with KNOWN tau, alpha, beta, so every element has a closed form in the scalar field:
+        a[v] = A_v(tau) G,  b_g1[v] = B_v(tau) G,  b_g2[v] = B_v(tau) G2,  ic / l [v] = (beta A_v + alpha B_v + C_v)(tau) G,
+    with A_v = sum of coeff * L_j over the variable's terms, L_j(tau) = (tau^m - 1) w^j / (m (tau - w^j))."""
+    import hashlib
+
+    import torch
+
+    r = M.R_ORDER
+    circuit_json = {   # x1 * x2 = x3;  (x3 + 5) * 1 = out;   0 = ONE, 1 = out, 2 = x1 (public), 3 = x2, 4 = x3
+        "constraints": [[{"2": "1"}, {"3": "1"}, {"4": "1"}], [{"4": "1", "0": "5"}, {"0": "1"}, {"1": str(r - 1), "0": "0"}]],
+        "nPubInputs": 1, "nOutputs": 1, "nVars": 5}
+    circuit = zk.circom.circuit_from_json(circuit_json)
+    cs = zk.circom.assemble(circuit)
+    power = zk.circom.domain_exponent(cs.num_constraints)
+    assert (cs.num_inputs, cs.num_aux, cs.num_constraints, power) == (3, 2, 5, 3)
+    m = 1 << power
+    tau, alpha, beta = 0x1234567 % r, 0x89ABCDEF01 % r, 0x55AA55AA55 % r
+    mul1 = lambda ks: O.G1.mul_many_affine(inputs.G1_GEN_RAW, np.stack([_limbs(k % r) for k in ks]))  # noqa: E731
+    mul2 = lambda ks: O.G2.mul_many_affine(inputs.G2_GEN_RAW, np.stack([_limbs(k % r) for k in ks]))  # noqa: E731
+    tp = [pow(tau, i, r) for i in range(2 * m - 1)]
+    acc = {"hash": torch.zeros(64, dtype=torch.uint8).cuda(), "tau_g1": _dev(mul1(tp)), "tau_g2": _dev(mul2(tp[:m])),
+           "alpha_g1": _dev(mul1([alpha * t for t in tp[:m]])), "beta_g1": _dev(mul1([beta * t for t in tp[:m]])), "beta_g2": _dev(mul2([beta]))}
+    radix = zk.ceremony.read_phase1radix2m(zk.ceremony.write_phase1radix2m(zk.ceremony.prepare_phase2(acc, m)), m)
+
+    mpc = zk.circom.mpc_parameters_new(circuit, False, radix)
+    w = M.domain_omega(power)
+    lag = [(pow(tau, m, r) - 1) * pow(w, j, r) % r * pow(m * (tau - pow(w, j, r)) % r, -1, r) % r for j in range(m)]
+    ev = lambda rows: [sum(c * lag[j] for c, j in row) % r for row in rows]  # noqa: E731
+    A, B, Cc = ev(cs.at_inputs + cs.at_aux), ev(cs.bt_inputs + cs.bt_aux), ev(cs.ct_inputs + cs.ct_aux)
+    P = mpc["params"]
+    assert np.array_equal(_host(P["a"]), mul1(A)) and np.array_equal(_host(P["b_g1"]), mul1(B)) and np.array_equal(_host(P["b_g2"]), mul2(B))
+    ext = [(beta * a + alpha * b + c) % r for a, b, c in zip(A, B, Cc)]
+    assert np.array_equal(_host(P["vk"]["ic"]), mul1(ext[:3])) and np.array_equal(_host(P["l"]), mul1(ext[3:]))
+    assert np.array_equal(_host(P["h"]), mul1([(pow(tau, m, r) - 1) * tp[i] for i in range(m - 1)]))
+    assert np.array_equal(_host(P["vk"]["alpha_g1"]), mul1([alpha])) and np.array_equal(_host(P["vk"]["beta_g2"]), mul2([beta]))
+    assert np.array_equal(_host(P["vk"]["delta_g1"])[0], inputs.G1_GEN_RAW) and np.array_equal(_host(P["vk"]["gamma_g2"])[0], inputs.G2_GEN_RAW)
+    assert A[3] == 0 and all(A[i] for i in (0, 1, 2, 4)) and [bool(v) for v in B] == [True, False, False, True, False]   # x2 has no A term (every input has its x * 0 = 0): infinity in the unfiltered queries
+    blob = zk.ceremony.write_parameters(P)
+    assert bytes(mpc["cs_hash"].cpu().numpy()) == hashlib.blake2b(bytes(blob.cpu().numpy()), digest_size=64).digest()
+    back = zk.ceremony.read_mpc_parameters(zk.ceremony.write_mpc_parameters(mpc), disallow_points_at_infinity=False)
+    assert torch.equal(back["cs_hash"], mpc["cs_hash"]) and back["contributions"] == []
+    assert all(torch.equal(back["params"][k], P[k]) for k in ("h", "l", "a", "b_g1", "b_g2")) and torch.equal(back["params"]["vk"]["ic"], P["vk"]["ic"])
+
+    filtered = zk.circom.mpc_parameters_new(circuit, True, radix)["params"]  # should_filter_points_at_infinity
+    keep_a = [i for i, v in enumerate(A) if v]
+    keep_b = [i for i, v in enumerate(B) if v]
+    assert len(keep_a) < len(A) and np.array_equal(_host(filtered["a"]), mul1([A[i] for i in keep_a]))
+    assert np.array_equal(_host(filtered["b_g1"]), mul1([B[i] for i in keep_b])) and np.array_equal(_host(filtered["b_g2"]), mul2([B[i] for i in keep_b]))
+    assert torch.equal(filtered["l"], P["l"])
+    # an auxiliary variable no constraint mentions: the L query would not be fully dense
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.circom.mpc_parameters_new(zk.circom.circuit_from_json(dict(circuit_json, nVars=6)), False, radix)
+    assert e.value.kind == zk.SynthesisError.UNCONSTRAINED_VARIABLE
+
+
 def test_contribute_accumulator_like_compute_constrained(zk, worker):
     """BASELINE config 1's compute step on the device (batched_accumulator.rs:1119-1292): the blank accumulator of
     `new_constrained` (every element a generator, :1295-1347) contributed with a known key has tau_g1[i] = tau^i G,
