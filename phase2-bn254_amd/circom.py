@@ -190,3 +190,77 @@ def mpc_parameters_new(circuit: CircomCircuit, should_filter_points_at_infinity:
     digest = ceremony.calculate_hash(ceremony.write_parameters(params))     # HashWriter over Parameters::write (parameters.rs:382-392)
     cs_hash = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(dev)
     return {"params": params, "cs_hash": cs_hash, "contributions": []}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# proving a circom circuit (circom_circuit.rs:187-191 `prove` = filter_params + create_random_proof; bellman's prepare_prover,
+# groth16/prover.rs:49-200)
+def prepare_prover(circuit: CircomCircuit, device):
+    """prepare_prover (groth16/prover.rs:153-187): the ONE input, the circuit, one `x * 0 = 0` constraint per input, with the
+    witness: per constraint the values of its A, B and C combinations, the assignments, and the three density maps (a variable
+    counts as dense in a query as soon as it OCCURS in a combination, whatever its coefficient: prover.rs:49-88).  Returns the
+    prover.ProvingAssignment (Montgomery Fr on the device, like Vec<Scalar<E>> / Vec<E::Fr>)."""
+    import torch
+
+    from . import prover as _prover
+    from .bellman import DensityTracker
+
+    if circuit.witness is None:
+        raise SynthesisError("AssignmentMissing")
+    w = circuit.witness
+    if len(w) != circuit.num_inputs + circuit.num_aux:
+        raise ValueError("the witness does not have one value per variable")
+    num_inputs, num_aux = circuit.num_inputs, circuit.num_aux
+    a_aux, b_in, b_aux = np.zeros(num_aux, dtype=bool), np.zeros(num_inputs, dtype=bool), np.zeros(num_aux, dtype=bool)
+    a, b, c = [], [], []
+    for ca, cb, cc in circuit.constraints:
+        acc = 0
+        for idx, coeff in ca:
+            acc += coeff * w[idx]
+            if idx >= num_inputs:
+                a_aux[idx - num_inputs] = True
+        a.append(acc % _R_ORDER)
+        acc = 0
+        for idx, coeff in cb:
+            acc += coeff * w[idx]
+            if idx >= num_inputs:
+                b_aux[idx - num_inputs] = True
+            else:
+                b_in[idx] = True
+        b.append(acc % _R_ORDER)
+        c.append(sum(coeff * w[idx] for idx, coeff in cc) % _R_ORDER)
+    for i in range(num_inputs):                      # x_i * 0 = 0
+        a.append(w[i] % _R_ORDER)
+        b.append(0)
+        c.append(0)
+
+    mont_r = (1 << 256) % _R_ORDER
+    mask = (1 << 64) - 1
+
+    def mont(vals):
+        arr = np.empty((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            v = v % _R_ORDER * mont_r % _R_ORDER
+            arr[i, 0], arr[i, 1], arr[i, 2], arr[i, 3] = v & mask, (v >> 64) & mask, (v >> 128) & mask, v >> 192
+        return torch.from_numpy(arr.view(np.int64)).to(device)
+
+    return _prover.ProvingAssignment(mont(a), mont(b), mont(c), mont(w[:num_inputs]), mont(w[num_inputs:]), DensityTracker.from_bools(a_aux),
+                                     DensityTracker.from_bools(b_in), DensityTracker.from_bools(b_aux))
+
+
+def filter_params(params):
+    """filter_params (circom_circuit.rs: the A / B queries without their points at infinity -- what the density maps index)"""
+    keep = lambda pts: pts[~(pts == 0).all(dim=1)].contiguous()  # noqa: E731
+    return dict(params, a=keep(params["a"]), b_g1=keep(params["b_g1"]), b_g2=keep(params["b_g2"]))
+
+
+def prove(pool, circuit: CircomCircuit, params, r: int, s: int):
+    """prove (circom_circuit.rs:187-191) with the blinding scalars given (create_random_proof draws them from the RNG):
+    returns the proof (a, b, c) as raw affine records.  params: the "params" dict of mpc_parameters_new / read_mpc_parameters."""
+    from . import prover as _prover
+
+    p = filter_params(params)
+    host = lambda t: t.cpu().numpy().view(np.uint64).reshape(-1)  # noqa: E731
+    vk = {k: host(p["vk"][k]) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2")}
+    assignment = prepare_prover(circuit, p["h"].device)
+    return _prover.create_proof(pool, _prover.Parameters(vk, p["h"], p["l"], p["a"], p["b_g1"], p["b_g2"]), assignment, r, s)

@@ -209,6 +209,21 @@ def test_mpc_parameters_new_from_a_circom_circuit(zk, worker):
     assert torch.equal(back["cs_hash"], mpc["cs_hash"]) and back["contributions"] == []
     assert all(torch.equal(back["params"][k], P[k]) for k in ("h", "l", "a", "b_g1", "b_g2")) and torch.equal(back["params"]["vk"]["ic"], P["vk"]["ic"])
 
+    # ---- prove (circom_circuit.rs:187-191) on these parameters with a witness: delta = gamma = 1 and tau, alpha, beta are known, so the
+    # proof has closed-form discrete logarithms:  A = alpha + A(tau) + r,  B = beta + B(tau) + s,
+    # C = L_aux + (A(tau) B(tau) - C(tau)) + s A + r B - r s   (the H query contributes h(tau) t(tau) = A B - C)
+    x1, x2 = 3, 4
+    wit = [1, (-(x1 * x2 + 5)) % r, x1, x2, x1 * x2]                      # ONE, out, x1, x2, x3  (the circuit's C combination is -out)
+    circuit.witness = zk.circom.witness_from_json([str(v) for v in wit])
+    rr, ss = 0x1234567890ABCDEF1122334455667788 % r, 0x0FEDCBA9876543210F1E2D3C4B5A6978 % r
+    pa, pb, pc = zk.circom.prove(worker, circuit, P, rr, ss)
+    At, Bt, Ct = (sum(wv * v for wv, v in zip(wit, X)) % r for X in (A, B, Cc))
+    log_a, log_b = (alpha + At + rr) % r, (beta + Bt + ss) % r
+    log_c = (sum(wv * e for wv, e in zip(wit[3:], ext[3:])) + At * Bt - Ct + ss * log_a + rr * log_b - rr * ss) % r
+    assert np.array_equal(pa, mul1([log_a])[0]) and np.array_equal(pb, mul2([log_b])[0]) and np.array_equal(pc, mul1([log_c])[0])
+    # Groth16's check in the exponent (gamma = delta = 1):  A B = alpha beta + IC(public inputs) + C
+    assert (log_a * log_b - alpha * beta - sum(wv * e for wv, e in zip(wit[:3], ext[:3])) - log_c) % r == 0
+
     filtered = zk.circom.mpc_parameters_new(circuit, True, radix)["params"]  # should_filter_points_at_infinity
     keep_a = [i for i, v in enumerate(A) if v]
     keep_b = [i for i, v in enumerate(B) if v]
