@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
       const FqU y2 = u_mul(u_from_std(base.y), C);
       const FqU xb = u_mul(x2, u_mul(u_from_std(glv_beta()), C));   // beta x, 2^261 domain, < 2p
       bool found = false;
-      for (int bit = 129; bit >= 0; --bit) {
+      for (int bit = 160; bit >= 0; --bit) {   // (canonical scalars end at bit 128; the leading zeros cost nothing: nothing is doubled before the first digit)
         const bool a1 = (p1[bit >> 5] >> (bit & 31)) & 1, m1 = (n1[bit >> 5] >> (bit & 31)) & 1;
         const bool a2 = (p2[bit >> 5] >> (bit & 31)) & 1, m2 = (n2[bit >> 5] >> (bit & 31)) & 1;
         if (found) acc = jacu_double(acc);
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
     digits(g.k2, mag2, sgn2);
     const FqU betaU = u_mul(u_from_std(glv_beta()), C);     // beta, 2^261 domain
 #pragma unroll 1
-    for (int j = 32; j >= 0; --j) {
+    for (int j = 39; j >= 0; --j) {   // all 40 nibbles of the five limbs: canonical scalars use 33, and doubling infinity returns at once
 #pragma unroll 1
       for (int rep = 0; rep < 4; ++rep) acc = jacu_double(acc);
       const uint32_t d1 = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
     const Fq2U cyU{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
     // table program, one nibble per field (load, double, add, store):  2P = 2*1P, 3P = 2P + 1P, 4P = 2*2P, 5P = 4P + 1P, ...
     constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};
-    constexpr int WINDOWS = 33;
+    constexpr int WINDOWS = 40;   // all nibbles of the five limbs (canonical scalars use 33; doubling infinity returns at once)
 #pragma unroll 1
     for (int step = 0; step < 7 + 5 * WINDOWS; ++step) {
       uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0, psi = 0;

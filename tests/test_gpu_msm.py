@@ -289,7 +289,8 @@ def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group
     ev = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD if group == 1 else M.Q % R
     vals = [ev, ev + 1, ev - 1, R - ev, 2 * ev % R, 3 * ev % R, (ev * ev) % R, (ev * ev + 1) % R, (1 << 128) - 1, 1 << 128, (1 << 128) + 1,
             (1 << 127), (ev << 64) % R, 7, 8, 9, 15, 16, 17, R - 2, (R - 1) // 2, (R + 1) // 2, 0x8888888888888888888888888888888888888888 % R,
-            0x0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F % R]
+            0x0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F % R,
+            R, R + 1, (1 << 256) - 1, (1 << 255) + 12345]                  # not canonical: still k * P (the split is exact for any 256-bit k)
     n = len(vals)
     bases = inputs.bases_progression_cpu(group, n, seed=190 + group)
     ks = np.array([M.to_limbs(v) for v in vals], dtype=np.uint64)
@@ -301,7 +302,7 @@ def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group
     torch.cuda.synchronize()
     got = d_o.cpu().numpy().view(np.uint64)
     for i in range(n):
-        assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), ks[i]))), hex(vals[i])
+        assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), np.array(M.to_limbs(vals[i] % R), dtype=np.uint64)))), hex(vals[i])
     for v in vals[:8]:                                                   # the same values as the ONE scalar of a phase2-style call
         one = torch.from_numpy(np.array([M.to_limbs(v)], dtype=np.uint64).view(np.int64)).cuda()
         assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(one.data_ptr()), n, 1, None) == 0
