@@ -221,6 +221,10 @@ class EvaluationDomain:
                 coeffs = np.concatenate([np.asarray(coeffs, dtype=np.uint64), np.zeros((m - n, 4), dtype=np.uint64)])
         elif not _is_torch(coeffs):
             coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).copy()
+        else:
+            # `from_coeffs` takes the Vec by value (domain.rs:52): the domain owns its coefficients and the transforms work in
+            # place, so the caller's tensor is copied -- a ProvingAssignment can then be proved twice
+            coeffs = coeffs.contiguous().clone()
         return cls(coeffs, exp)
 
     def as_ref(self):
@@ -260,6 +264,14 @@ class EvaluationDomain:
             raise ValueError("device-resident coefficients (a torch CUDA tensor) required")
         return C.c_void_p(self.coeffs.data_ptr())
 
+    def _on_device(self):
+        """context manager: the coefficients' GPU is current (kernels and `_stream_ptr()` then refer to ITS stream, not to the
+        stream of whatever device the caller last selected)"""
+        import torch
+
+        self._dev_coeffs()
+        return torch.cuda.device(self.coeffs.device)
+
     def z(self, tau):
         """domain.rs:207-212: tau^m - 1 (tau, result: 4 u64 Montgomery limbs)."""
         tau = np.ascontiguousarray(tau, dtype=np.uint64)
@@ -270,19 +282,24 @@ class EvaluationDomain:
         return out
 
     def divide_by_z_on_coset(self, worker: Worker):  # domain.rs:217-234
-        rc = _lib.load().mi355zk_bn254_fr_divide_by_z_on_coset_dev(self._dev_coeffs(), self.exp, _stream_ptr())
+        with self._on_device():
+            rc = _lib.load().mi355zk_bn254_fr_divide_by_z_on_coset_dev(self._dev_coeffs(), self.exp, _stream_ptr())
         if rc != 0:
             raise DeviceError(f"mi355zk divide_by_z_on_coset failed rc={rc}")
 
     def mul_assign(self, worker: Worker, other: "EvaluationDomain"):  # domain.rs:236-249
         assert self.coeffs.shape[0] == other.coeffs.shape[0]
-        rc = _lib.load().mi355zk_bn254_fr_mul_assign_dev(self._dev_coeffs(), other._dev_coeffs(), self.coeffs.shape[0], _stream_ptr())
+        assert other.coeffs.device == self.coeffs.device
+        with self._on_device():
+            rc = _lib.load().mi355zk_bn254_fr_mul_assign_dev(self._dev_coeffs(), other._dev_coeffs(), self.coeffs.shape[0], _stream_ptr())
         if rc != 0:
             raise DeviceError(f"mi355zk mul_assign failed rc={rc}")
 
     def sub_assign(self, worker: Worker, other: "EvaluationDomain"):  # domain.rs:251-260
         assert self.coeffs.shape[0] == other.coeffs.shape[0]
-        rc = _lib.load().mi355zk_bn254_fr_sub_assign_dev(self._dev_coeffs(), other._dev_coeffs(), self.coeffs.shape[0], _stream_ptr())
+        assert other.coeffs.device == self.coeffs.device
+        with self._on_device():
+            rc = _lib.load().mi355zk_bn254_fr_sub_assign_dev(self._dev_coeffs(), other._dev_coeffs(), self.coeffs.shape[0], _stream_ptr())
         if rc != 0:
             raise DeviceError(f"mi355zk sub_assign failed rc={rc}")
 

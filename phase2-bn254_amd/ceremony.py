@@ -406,27 +406,38 @@ def eval_qap_polynomials(radix, at, bt, ct):
 #   transcript[64].
 # Offsets and the length words are host work; every point goes through the codec kernels.
 def _be32(data, off: int) -> int:
+    if off < 0 or off + 4 > data.numel():
+        raise ValueError("parameter file too short in a length word")      # read_u32: io::ErrorKind::UnexpectedEof
     return int.from_bytes(bytes(data[off:off + 4].cpu().numpy()), "big")
 
 
 class _Reader:
+    """Cursor over a parameter file.  Every read checks the remaining length first: slicing a tensor past its end returns
+    FEWER bytes without complaint (and int.from_bytes(b"") is 0), whereas the reference's read_u32 / read_exact fail with
+    UnexpectedEof on a truncated file (groth16/mod.rs:296-383, phase2/src/parameters.rs:683-706)."""
+
     def __init__(self, data):
         self.data, self.off = data, 0
 
+    def _need(self, n: int, what: str):
+        if n < 0 or self.off + n > self.data.numel():
+            raise ValueError(f"parameter file too short in {what}")        # io::ErrorKind::UnexpectedEof
+
     def points(self, n: int, group: int, checked: bool, no_infinity: bool, what: str):
         sz = _ENC_SIZE[(group, False)]
-        if self.data.numel() < self.off + n * sz:
-            raise ValueError(f"parameter file too short in {what}")        # io::ErrorKind::UnexpectedEof
+        self._need(n * sz, what)
         pts = decode_points(self.data[self.off:self.off + n * sz].view(n, sz), group, False, checked)
         self.off += n * sz
         return _no_infinity(pts, what) if no_infinity else pts
 
-    def u32(self) -> int:
+    def u32(self, what: str = "a length word") -> int:
+        self._need(4, what)
         v = _be32(self.data, self.off)
         self.off += 4
         return v
 
-    def raw(self, n: int):
+    def raw(self, n: int, what: str = "a hash"):
+        self._need(n, what)
         out = self.data[self.off:self.off + n].clone()
         self.off += n
         return out
@@ -440,10 +451,10 @@ def read_parameters(data, disallow_points_at_infinity: bool = True, checked: boo
     vk = {}
     for name, g in (("alpha_g1", 1), ("beta_g1", 1), ("beta_g2", 2), ("gamma_g2", 2), ("delta_g1", 1), ("delta_g2", 2)):
         vk[name] = rd.points(1, g, True, False, name)
-    vk["ic"] = rd.points(rd.u32(), 1, True, True, "ic")
+    vk["ic"] = rd.points(rd.u32("the length of ic"), 1, True, True, "ic")
     out = {"vk": vk}
     for name, g in (("h", 1), ("l", 1), ("a", 1), ("b_g1", 1), ("b_g2", 2)):
-        out[name] = rd.points(rd.u32(), g, checked, disallow_points_at_infinity, name)
+        out[name] = rd.points(rd.u32(f"the length of {name}"), g, checked, disallow_points_at_infinity, name)
     return out
 
 
@@ -467,12 +478,12 @@ def read_mpc_parameters(data, disallow_points_at_infinity: bool = True, checked:
     (every public-key point checked and never the point at infinity, keypair.rs:64-120)."""
     rd = _Reader(data)
     out = {"params": read_parameters(data, disallow_points_at_infinity, checked, _reader=rd)}
-    out["cs_hash"] = rd.raw(64)
+    out["cs_hash"] = rd.raw(64, "cs_hash")
     out["contributions"] = []
-    for _ in range(rd.u32()):
+    for _ in range(rd.u32("the number of contributions")):
         pk = {"delta_after": rd.points(1, 1, True, True, "delta_after"), "s": rd.points(1, 1, True, True, "s"),
               "s_delta": rd.points(1, 1, True, True, "s_delta"), "r_delta": rd.points(1, 2, True, True, "r_delta")}
-        pk["transcript"] = rd.raw(64)
+        pk["transcript"] = rd.raw(64, "a transcript")
         out["contributions"].append(pk)
     return out
 

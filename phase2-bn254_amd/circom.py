@@ -58,8 +58,20 @@ def circuit_from_json(text) -> CircomCircuit:
     if num_aux < 0:
         raise ValueError("nVars < nPubInputs + nOutputs + 1")
 
+    def index(k) -> int:
+        # Rust's `parse::<usize>()` (circom_circuit.rs:346-350, unwrap): ASCII digits with an optional leading '+', nothing else
+        # -- Python's int() would also take "-1", " 2" or "1_0", and a negative index would alias the LAST variable.  A variable
+        # index past nVars panics in the reference when the constraint is synthesized; here it is rejected up front.
+        digits = k[1:] if isinstance(k, str) and k.startswith("+") else k
+        if not (isinstance(digits, str) and digits.isascii() and digits.isdigit()):
+            raise ValueError(f"circuit.json: {k!r} is not a variable index")
+        idx = int(digits)
+        if idx >= num_variables:
+            raise ValueError(f"circuit.json: variable index {idx} out of range (nVars = {num_variables})")
+        return idx
+
     def convert(lc):   # a BTreeMap<String, String>: iterated in the order of the KEYS AS STRINGS
-        return [(int(k), _fr_from_str(lc[k])) for k in sorted(lc.keys())]
+        return [(index(k), _fr_from_str(lc[k])) for k in sorted(lc.keys())]
 
     constraints = [(convert(c[0]), convert(c[1]), convert(c[2])) for c in cj["constraints"]]
     return CircomCircuit(num_inputs, num_aux, num_variables, constraints)
@@ -249,9 +261,11 @@ def prepare_prover(circuit: CircomCircuit, device):
 
 
 def filter_params(params):
-    """filter_params (circom_circuit.rs: the A / B queries without their points at infinity -- what the density maps index)"""
+    """filter_params (circom_circuit.rs:271-277): vk.ic, h, a, b_g1 and b_g2 without their points at infinity (the A / B queries
+    are what the density maps index; l is left as it is, as in the reference)."""
     keep = lambda pts: pts[~(pts == 0).all(dim=1)].contiguous()  # noqa: E731
-    return dict(params, a=keep(params["a"]), b_g1=keep(params["b_g1"]), b_g2=keep(params["b_g2"]))
+    vk = dict(params["vk"], ic=keep(params["vk"]["ic"]))
+    return dict(params, vk=vk, h=keep(params["h"]), a=keep(params["a"]), b_g1=keep(params["b_g1"]), b_g2=keep(params["b_g2"]))
 
 
 def prove(pool, circuit: CircomCircuit, params, r: int, s: int):

@@ -153,7 +153,8 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
 
     def submit(bases, density, exponents):
         if ex is None:
-            fut = multiexp(pool, bases, density, exponents, scalars_montgomery=True)
+            with torch.cuda.device(device):
+                fut = multiexp(pool, bases, density, exponents, scalars_montgomery=True)
             return fut.wait
 
         def call():
@@ -183,7 +184,9 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
     a.icoset_fft(pool)
     coeffs = a.into_coeffs()
     coeffs = coeffs[:coeffs.shape[0] - 1]                       # a.truncate(a_len)
-    torch.cuda.current_stream().synchronize()                   # the multiexp threads use their own view of the stream
+    # the multiexp threads use their own streams: the H pipeline (queued on the stream of the TENSORS' device, which need not be
+    # the caller's current device) must be complete before they read `coeffs`
+    torch.cuda.current_stream(device).synchronize()
     h = submit(params.get_h(coeffs.shape[0]), FullDensity(), coeffs)
 
     # ---- the assignments (prover.rs:256-298); into_repr is fused into every multiexp

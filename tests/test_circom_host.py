@@ -43,6 +43,17 @@ def test_field_element_strings_like_from_str(bad):
     assert zk.circom.circuit_from_json(dict(CIRCUIT, constraints=[[{"1": str(M.R_ORDER - 1)}, {"1": "0"}, {}]])).constraints[0][0] == [(1, M.R_ORDER - 1)]
 
 
+@pytest.mark.parametrize("bad", ["-1", " 2", "1_0", "2 ", "", "0x2", "11", "99999999999999999999", "\u0662"])
+def test_variable_indices_like_parse_usize(bad):
+    """`s.parse::<usize>()` on the keys (circom_circuit.rs:346-350): no sign but '+', no blanks, no underscores, ASCII digits
+    only; an index past nVars (11 here) never aliases another variable."""
+    zk = _zk()
+    with pytest.raises(ValueError):
+        zk.circom.circuit_from_json(dict(CIRCUIT, constraints=[[{bad: "1"}, {}, {}]]))
+    ok = zk.circom.circuit_from_json(dict(CIRCUIT, constraints=[[{"+3": "1", "10": "2", "007": "5"}, {}, {}]]))
+    assert ok.constraints[0][0] == [(3, 1), (7, 5), (10, 2)]           # keys in string order: "+3" < "007" < "10"
+
+
 def test_assembly_like_mpc_parameters_new():
     zk = _zk()
     cs = zk.circom.assemble(zk.circom.circuit_from_json(CIRCUIT))

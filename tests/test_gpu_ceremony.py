@@ -475,6 +475,21 @@ def test_groth16_and_mpc_parameter_files(zk, worker):
         zk.ceremony.read_parameters(torch.from_numpy(bad).cuda(), checked=False)
     with pytest.raises(ValueError):
         zk.ceremony.read_parameters(torch.from_numpy(params_bytes[:-10].copy()).cuda())
+    # truncated MPC files: at every field boundary, one byte before it and in the middle of the field that follows it, the
+    # reader fails like the reference's read_u32 / read_exact (UnexpectedEof) instead of returning short vectors, a short
+    # cs_hash or zero contributions
+    bounds, o = [], 0
+    for sz in [64, 64, 128, 128, 64, 128, 4, 3 * 64, 4, 15 * 64, 4, 13 * 64, 4, 16 * 64, 4, 9 * 64, 4, 9 * 128, 64, 4, 64, 64, 64, 128, 64]:
+        bounds.append((o, sz))
+        o += sz
+    assert o == mpc_bytes.size
+    dev_bytes = torch.from_numpy(mpc_bytes).cuda()
+    for start, sz in bounds:
+        for cut in {start, start + 1, start + sz // 2, start + sz - 1}:
+            if 0 <= cut < mpc_bytes.size:
+                with pytest.raises(ValueError, match="too short"):
+                    zk.ceremony.read_mpc_parameters(dev_bytes[:cut])
+    zk.ceremony.read_mpc_parameters(dev_bytes[:mpc_bytes.size])
 
     # contribute: the heavy part of phase2 `contribute` on the parsed file, written back and re-read
     delta = 0x6A09E667F3BCC908BB67AE8584CAA73B3C6EF372FE94F82BA54FF53A5F1D36F1 % M.R_ORDER

@@ -65,3 +65,28 @@ def test_shard_plan_covers_every_rank_once():
             assert pg * wg == world and 0 <= p < pg and 0 <= w < wg
             cells.add((p, w))
         assert len(cells) == world
+
+
+def test_parameter_file_reader_fails_on_truncation_like_read_exact():
+    """`_Reader.u32` / `.raw` (ceremony.py): the reference's read_u32 / read_exact return UnexpectedEof on a truncated file
+    (bellman/src/groth16/mod.rs:296-383, phase2/src/parameters.rs:683-706); slicing a tensor past its end silently returns fewer
+    bytes and int.from_bytes(b"") is 0, so every read checks the remaining length first."""
+    import torch
+
+    import phase2_bn254_amd as zk
+
+    data = torch.arange(10, dtype=torch.uint8)
+    rd = zk.ceremony._Reader(data)
+    assert rd.u32() == 0x00010203 and rd.off == 4
+    assert bytes(rd.raw(4).numpy()) == bytes([4, 5, 6, 7])
+    with pytest.raises(ValueError, match="too short"):
+        rd.u32()          # two bytes left
+    with pytest.raises(ValueError, match="too short"):
+        rd.raw(3)
+    assert bytes(rd.raw(2).numpy()) == bytes([8, 9])
+    with pytest.raises(ValueError, match="too short"):
+        rd.raw(1)
+    with pytest.raises(ValueError, match="too short"):
+        zk.ceremony._Reader(torch.zeros(0, dtype=torch.uint8)).u32()
+    with pytest.raises(ValueError, match="too short"):
+        zk.ceremony._be32(data, 8)
