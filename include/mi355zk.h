@@ -75,11 +75,16 @@ int mi355zk_bn254_g1_msm(const uint8_t *bases, size_t n_bases, size_t base_offse
                          const uint64_t *scalars, size_t n_scalars,
                          const uint32_t *density, size_t density_bits,
                          uint64_t out_xyz[12]);
-/* Host-buffer calls keep the uploaded BASE vector cached on the device, keyed by (pointer, length, group, a fingerprint of
- * sampled records): the CRS is an immutable `Arc<Vec<G>>` reused by every proof (groth16/mod.rs:216-238), so only the scalars
- * cross PCIe after the first call; large calls are streamed (chunked upload overlapped with the kernels).  A caller that
- * REWRITES a base vector in place must say so: mi355zk_bases_cache_invalidate(ptr) (NULL: every cached vector).  The cache is
- * LRU-bounded by env MI355ZK_BASES_CACHE_GB (default 64, 0 = off). */
+/* The CRS is an immutable `Arc<Vec<G>>` reused by every proof (groth16/mod.rs:216-238).  A caller that can PROMISE that --
+ * the Rust shim keeps a clone of the Arc next to its raw-record vector, so the allocation is neither rewritten nor freed --
+ * pins the vector: mi355zk_bases_cache_pin(ptr, n_bases, group 1|2).  Host-buffer calls over exactly (ptr, n_bases) then keep
+ * their uploaded copy on the device and only the scalars cross PCIe after the first call (large calls are streamed: chunked
+ * upload overlapped with the kernels).  Vectors that were NOT pinned are uploaded on every call: the plain `const uint8_t*`
+ * entry is correct whatever the caller does with its buffer between calls.  mi355zk_bases_cache_invalidate(ptr) ends the
+ * promise and drops the device copy (NULL: every vector) -- call it before rewriting or freeing a pinned vector.  A
+ * fingerprint of sampled records is re-checked on every call as a second line of defence.  LRU-bounded by env
+ * MI355ZK_BASES_CACHE_GB (default 64, 0 = off); env MI355ZK_BASES_CACHE_IMPLICIT=1 treats every vector as pinned. */
+int mi355zk_bases_cache_pin(const void *host_bases, size_t n_bases, int group);
 void mi355zk_bases_cache_invalidate(const void *host_bases);
 /* Same for G = G2Affine (prover.rs:297-298). */
 int mi355zk_bn254_g2_msm(const uint8_t *bases, size_t n_bases, size_t base_offset,

@@ -20,4 +20,6 @@ from .bellman import (  # noqa: F401
     SynthesisError,
     Worker,
     multiexp,
+    pin_bases,
+    unpin_bases,
 )

@@ -141,6 +141,21 @@ class _Ready:
         return self._value
 
 
+def pin_bases(arr) -> None:
+    """mi355zk_bases_cache_pin: declare the HOST base vector `arr` ((n, 8) / (n, 16) u64, C-contiguous) immutable until
+    unpin_bases(arr) -- the `Arc<Vec<G>>` of a Parameters object (groth16/mod.rs:216-238).  Host-buffer multiexps over it then
+    keep their uploaded copy on the device.  Without the promise every call uploads its bases again."""
+    assert not _is_torch(arr) and arr.flags["C_CONTIGUOUS"] and arr.dtype == np.uint64
+    rc = _lib.load().mi355zk_bases_cache_pin(arr.ctypes.data_as(C.c_void_p), arr.shape[0], {8: 1, 16: 2}[arr.shape[1]])
+    if rc != 0:
+        raise ValueError("mi355zk_bases_cache_pin: bad arguments")
+
+
+def unpin_bases(arr=None) -> None:
+    """mi355zk_bases_cache_invalidate: the promise ends (before rewriting or freeing the vector); None: every vector."""
+    _lib.load().mi355zk_bases_cache_invalidate(arr.ctypes.data_as(C.c_void_p) if arr is not None else None)
+
+
 def multiexp(pool: Worker, bases, density_map, exponents, window_group=None, scalars_montgomery: bool = False) -> _Ready:
     """bellman/src/multiexp.rs:330.  (window_group = (groups, index), device-resident data only: the partial sum over one
     of `groups` equal groups of scalar windows -- multi-GPU sharding by windows, shard.py; None = the whole multiexp.

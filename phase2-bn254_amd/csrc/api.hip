@@ -594,19 +594,46 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
   return ZK_OK;
 }
 
-// fixed base given by value on the host (input synthesis: P_i = k_i * G)
+// fixed base given by value on the host (input synthesis: P_i = k_i * G).  The 64 / 128-byte device copy of the base comes from a
+// per-(device, stream) ring of slots allocated once: hipMalloc / hipFree per call synchronise the whole device, and this entry is
+// the building block of per-point batch_exp synthesis (256 calls per bench input).  A slot is in flight only until its call's
+// closing stream synchronisation; MUL_SLOTS concurrent calls on ONE stream is more than any caller here issues.
+constexpr int MUL_SLOTS = 16;
+struct MulSlots {
+  void* p = nullptr;
+  unsigned next = 0;
+};
+static std::mutex g_mul_mu;
+static std::map<std::pair<int, void*>, MulSlots> g_mul_slots;
+static int mul_slot(void* stream, void** out) {
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mul_mu);
+  MulSlots& m = g_mul_slots[std::make_pair(dev, stream)];
+  if (m.p == nullptr) ZK_HIP(hipMalloc(&m.p, (size_t)MUL_SLOTS * 256));
+  *out = (char*)m.p + (size_t)(m.next++ % MUL_SLOTS) * 256;
+  return ZK_OK;
+}
+void mul_slots_release_all() {
+  std::lock_guard<std::mutex> lk(g_mul_mu);
+  for (auto& kv : g_mul_slots) {
+    (void)hipSetDevice(kv.first.first);
+    (void)hipFree(kv.second.p);
+  }
+  g_mul_slots.clear();
+}
 template <class F>
 int batch_mul(void* d_out, const uint64_t* base_raw, const void* d_scalars, size_t n, void* stream) {
+  static_assert(sizeof(Affine<F>) <= 256, "slot size");
   if (!d_out || !base_raw || (!d_scalars && n)) return ZK_ERR_BAD_ARGS;
   if (n == 0) return ZK_OK;
-  Affine<F>* d_base = nullptr;
-  ZK_HIP(hipMalloc(&d_base, sizeof(Affine<F>)));
-  hipError_t e = hipMemcpyAsync(d_base, base_raw, sizeof(Affine<F>), hipMemcpyHostToDevice, (hipStream_t)stream);
-  int rc = e == hipSuccess ? batch_exp<F>(d_out, d_base, 1, d_scalars, 0, n, stream) : ZK_ERR_DEVICE;
-  if (rc == ZK_OK) e = hipStreamSynchronize((hipStream_t)stream);
-  (void)hipFree(d_base);
+  void* d_base = nullptr;
+  int rc = mul_slot(stream, &d_base);
+  if (rc) return rc;
+  ZK_HIP(hipMemcpyAsync(d_base, base_raw, sizeof(Affine<F>), hipMemcpyHostToDevice, (hipStream_t)stream));
+  rc = batch_exp<F>(d_out, d_base, 1, d_scalars, 0, n, stream);
   if (rc != ZK_OK) return rc;
-  ZK_HIP(e);
+  ZK_HIP(hipStreamSynchronize((hipStream_t)stream));  // base_raw is the caller's (pageable) memory; the result is ready on return
   return ZK_OK;
 }
 
@@ -817,8 +844,11 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
 // ------------------------------------------------------------------------------------------------
 // Host-buffer entry points (SURVEY 8b "Ownership"): the caller's bases and scalars live in (pageable) host memory.
 //   * BASES CACHE: the CRS / tau-table is reused across calls (`Arc<Vec<G>>` inside groth16::Parameters, groth16/mod.rs:216-238),
-//     so an uploaded base vector stays on the device, keyed by (host pointer, length, group, fingerprint of sampled records);
-//     LRU-bounded (env MI355ZK_BASES_CACHE_GB, default 64; 0 disables).
+//     so the device copy of a base vector the caller has PINNED (mi355zk_bases_cache_pin: "this host vector is immutable until
+//     I invalidate it" -- the shim holds a clone of the Arc, so the allocation can neither be rewritten nor freed and reused)
+//     stays on the device, keyed by (host pointer, length, group) with a fingerprint of sampled records as a safety net;
+//     LRU-bounded (env MI355ZK_BASES_CACHE_GB, default 64; 0 disables).  Vectors that were not pinned are uploaded on every call
+//     (env MI355ZK_BASES_CACHE_IMPLICIT=1 restores round 2's behaviour: every vector is treated as pinned).
 //   * STREAMED UPLOAD: a large call is cut into chunks of ~2^24 exponents; a copy thread uploads chunk i + 1 (its scalars into
 //     one of two staging buffers, its bases -- when they are not cached yet -- straight into the cache entry) on a copy stream
 //     while the calling thread runs the multiexp of chunk i on a compute stream; the Jacobian partials are added on the host.
@@ -844,8 +874,8 @@ uint64_t fnv1a(uint64_t h, const uint8_t* p, size_t n) {
   return h;
 }
 // first / last 4 KiB and 4096 records spread over the array: cheap (~0.3 MB hashed), and a different CRS at the same address
-// is caught; a few records rewritten IN PLACE are not -- the contract (include/mi355zk.h) is the reference's: the vector behind
-// an `Arc<Vec<G>>` is immutable, and mi355zk_bases_cache_invalidate() exists for callers that do rewrite it
+// is caught; a few records rewritten IN PLACE are not -- which is why caching is OPT-IN: only vectors the caller pinned (declared
+// immutable) are served from the device copy, the fingerprint is a second line of defence, not the contract
 uint64_t bases_fingerprint(const uint8_t* p, size_t bytes, size_t rec) {
   uint64_t h = 0xcbf29ce484222325ull;
   const size_t edge = bytes < 4096 ? bytes : 4096;
@@ -860,11 +890,37 @@ size_t bases_cache_cap() {
   const double gb = env ? std::atof(env) : 64.0;
   return gb <= 0 ? 0 : (size_t)(gb * 1073741824.0);
 }
-// returns the entry (locked for filling when *fill == true: the caller uploads and then sets ready) or nullptr (cache off / no room)
+// the vectors the caller declared immutable (mi355zk_bases_cache_pin)
+struct BasesPin {
+  const void* host;
+  size_t n;
+  int group;
+};
+std::vector<BasesPin> g_bc_pins;  // under g_bc_mu
+bool bases_cache_implicit() {
+  static const char* env = std::getenv("MI355ZK_BASES_CACHE_IMPLICIT");
+  return env && env[0] == '1';
+}
+int bases_cache_pin(const void* host, size_t n, int group) {
+  if (!host || n == 0 || (group != 1 && group != 2)) return ZK_ERR_BAD_ARGS;
+  std::lock_guard<std::mutex> lk(g_bc_mu);
+  for (auto& p : g_bc_pins)
+    if (p.host == host && p.n == n && p.group == group) return ZK_OK;
+  g_bc_pins.push_back(BasesPin{host, n, group});
+  return ZK_OK;
+}
+// returns the entry (locked for filling when *fill == true: the caller uploads and then sets ready) or nullptr (cache off / not
+// pinned / no room)
 std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, size_t bytes, int dev, bool* fill) {
   *fill = false;
   const size_t cap = bases_cache_cap();
   if (cap == 0 || bytes > cap) return nullptr;
+  if (!bases_cache_implicit()) {
+    std::lock_guard<std::mutex> lk(g_bc_mu);
+    bool pinned = false;
+    for (auto& p : g_bc_pins) pinned = pinned || (p.host == host && p.n == n && p.group == group);
+    if (!pinned) return nullptr;
+  }
   const uint64_t fp = bases_fingerprint((const uint8_t*)host, bytes, group == 1 ? 64 : 128);
   std::shared_ptr<BasesEntry> hit;
   {
@@ -889,7 +945,9 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
       for (size_t i = 0; i < g_bc.size(); ++i)
         if (g_bc[i]->ready && g_bc[i].use_count() == 1 && (victim == g_bc.size() || g_bc[i]->tick < g_bc[victim]->tick)) victim = i;
       if (victim == g_bc.size()) break;
+      (void)hipSetDevice(g_bc[victim]->dev);  // the victim may live on another GPU of this process
       (void)hipFree(g_bc[victim]->d);
+      (void)hipSetDevice(dev);
       used -= g_bc[victim]->bytes;
       g_bc.erase(g_bc.begin() + (long)victim);
     }
@@ -970,7 +1028,13 @@ int stage_reserve(void** p, size_t* have, size_t want) {
 
 // forget the device copies of the base vector at `host` (nullptr: of every vector); entries in use stay until their call ends
 void bases_cache_invalidate(const void* host) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
   std::lock_guard<std::mutex> lk(g_bc_mu);
+  for (size_t i = 0; i < g_bc_pins.size();) {  // the promise of immutability ends here
+    if (host == nullptr || g_bc_pins[i].host == host) g_bc_pins.erase(g_bc_pins.begin() + (long)i);
+    else ++i;
+  }
   for (size_t i = 0; i < g_bc.size();) {
     if ((host == nullptr || g_bc[i]->host == host) && g_bc[i]->ready && g_bc[i].use_count() == 1) {
       (void)hipSetDevice(g_bc[i]->dev);
@@ -981,6 +1045,7 @@ void bases_cache_invalidate(const void* host) {
       ++i;
     }
   }
+  (void)hipSetDevice(cur);
 }
 
 void host_entry_release_all() {
@@ -1292,6 +1357,7 @@ int mi355zk_init(const int* device_ids, int n_devices) {
 void mi355zk_shutdown(void) {
   ntt_release_all();
   exp_scratch_release_all();
+  mul_slots_release_all();
   host_entry_release_all();
   msm_release_g1();
   msm_release_g2();
@@ -1299,6 +1365,7 @@ void mi355zk_shutdown(void) {
 
 const char* mi355zk_version(void) { return "mi355zk 0.2 (gfx950)"; }
 
+int mi355zk_bases_cache_pin(const void* host_bases, size_t n_bases, int group) { return bases_cache_pin(host_bases, n_bases, group); }
 void mi355zk_bases_cache_invalidate(const void* host_bases) {
   int dev = 0;
   const bool have = hipGetDevice(&dev) == hipSuccess;

@@ -23,6 +23,7 @@ SIGNATURES = {
     "mi355zk_init": (_i, [C.POINTER(C.c_int), _i]),
     "mi355zk_shutdown": (None, []),
     "mi355zk_version": (C.c_char_p, []),
+    "mi355zk_bases_cache_pin": (_i, [_vp, _sz, _i]),
     "mi355zk_bases_cache_invalidate": (None, [_vp]),
     "mi355zk_bn254_g1_msm": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_msm": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp]),

@@ -680,7 +680,8 @@ def test_montgomery_scalars_fused_into_repr(zk, worker, group):
 def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
     """The host-buffer entry point (mi355zk_bn254_g1_msm, what a bellman shim calls with `Arc<Vec<G1Affine>>` + `Vec<FrRepr>`):
     2^23 exponents are cut into chunks whose upload overlaps the previous chunk's kernels, and the base vector stays cached on
-    the device under (pointer, length, fingerprint).  Same group element as the device-resident call -- with a density map and
+    the device once the caller has PINNED it (mi355zk_bases_cache_pin; unpinned vectors are uploaded on every call, so a record
+    rewritten in place is seen).  Same group element as the device-resident call -- with a density map and
     a source offset, on the first (uploading) and the second (cached) call; a changed CRS at the same address is noticed; the
     Source errors keep their global exponent index across chunks."""
     import torch
@@ -703,13 +704,29 @@ def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
     want = O.G1.to_affine(zk.multiexp(worker, (d_bases, off), dm, d_scalars).wait())
     h_bases = d_bases.cpu().numpy().view(np.uint64)
     h_scalars = d_scalars.cpu().numpy().view(np.uint64)
+    # NOT pinned: the plain host-buffer entry uploads its bases on every call, so a record rewritten in place between two calls
+    # -- one the cache's fingerprint does not sample -- is seen (the reference reads the vector it is given)
+    plain = zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()
+    assert np.array_equal(O.G1.to_affine(plain), want)
+    mid = off + 12345
+    saved = h_bases[mid].copy()
+    h_bases[mid] = h_bases[mid + 1]
+    d_bases[mid] = d_bases[mid + 1]
+    want_mut = O.G1.to_affine(zk.multiexp(worker, (d_bases, off), dm, d_scalars).wait())
+    assert not np.array_equal(want_mut, want)
+    assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()), want_mut)
+    h_bases[mid] = saved
+    d_bases[mid] = torch.from_numpy(saved.view(np.int64)).to(dev)
+    # pinned (the shim's promise that the Arc<Vec<G>> is immutable): the second call is served from the device copy
+    zk.pin_bases(h_bases)
     first = zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()       # uploads bases + scalars, chunk by chunk
     second = zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()      # bases served from the cache
     assert np.array_equal(O.G1.to_affine(first), want) and np.array_equal(O.G1.to_affine(second), want)
     # FullDensity over a prefix of the same (cached) vector
     want_fd = O.G1.to_affine(zk.multiexp(worker, (d_bases, 0), zk.FullDensity(), d_scalars[:used]).wait())
     assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (h_bases, 0), zk.FullDensity(), h_scalars[:used]).wait()), want_fd)
-    # the CRS changes in place (same pointer, same length): the fingerprint differs, the stale copy is not used
+    # a different CRS at the same address without an invalidate (a broken promise): the fingerprint of the sampled records is
+    # the second line of defence -- record 0 is always sampled
     h_bases[0] = h_bases[1]
     d_bases[0] = d_bases[1]
     want2 = O.G1.to_affine(zk.multiexp(worker, (d_bases, off), dm, d_scalars).wait())
@@ -718,7 +735,7 @@ def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
     sel = np.nonzero(bits)[0]
     target = int(sel[len(sel) * 3 // 4])
     h_bases[off + len(sel) * 3 // 4] = 0
-    zk.lib.load().mi355zk_bases_cache_invalidate(h_bases.ctypes.data_as(C.c_void_p))   # a record rewritten in place: the caller says so
+    zk.unpin_bases(h_bases)   # a record rewritten in place: the promise ends first (the vector is uploaded again from here on)
     with pytest.raises(zk.SynthesisError) as e:
         zk.multiexp(worker, (h_bases, off), dm, h_scalars).wait()
     assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == target

@@ -1,0 +1,199 @@
+"""An anchor for the oracle (and the kernels) that comes from OUTSIDE both the reference and this repository.
+
+The reference holds no BN254 known-answer value for multiexp / the group law ("parity unpinned" -- only the DummyEngine
+literals and the curve constants), so BN254 *values* would otherwise rest on the oracle + the builder's own big-int model.  But
+`pairing/src/bn256` IS Ethereum's alt_bn128: same q, r, b = 3, G1 generator (1, 2) and the G2 generator of `fq.rs:54-83`.  The
+published test vectors of the EVM precompiles therefore pin this curve from the outside:
+
+* EIP-196 (ecAdd 0x06 / ecMul 0x07): the "chfast1", "chfast2", "chfast3" cases of go-ethereum's
+  `core/vm/testdata/precompiles/bn256Add.json` / `bn256ScalarMul.json` (the same inputs appear in the cpp-ethereum / aleth
+  precompile tests they were taken from), and the doubling 2*(1, 2) quoted in EIP-196 itself.  Encoding: x || y, 32-byte
+  big-endian each; scalars 32-byte big-endian and NOT reduced (chfast2's scalar is q - 1 > r).
+* EIP-197 (ecPairing 0x08): the first case ("jeff1") of `bn256Pairing.json`: two (G1, G2) pairs whose pairing product is one.
+  G2 encoding: x.c1 || x.c0 || y.c1 || y.c0 big-endian -- byte for byte the reference's `G2Uncompressed` (ec.rs:1214-1231), and
+  x || y is its `G1Uncompressed` (ec.rs:827-842).  The second G2 point is the EIP-197 generator.  No pairing is computed here
+  (out of scope); the points anchor the twist equation, the wire format and -- r * P = infinity on a non-generator r-torsion
+  point -- the G2 group law.
+
+The vectors were typed in from memory of those files (no network in this image) and are self-checking: every input and output
+below must lie on the curve, which a single wrong hex digit breaks with overwhelming probability, before it is compared with
+anything this repository computes.  TEST INFRASTRUCTURE: the oracle is the thing under test here, not the product.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bn254_model as M
+import oracle_lib as O
+
+# ---- EIP-196 ----------------------------------------------------------------------------------------------------------
+ADD = {
+    "chfast1": ("18b18acfb4c2c30276db5411368e7185b311dd124691610c5d3b74034e093dc9063c909c4720840cb5134cb9f59fa749755796819658d32efc0d288198f37266"
+                "07c2b7f58a84bd6145f00c9c2bc0bb1a187f20ff2c92963a88019e7c6a014eed06614e20c147e940f2d70da3f74c9a17df361706a4485c742bd6788478fa17d7",
+                "2243525c5efd4b9c3d3c45ac0ca3fe4dd85e830a4ce6b65fa1eeaee202839703301d1d33be6da8e509df21cc35964723180eed7532537db9ae5e7d48f195c915"),
+    "chfast2": ("2243525c5efd4b9c3d3c45ac0ca3fe4dd85e830a4ce6b65fa1eeaee202839703301d1d33be6da8e509df21cc35964723180eed7532537db9ae5e7d48f195c915"
+                "18b18acfb4c2c30276db5411368e7185b311dd124691610c5d3b74034e093dc9063c909c4720840cb5134cb9f59fa749755796819658d32efc0d288198f37266",
+                "2bd3e6d0f3b142924f5ca7b49ce5b9d54c4703d7ae5648e61d02268b1a0a9fb721611ce0a6af85915e2f1d70300909ce2e49dfad4a4619c8390cae66cefdb204"),
+}
+MUL = {
+    "chfast1": ("2bd3e6d0f3b142924f5ca7b49ce5b9d54c4703d7ae5648e61d02268b1a0a9fb721611ce0a6af85915e2f1d70300909ce2e49dfad4a4619c8390cae66cefdb204"
+                "00000000000000000000000000000000000000000000000011138ce750fa15c2",
+                "070a8d6a982153cae4be29d434e8faef8a47b274a053f5a4ee2a6c9c13c31e5c031b8ce914eba3a9ffb989f9cdd5b0f01943074bf4f0f315690ec3cec6981afc"),
+    "chfast2": ("070a8d6a982153cae4be29d434e8faef8a47b274a053f5a4ee2a6c9c13c31e5c031b8ce914eba3a9ffb989f9cdd5b0f01943074bf4f0f315690ec3cec6981afc"
+                "30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd46",
+                "025a6f4181d2b4ea8b724290ffb40156eb0adb514c688556eb79cdea0752c2bb2eff3f31dea215f1eb86023a133a996eb6300b44da664d64251d05381bb8a02e"),
+    "chfast3": ("025a6f4181d2b4ea8b724290ffb40156eb0adb514c688556eb79cdea0752c2bb2eff3f31dea215f1eb86023a133a996eb6300b44da664d64251d05381bb8a02e"
+                "183227397098d014dc2822db40c0ac2ecbc0b548b438e5469e10460b6c3e7ea3",
+                "14789d0d4a730b354403b5fac948113739e276c23e0258d8596ee72f9cd9d3230af18a63153e0ec25ff9f2951dd3fa90ed0197bfef6e2a1a62b5095b9d2b4a27"),
+}
+DOUBLE_OF_GENERATOR = "030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd315ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4"
+
+# ---- EIP-197: bn256Pairing.json "jeff1" = (A1, B1), (A2, G2 generator) ---------------------------------------------------
+PAIRING_JEFF1 = (
+    "1c76476f4def4bb94541d57ebba1193381ffa7aa76ada664dd31c16024c43f593034dd2920f673e204fee2811c678745fc819b55d3e9d294e45c9b03a76aef41"
+    "209dd15ebff5d46c4bd888e51a93cf99a7329636c63514396b4a452003a35bf704bf11ca01483bfa8b34b43561848d28905960114c8ac04049af4b6315a41678"
+    "2bb8324af6cfc93537a2ad1a445cfd0ca2a71acd7ac41fadbf933c2a51be344d120a2a4cf30c1bf9845f20c6fe39e07ea2cce61f0c9bb048165fe5e4de877550"
+    "111e129f1cf1097710d41c4ac70fcdfa5ba2023c6ff1cbeac322de49d1b6df7c2032c61a830e3c17286de9462bf242fca2883585b93870a73853face6a6bf411"
+    "198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c21800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed"
+    "090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa")
+
+
+def _words(h):
+    return [int(h[i:i + 64], 16) for i in range(0, len(h), 64)]
+
+
+def _g1_raw(x, y):
+    return np.array(M.g1_affine_to_raw((x, y)), dtype=np.uint64)
+
+
+def _limbs(k):
+    return np.array(M.to_limbs(k), dtype=np.uint64)
+
+
+def _on_g1(x, y):
+    return (y * y - x * x * x - 3) % M.Q == 0 and x < M.Q and y < M.Q
+
+
+def test_the_vectors_check_themselves():
+    """Every point typed in above is on its curve (a wrong digit would not be), independently of the oracle."""
+    for inp, out in list(ADD.values()):
+        x1, y1, x2, y2 = _words(inp)
+        assert _on_g1(x1, y1) and _on_g1(x2, y2) and _on_g1(*_words(out))
+    for inp, out in MUL.values():
+        x, y, _ = _words(inp)
+        assert _on_g1(x, y) and _on_g1(*_words(out))
+    assert _on_g1(*_words(DOUBLE_OF_GENERATOR))
+    w = _words(PAIRING_JEFF1)
+    for k in range(2):
+        a = w[6 * k:6 * k + 6]
+        assert _on_g1(a[0], a[1]) and M.on_curve_g2(((a[3], a[2]), (a[5], a[4])))
+    # the chain the cases form: add1's output is add2's input, add2's output mul1's base, mul1's output mul2's base, ...
+    assert ADD["chfast1"][1] == ADD["chfast2"][0][:128] and ADD["chfast2"][1] == MUL["chfast1"][0][:128]
+    assert MUL["chfast1"][1] == MUL["chfast2"][0][:128] and MUL["chfast2"][1] == MUL["chfast3"][0][:128]
+
+
+def test_oracle_group_law_against_eip196():
+    """ecAdd / ecMul of the EVM precompiles through the oracle's add_assign, add_assign_mixed, double and mul_assign restatements
+    (ec.rs:301-563)."""
+    G = O.G1
+    for name, (inp, out) in ADD.items():
+        x1, y1, x2, y2 = _words(inp)
+        want = _g1_raw(*_words(out))
+        a, b = G.from_affine(_g1_raw(x1, y1)), G.from_affine(_g1_raw(x2, y2))
+        assert np.array_equal(G.to_affine(G.add(a, b)), want), name
+        assert np.array_equal(G.to_affine(G.add_mixed(a, _g1_raw(x2, y2))), want), name
+    for name, (inp, out) in MUL.items():
+        x, y, k = _words(inp)
+        got = G.to_affine(G.mul(G.from_affine(_g1_raw(x, y)), _limbs(k)))      # chfast2: k = q - 1 > r, not reduced (the EVM's rule and mul_assign's)
+        assert np.array_equal(got, _g1_raw(*_words(out))), name
+    gen = G.from_affine(_g1_raw(1, 2))
+    want = _g1_raw(*_words(DOUBLE_OF_GENERATOR))
+    assert np.array_equal(G.to_affine(G.double(gen)), want) and np.array_equal(G.to_affine(G.add(gen, gen)), want)
+    assert np.array_equal(G.to_affine(G.mul(gen, _limbs(2))), want)
+
+
+def test_oracle_multiexp_against_eip196():
+    """multiexp (multiexp.rs:330-355) over the published bases and (canonical) scalars: the sum of the published products."""
+    G = O.G1
+    names = ("chfast1", "chfast3")
+    bases = np.stack([_g1_raw(*_words(MUL[n][0])[:2]) for n in names])
+    scalars = np.stack([_limbs(_words(MUL[n][0])[2]) for n in names])
+    want = G.add(G.from_affine(_g1_raw(*_words(MUL[names[0]][1]))), G.from_affine(_g1_raw(*_words(MUL[names[1]][1]))))
+    rc, got = G.multiexp(bases, scalars)
+    assert rc == 0 and np.array_equal(G.to_affine(got), G.to_affine(want))
+    # exponent one (the reference's shortcut, multiexp.rs:97-99) on ecAdd's inputs: the published sum
+    x1, y1, x2, y2 = _words(ADD["chfast1"][0])
+    rc, got = G.multiexp(np.stack([_g1_raw(x1, y1), _g1_raw(x2, y2)]), np.stack([_limbs(1), _limbs(1)]))
+    assert rc == 0 and np.array_equal(G.to_affine(got), _g1_raw(*_words(ADD["chfast1"][1])))
+
+
+def test_oracle_codecs_and_g2_against_eip197():
+    """The pairing input's points are the reference's uncompressed wire format: the oracle's CHECKED decoders (on-curve test with
+    b = 3 and b' = 3 / (9 + u), ec.rs:763-946, 1136-1344) accept them, re-encode them byte for byte, and the G2 generator in there
+    is the reference's literal (fq.rs:54-83).  B1 is a non-generator point of the r-torsion: r * B1 = 0 through the oracle's G2
+    mul_assign, and (r - 1) * B1 = -B1."""
+    raw = np.frombuffer(bytes.fromhex(PAIRING_JEFF1), dtype=np.uint8)
+    g1_bytes = np.stack([raw[0:64], raw[192:256]])
+    g2_bytes = np.stack([raw[64:192], raw[256:384]])
+    rc, err, g1 = O.decode_points(1, g1_bytes, compressed=False, checked=True)
+    assert rc == 0 and err == -1 and np.array_equal(O.encode_points(1, g1, False), g1_bytes)
+    rc, err, g2 = O.decode_points(2, g2_bytes, compressed=False, checked=True)
+    assert rc == 0 and err == -1 and np.array_equal(O.encode_points(2, g2, False), g2_bytes)
+    import inputs
+
+    assert np.array_equal(g2[1], inputs.G2_GEN_RAW)       # EIP-197's generator == pairing/src/bn256/fq.rs:54-83
+    w = _words(PAIRING_JEFF1)
+    assert np.array_equal(g1[0], _g1_raw(w[0], w[1]))
+    r, rm1 = _limbs(M.R_ORDER), _limbs(M.R_ORDER - 1)
+    for G, pts in ((O.G1, g1), (O.G2, g2)):
+        for p in pts:
+            j = G.from_affine(p)
+            assert not G.to_affine(G.mul(j, r)).any()                       # infinity
+            neg = G.to_affine(G.mul(j, rm1))
+            assert np.array_equal(neg[:4 * G.g], p[:4 * G.g]) and not np.array_equal(neg, p)   # same x, other y
+            assert not G.to_affine(G.add(G.from_affine(neg), j)).any()
+    # compressed round trip of the external G2 point (Fq2::sqrt with the reference's NEGATIVE_ONE quirk, fq2.rs:211-261)
+    comp = O.encode_points(2, g2, True)
+    rc, err, back = O.decode_points(2, comp, compressed=True, checked=True)
+    assert rc == 0 and np.array_equal(back, g2)
+
+
+@pytest.mark.gpu
+def test_device_against_eip196_and_eip197(zk, worker):
+    """The same outside vectors through the product: per-point batch_exp (phase2/src/parameters.rs:423-470 shape) on the ecMul
+    cases incl. the unreduced scalar q - 1, multiexp on the ecMul bases and on ecAdd's inputs with exponent one, the device
+    decoders on the EIP-197 bytes, r * B1 = infinity in G2."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)  # noqa: E731
+    names = ("chfast1", "chfast2", "chfast3")
+    bases = np.stack([_g1_raw(*_words(MUL[n][0])[:2]) for n in names])
+    scalars = np.stack([_limbs(_words(MUL[n][0])[2]) for n in names])
+    want = np.stack([_g1_raw(*_words(MUL[n][1])) for n in names])
+    got = zk.ceremony.batch_exp(to_dev(bases), to_dev(scalars), same_scalar=False)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+    # multiexp wants canonical exponents: cases 1 and 3
+    sel = [0, 2]
+    acc = O.G1.add(O.G1.from_affine(want[0]), O.G1.from_affine(want[2]))
+    res = zk.multiexp(worker, (to_dev(bases[sel]), 0), zk.FullDensity(), to_dev(scalars[sel])).wait()
+    assert np.array_equal(O.G1.to_affine(res), O.G1.to_affine(acc))
+    x1, y1, x2, y2 = _words(ADD["chfast1"][0])
+    res = zk.multiexp(worker, (to_dev(np.stack([_g1_raw(x1, y1), _g1_raw(x2, y2)])), 0), zk.FullDensity(), to_dev(np.stack([_limbs(1), _limbs(1)]))).wait()
+    assert np.array_equal(O.G1.to_affine(res), _g1_raw(*_words(ADD["chfast1"][1])))
+    # EIP-197 bytes through the device decoders, then r * P = infinity and (r - 1) * P = -P in both groups
+    raw = np.frombuffer(bytes.fromhex(PAIRING_JEFF1), dtype=np.uint8)
+    g1_bytes = np.stack([raw[0:64], raw[192:256]])
+    g2_bytes = np.stack([raw[64:192], raw[256:384]])
+    for group, data in ((1, g1_bytes), (2, g2_bytes)):
+        pts = zk.ceremony.decode_points(torch.from_numpy(data.copy()).to(dev), group, False, True)
+        rc, _, want_pts = O.decode_points(group, data, compressed=False, checked=True)
+        assert rc == 0 and np.array_equal(pts.cpu().numpy().view(np.uint64), want_pts)
+        assert np.array_equal(zk.ceremony.encode_points(pts, False).cpu().numpy(), data)
+        r = to_dev(_limbs(M.R_ORDER).reshape(1, 4))
+        assert not zk.ceremony.batch_exp(pts, r, same_scalar=True).cpu().numpy().any()
+        rm1 = to_dev(_limbs(M.R_ORDER - 1).reshape(1, 4))
+        neg = zk.ceremony.batch_exp(pts, rm1, same_scalar=True).cpu().numpy().view(np.uint64)
+        half = 4 * group
+        assert np.array_equal(neg[:, :half], want_pts[:, :half]) and not np.array_equal(neg, want_pts)
