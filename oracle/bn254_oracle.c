@@ -347,6 +347,18 @@ EXPORT int oracle_g2_multiexp(const uint64_t *bases, size_t n_bases, size_t base
 }
 EXPORT uint32_t oracle_multiexp_window_bits(size_t n_scalars) { return g1m_choose_c(n_scalars); }
 
+/* powersoftau::utils::dense_multiexp (powersoftau/src/utils.rs:189-292); `cpus` = num_cpus::get() */
+EXPORT void oracle_g1_dense_multiexp(const uint64_t *bases, const uint64_t *scalars, size_t n, int cpus, uint64_t out_xyz[12]) {
+  g1_jac_t out;
+  g1m_dense_multiexp((const g1_affine_t *)bases, scalars, n, cpus, &out);
+  memcpy(out_xyz, &out, sizeof out);
+}
+EXPORT void oracle_g2_dense_multiexp(const uint64_t *bases, const uint64_t *scalars, size_t n, int cpus, uint64_t out_xyz[24]) {
+  g2_jac_t out;
+  g2m_dense_multiexp((const g2_affine_t *)bases, scalars, n, cpus, &out);
+  memcpy(out_xyz, &out, sizeof out);
+}
+
 /* naive sum_i k_i * P_i via mul_assign (the reference tests' `naive_multiexp`, multiexp.rs:486-499) */
 EXPORT void oracle_g1_naive_multiexp(const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_xyz[12]) {
   g1_jac_t acc; g1_set_zero(&acc);

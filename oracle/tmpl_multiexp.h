@@ -162,3 +162,76 @@ static int MNAME(multiexp)(const M_AFFINE *bases, size_t n_bases, size_t base_of
   free(results); free(rcs); free(err_idx);
   return rc;
 }
+
+/* ---- powersoftau's dense_multiexp (powersoftau/src/utils.rs:189-292): bases.len() == exponents.len(), no Source, no density.
+ * ALL cores work on ONE region at a time: the bases are cut into chunks of n / cpus + 1 (:217), every chunk gets a thread with its
+ * own bucket array (:227) that fills it (zero exponents skipped, exponent one added directly in region 0, :243-258), sums it by
+ * parts (:262-266) and adds its result to the region's sum under a lock (:268-270); the regions are joined as in multiexp_inner
+ * (:276-291: the higher region doubled c times, plus this one).  A base at infinity adds nothing (add_assign_mixed returns at
+ * once for an identity operand, ec.rs:457-459): there is no error path. */
+typedef struct {
+  const M_AFFINE *bases; const uint64_t *exps; size_t lo, hi;
+  uint32_t skip, c; int handle_trivial; M_PROJ acc;
+} MNAME(dense_job_t);
+
+static void *MNAME(dense_worker)(void *arg) {
+  MNAME(dense_job_t) *j = (MNAME(dense_job_t) *)arg;
+  size_t nb = ((size_t)1 << j->c) - 1;
+  M_PROJ *buckets = (M_PROJ *)malloc(nb * sizeof(M_PROJ));
+  for (size_t i = 0; i < nb; ++i) M_SET_ZERO(&buckets[i]);
+  M_PROJ acc;
+  M_SET_ZERO(&acc);
+  for (size_t i = j->lo; i < j->hi; ++i) {
+    const uint64_t *e = j->exps + i * M_SCALAR_LIMBS;
+    if (MNAME(repr_is)(e, 0)) continue;
+    if (MNAME(repr_is)(e, 1)) {
+      if (j->handle_trivial && !M_AFFINE_IS_ZERO(&j->bases[i])) M_ADD_MIXED(&acc, &j->bases[i]);
+    } else {
+      uint64_t d = MNAME(window_digit)(e, j->skip, j->c);
+      if (d && !M_AFFINE_IS_ZERO(&j->bases[i])) M_ADD_MIXED(&buckets[d - 1], &j->bases[i]);
+    }
+  }
+  M_PROJ running;
+  M_SET_ZERO(&running);
+  for (size_t k = nb; k-- > 0;) {
+    M_ADD(&running, &buckets[k]);
+    M_ADD(&acc, &running);
+  }
+  j->acc = acc;
+  free(buckets);
+  return NULL;
+}
+
+static void MNAME(dense_multiexp)(const M_AFFINE *bases, const uint64_t *exps, size_t n, int cpus, M_PROJ *out) {
+  uint32_t c = MNAME(choose_c)(n);  /* utils.rs:199-203: the same rule as multiexp */
+  if (cpus < 1) cpus = 1;
+  size_t chunk = n / (size_t)cpus + 1;
+  size_t n_jobs = (n + chunk - 1) / chunk;
+  if (n_jobs == 0) n_jobs = 1;
+  uint32_t n_regions = (M_NUM_BITS + c - 1) / c;
+  M_PROJ *regions = (M_PROJ *)malloc(n_regions * sizeof(M_PROJ));
+  MNAME(dense_job_t) *jobs = (MNAME(dense_job_t) *)malloc(n_jobs * sizeof(MNAME(dense_job_t)));
+  pthread_t *tid = (pthread_t *)malloc(n_jobs * sizeof(pthread_t));
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    for (size_t t = 0; t < n_jobs; ++t) {
+      size_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+      if (lo > n) lo = n;
+      jobs[t].bases = bases; jobs[t].exps = exps; jobs[t].lo = lo; jobs[t].hi = hi;
+      jobs[t].skip = r * c; jobs[t].c = c; jobs[t].handle_trivial = r == 0;
+      if (n_jobs > 1) pthread_create(&tid[t], NULL, MNAME(dense_worker), &jobs[t]);
+      else MNAME(dense_worker)(&jobs[t]);
+    }
+    M_SET_ZERO(&regions[r]);
+    for (size_t t = 0; t < n_jobs; ++t) {
+      if (n_jobs > 1) pthread_join(tid[t], NULL);
+      M_ADD(&regions[r], &jobs[t].acc);  /* (the reference adds in completion order under a Mutex: the same group element) */
+    }
+  }
+  M_PROJ acc = regions[n_regions - 1];
+  for (uint32_t r = n_regions - 1; r-- > 0;) {
+    for (uint32_t k = 0; k < c; ++k) M_DOUBLE(&acc);
+    M_ADD(&acc, &regions[r]);
+  }
+  *out = acc;
+  free(regions); free(jobs); free(tid);
+}

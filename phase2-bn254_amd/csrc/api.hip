@@ -3,6 +3,7 @@
 // bellman/src/domain.rs:52-99, and the kernel-timing hooks used by bench.py.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -29,9 +30,11 @@ void ntt_release_all();
 int ntt_configure();
 // msm.hip
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
-                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont);
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont,
+                  MsmChunks* chunks);
 int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
-                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont);
+                  const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont,
+                  MsmChunks* chunks);
 int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
@@ -786,9 +789,10 @@ struct DensityPool {
 template <int GROUP>
 int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                   const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0,
-                  uint32_t flags = 0) {
+                  uint32_t flags = 0, MsmChunks* chunks = nullptr) {
+  // chunks != nullptr: the exponents are handed over chunk by chunk while the call runs (msm_host_entry); d_scalars is unused
   t_last_err_index = -1;
-  if (!out_xyz || (n_scalars && !d_scalars) || (n_bases && !d_bases)) return ZK_ERR_BAD_ARGS;
+  if (!out_xyz || (n_scalars && !d_scalars && !chunks) || (n_bases && !d_bases)) return ZK_ERR_BAD_ARGS;
   if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   hipStream_t st = (hipStream_t)stream;
   DensityPlan P;
@@ -814,8 +818,9 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
   }
   long long err_index = -1;
   const bool mont = (flags & MI355ZK_MSM_SCALARS_MONTGOMERY) != 0;
-  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont);
-  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont);
+  if (chunks && (chunks->n_chunks == 0 || chunks->cuts[chunks->n_chunks] != n)) return ZK_ERR_BAD_ARGS;
+  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont, chunks);
+  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont, chunks);
   if (rc == ZK_ERR_UNEXPECTED_IDENTITY) {
     // the kernels report the lowest BASE index that was the identity under a non-zero exponent; the exponent that owns it
     // is the (index - base_offset)-th selected one (source.rs:101-118): itself under FullDensity
@@ -1070,8 +1075,8 @@ void host_entry_release_all() {
   }
 }
 
-constexpr uint64_t HOST_CHUNK = 1ull << 24;      // exponents per chunk of a streamed call whose bases are already on the device
-constexpr uint64_t HOST_CHUNK_MIN = 1ull << 22;  // first chunk of a call whose bases are cached; below 2 of these the call is not cut
+constexpr uint64_t HOST_CHUNK_UPLOAD = 1ull << 23;  // exponents per chunk of a streamed call whose bases travel too (link-bound)
+constexpr uint64_t HOST_CHUNK_MIN = 1ull << 21;     // smallest first chunk of a call whose bases are on the device; below 4 of these the call is not cut
 
 template <int GROUP>
 int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
@@ -1081,7 +1086,6 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   constexpr size_t bsz = GROUP == 1 ? 64 : 128;
   constexpr size_t jac_words = GROUP == 1 ? 12 : 24;
-  using Jac = typename std::conditional<GROUP == 1, G1Jacobian, G2Jacobian>::type;
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
   StageLease stage_lease;
@@ -1108,7 +1112,7 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
     return r;
   };
 
-  // ---- bases: cached, being cached by this call, or (cache off / full) the leased stage's buffer
+  // ---- bases: cached, being cached by this call, or (not pinned / cache off / full) the leased stage's buffer
   bool fill = false;
   std::shared_ptr<BasesEntry> entry = n_bases ? bases_lookup(bases, n_bases, GROUP, n_bases * bsz, dev, &fill) : nullptr;
   void* d_bases = entry ? entry->d : nullptr;
@@ -1130,25 +1134,33 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
     }
   } guard{entry, fill};
 
-  // ---- chunks (cut at multiples of 32 exponents, so that density words are not shared between chunks)
+  // ---- chunks (cut at multiples of 32 exponents, so that density words are not shared between chunks).  Every chunk runs digits ->
+  // partition -> accumulate into the ONE bucket array of the call (msm_device, MsmChunks); what a chunk costs on top of its share
+  // of the work is the re-partition of the bucket bounds and one read + write of every bucket record it touches (~1.3 ms at 2^26).
   std::vector<uint64_t> cuts{0};
-  if (n >= 2 * HOST_CHUNK_MIN) {
-    // Bases travelling too (96 B per exponent): the link is the bottleneck; even chunks of 2^24 -- small ones were measured and
-    // lose (16 chunks of 2^22: 243 ms for 2^26 against 137 ms with four: pageable copies of 100-MB pieces run far below the link
-    // rate).  Bases cached: the kernels are the bottleneck and a multiexp is the more efficient the larger it is (2^22: 65 % of the
-    // 2^26 rate, 2^24: 90 %), so the chunks DOUBLE: a small one gets the device going, and each chunk's upload hides behind the
-    // previous chunk's kernels (the link moves a chunk in half the time the kernels need for one of half the size).
+  static const char* env_grow = std::getenv("MI355ZK_HOST_CHUNK_GROWTH");  // percent, default 180
+  static const char* env_first = std::getenv("MI355ZK_HOST_CHUNK_FIRST");  // log2 of the first chunk (bases on the device)
+  if (n >= 4 * HOST_CHUNK_MIN) {
     if (upload_bases) {
-      uint64_t k = (n + HOST_CHUNK - 1) / HOST_CHUNK;
+      // Bases travelling too (96 B per exponent): the link is the bottleneck and the kernels of a chunk finish long before the
+      // next one has arrived; even chunks, small enough that the last one's kernels are a short tail behind the last byte.
+      uint64_t k = (n + HOST_CHUNK_UPLOAD - 1) / HOST_CHUNK_UPLOAD;
       if (k < 2) k = 2;
       const uint64_t per = ((n + k - 1) / k + 31) & ~31ull;
       for (uint64_t lo = per; lo < n; lo += per) cuts.push_back(lo);
     } else {
-      uint64_t lo = 0, sz = HOST_CHUNK_MIN;
+      // Bases on the device: the kernels are the bottleneck (~1 G exponents/s against ~1.7 G/s of link).  Only the FIRST chunk's
+      // upload is exposed, so it is small; each following chunk may be ~1.8 x the previous one and still arrive before the
+      // kernels of its predecessor are done.
+      const double grow = env_grow && std::atoi(env_grow) >= 100 ? std::atoi(env_grow) / 100.0 : 1.8;
+      uint64_t sz = n / 20 > HOST_CHUNK_MIN ? n / 20 : HOST_CHUNK_MIN;
+      if (env_first && std::atoi(env_first) >= 16 && std::atoi(env_first) <= 30) sz = 1ull << std::atoi(env_first);
+      sz = (sz + 31) & ~31ull;
+      uint64_t lo = 0;
       while (n - lo > sz + sz / 2) {  // the last chunk takes what is left, up to 1.5 x the next size
         lo += sz;
         cuts.push_back(lo);
-        sz <<= 1;
+        sz = ((uint64_t)((double)sz * grow) + 31) & ~31ull;
       }
     }
   }
@@ -1166,21 +1178,63 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
     if (S->sc_bytes < sc_bytes) S->sc_bytes = sc_bytes;
   }
 
-  // the copy thread: for chunk c, scalars -> staging[c & 1] and (when uploading) the bases the chunk consumes; afterwards the
-  // bases outside the consumed range, so that a cache entry is complete.  `freed` counts chunks whose staging may be reused.
-  std::mutex mu;
-  std::condition_variable cv;
-  uint64_t copied = 0, freed = 0;
-  bool copy_failed = false, abort_copy = false;
+  // The copy thread: for chunk c, scalars -> staging[c & 1] and (when uploading) the bases the chunk consumes; afterwards the
+  // bases outside the consumed range, so that a cache entry is complete.  staging[c & 1] is free again once the DIGIT kernel of
+  // chunk c - 2 -- the only reader of a chunk's exponents -- has run: the compute side records an event behind it.
+  struct Feed : MsmChunks {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t copied = 0, digits = 0;          // chunks uploaded / chunks whose digit kernel has been enqueued
+    bool copy_failed = false, abort_copy = false;
+    void* sc[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev;               // ev[c]: recorded behind chunk c's digit kernel
+    int acquire(uint32_t c, hipStream_t, const void** d) override {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return copy_failed || copied > c; });  // (a host-side wait: the earlier chunks' kernels are already queued)
+      if (copy_failed) return ZK_ERR_DEVICE;
+      *d = sc[c & 1];
+      return ZK_OK;
+    }
+    int digits_enqueued(uint32_t c, hipStream_t st) override {
+      ZK_HIP(hipEventRecord(ev[c], st));
+      std::lock_guard<std::mutex> lk(mu);
+      digits = c + 1;
+      cv.notify_all();
+      return ZK_OK;
+    }
+    ~Feed() override {
+      for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+  } feed;
+  feed.n_chunks = (uint32_t)n_chunks;
+  feed.cuts = cuts.data();
+  feed.sc[0] = S->sc[0];
+  feed.sc[1] = S->sc[1];
+  feed.ev.reserve(n_chunks);
+  for (uint64_t c = 0; c < n_chunks; ++c) {
+    hipEvent_t e;
+    ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    feed.ev.push_back(e);
+  }
   const uint64_t b_lo = base_offset < n_bases ? base_offset : n_bases;
+  static const bool trace = std::getenv("MI355ZK_TRACE_HOST") != nullptr;  // timeline of the streamed call on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   auto copy_fn = [&]() {
-    if (hipSetDevice(dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); copy_failed = true; cv.notify_all(); return; }
+    auto fail = [&] { std::lock_guard<std::mutex> lk(feed.mu); feed.copy_failed = true; feed.cv.notify_all(); };
+    if (hipSetDevice(dev) != hipSuccess) { fail(); return; }
     uint64_t b_done = b_lo;  // bases [b_lo, b_done) are on the device
     for (uint64_t c = 0; c < n_chunks; ++c) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return abort_copy || c < freed + 2; });
-        if (abort_copy) return;
+      if (c >= 2) {
+        {
+          std::unique_lock<std::mutex> lk(feed.mu);
+          feed.cv.wait(lk, [&] { return feed.abort_copy || feed.digits >= c - 1; });
+          if (feed.abort_copy) return;
+        }
+        if (hipEventSynchronize(feed.ev[c - 2]) != hipSuccess) { fail(); return; }
+      } else {
+        std::lock_guard<std::mutex> lk(feed.mu);
+        if (feed.abort_copy) return;
       }
       const uint64_t lo = cuts[c], hi = cuts[c + 1];
       hipError_t e = hipMemcpyAsync(S->sc[c & 1], scalars + lo * 4, (hi - lo) * 32, hipMemcpyHostToDevice, S->copy);
@@ -1193,10 +1247,11 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
         }
       }
       if (e == hipSuccess) e = hipStreamSynchronize(S->copy);
-      std::lock_guard<std::mutex> lk(mu);
-      if (e != hipSuccess) { copy_failed = true; cv.notify_all(); return; }
-      copied = c + 1;
-      cv.notify_all();
+      if (e != hipSuccess) { fail(); return; }
+      if (trace) std::fprintf(stderr, "[mi355zk] host entry: chunk %llu (%llu exponents) uploaded at %.2f ms\n", (unsigned long long)c, (unsigned long long)(hi - lo), ms_now());
+      std::lock_guard<std::mutex> lk(feed.mu);
+      feed.copied = c + 1;
+      feed.cv.notify_all();
     }
     if (upload_bases && entry) {  // the rest of the vector (not needed by this call) completes the cache entry
       hipError_t e = hipSuccess;
@@ -1204,62 +1259,45 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
       if (e == hipSuccess && b_done < n_bases)
         e = hipMemcpyAsync((char*)d_bases + b_done * bsz, bases + b_done * bsz, (n_bases - b_done) * bsz, hipMemcpyHostToDevice, S->copy);
       if (e == hipSuccess) e = hipStreamSynchronize(S->copy);
-      std::lock_guard<std::mutex> lk(mu);
-      if (e != hipSuccess) copy_failed = true;
+      if (e != hipSuccess) fail();
     }
   };
 
-  Jac total = Jac::zero();
+  uint64_t result_xyz[jac_words];
+  std::memset(result_xyz, 0, sizeof result_xyz);
   int result = ZK_OK;
   long long err_idx = -1;
+  bool aborted = false;
   if (n_chunks > 0) {
     std::thread copier(copy_fn);
-    for (uint64_t c = 0; c < n_chunks; ++c) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return copy_failed || copied > c; });
-        if (copy_failed) { result = ZK_ERR_DEVICE; break; }
-      }
-      const uint64_t lo = cuts[c], hi = cuts[c + 1];
-      uint64_t part[jac_words];
-      // the chunk is a multiexp of its own: same base vector, source offset advanced by the bases the earlier chunks consumed
-      int crc = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset + rank_of(lo), S->sc[c & 1], hi - lo, density ? density + (lo >> 5) : nullptr,
-                                     density ? hi - lo : 0, (void*)S->compute, part);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        freed = c + 1;
-        cv.notify_all();
-      }
-      if (crc != ZK_OK) {
-        result = crc;
-        err_idx = t_last_err_index >= 0 ? t_last_err_index + (long long)lo : -1;
-        break;
-      }
-      Jac pj;
-      std::memcpy(&pj, part, sizeof pj);
-      jac_add(total, pj);
-    }
+    result = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset, nullptr, n_scalars, density, density_bits, (void*)S->compute, result_xyz, 1, 0, 0,
+                                  &feed);
+    err_idx = t_last_err_index;
+    if (trace) std::fprintf(stderr, "[mi355zk] host entry: result at %.2f ms (%llu chunks)\n", ms_now(), (unsigned long long)n_chunks);
     {
-      std::lock_guard<std::mutex> lk(mu);
-      abort_copy = result != ZK_OK;
-      cv.notify_all();
+      std::lock_guard<std::mutex> lk(feed.mu);
+      // a call that failed before it had taken every chunk leaves the copy thread waiting: release it
+      aborted = result != ZK_OK && result != ZK_ERR_UNEXPECTED_EOF && feed.digits < n_chunks;
+      feed.abort_copy = aborted;
+      feed.cv.notify_all();
     }
     copier.join();
-    if (copy_failed && result == ZK_OK) result = ZK_ERR_DEVICE;
+    if (feed.copy_failed) result = ZK_ERR_DEVICE;
   } else if (upload_bases && entry && n_bases) {
     // nothing to evaluate, but the entry was created: fill it
     hipError_t e = hipMemcpyAsync(d_bases, bases, n_bases * bsz, hipMemcpyHostToDevice, S->copy);
     if (e == hipSuccess) e = hipStreamSynchronize(S->copy);
     if (e != hipSuccess) result = ZK_ERR_DEVICE;
+    if (result == ZK_OK && P.eof_index >= 0) { result = ZK_ERR_UNEXPECTED_EOF; err_idx = P.eof_index; }
+  } else if (P.eof_index >= 0) {
+    result = ZK_ERR_UNEXPECTED_EOF;
+    err_idx = P.eof_index;
   }
-  guard.ok = result != ZK_ERR_DEVICE && !copy_failed && !(fill && abort_copy);  // an aborted streamed upload is incomplete
-  if (result != ZK_OK) {
-    t_last_err_index = err_idx;
-    return result;
-  }
-  std::memcpy(out_xyz, &total, sizeof total);
-  if (P.eof_index >= 0) { t_last_err_index = P.eof_index; return ZK_ERR_UNEXPECTED_EOF; }
-  return ZK_OK;
+  guard.ok = result != ZK_ERR_DEVICE && !feed.copy_failed && !(fill && aborted);  // an aborted streamed upload is incomplete
+  t_last_err_index = err_idx;
+  if (result != ZK_OK && result != ZK_ERR_UNEXPECTED_EOF) return result;
+  std::memcpy(out_xyz, result_xyz, sizeof result_xyz);
+  return result;
 }
 
 int ntt_host(uint64_t* a, uint32_t log_n, int op, const uint64_t* omega) {

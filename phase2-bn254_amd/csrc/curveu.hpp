@@ -172,6 +172,15 @@ ZK_HD XYZZ<Fp<PR>> xyzzu_to_r(const XYZZU<PR>& a) {
   return r;
 }
 
+// record -> bucket accumulator (X, Y: 2^261; ZZ, ZZZ: 2^266): a bucket sum carried from one chunk of a streamed multiexp to the
+// next (msm_impl.hpp: msm_accumulate_kernel<.., CARRY>) is taken up again at the price of two products
+template <class PR>
+ZK_HD XYZZU<PR> xyzzu_from_r(const XYZZ<Fp<PR>>& s) {
+  if (s.is_zero()) return XYZZU<PR>::zero();
+  const FpU<PR> c266 = UPow2<PR, 266>::get();  // v*2^261 * 2^266 / 2^261 = v * 2^266
+  return XYZZU<PR>{u_from_std(s.x), u_from_std(s.y), u_mul(u_from_std(s.zz), c266), u_mul(u_from_std(s.zzz), c266)};  // < p, < p, < 2p, < 2p
+}
+
 template <class PR>
 ZK_HD XYZZU<PR> xyzzr_load(const XYZZ<Fp<PR>>& s) {  // canonical coordinates: < p, N-form; the zero record gives ZZ == 0 limbs
   return XYZZU<PR>{u_from_std(s.x), u_from_std(s.y), u_from_std(s.zz), u_from_std(s.zzz)};
@@ -508,6 +517,12 @@ ZK_HD XYZZ<Fq2> xyzzu_to_r(const XYZZU2& a) {          // bucket accumulator (X,
   r.zz = Fq2{u_to_std_lt2p(u_mul(a.zz.c0, c256)), u_to_std_lt2p(u_mul(a.zz.c1, c256))};
   r.zzz = Fq2{u_to_std_lt2p(u_mul(a.zzz.c0, c256)), u_to_std_lt2p(u_mul(a.zzz.c1, c256))};
   return r;
+}
+ZK_HD XYZZU2 xyzzu_from_r(const XYZZ<Fq2>& s) {          // record -> bucket accumulator (see the G1 form)
+  if (s.is_zero()) return XYZZU2::zero();
+  const FqU c266 = UPow2<FqParams, 266>::get();
+  return XYZZU2{f2u_from_std(s.x), f2u_from_std(s.y), Fq2U{u_mul(u_from_std(s.zz.c0), c266), u_mul(u_from_std(s.zz.c1), c266)},
+                Fq2U{u_mul(u_from_std(s.zzz.c0), c266), u_mul(u_from_std(s.zzz.c1), c266)}};
 }
 ZK_HD XYZZU2 xyzzr_load(const XYZZ<Fq2>& s) {
   return XYZZU2{f2u_from_std(s.x), f2u_from_std(s.y), f2u_from_std(s.zz), f2u_from_std(s.zzz)};

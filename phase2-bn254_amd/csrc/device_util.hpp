@@ -24,6 +24,19 @@
 
 namespace zk {
 
+// A multiexp whose exponents arrive in CHUNKS: the host-buffer entry point (api.hip: msm_host_entry) uploads them over PCIe while
+// the kernels of the earlier chunks run.  msm_device (msm_impl.hpp) evaluates chunk c = exponents [cuts[c], cuts[c+1]) when told
+// where they are, with ONE geometry and ONE bucket array for the whole call.
+struct MsmChunks {
+  uint32_t n_chunks = 0;
+  const uint64_t* cuts = nullptr;  // n_chunks + 1 exponent indices: 0 = cuts[0] < ... < cuts[n_chunks] = n, inner cuts multiples of 32
+  // the device pointer of chunk c's exponents; makes `st` wait (device-side) until they have arrived
+  virtual int acquire(uint32_t c, hipStream_t st, const void** d_scalars) = 0;
+  // the digit kernel of chunk c -- the only reader of its exponents -- has been enqueued on `st`
+  virtual int digits_enqueued(uint32_t c, hipStream_t st) = 0;
+  virtual ~MsmChunks() {}
+};
+
 // Lightweight per-kernel timing used by bench.py's roofline leg: when enabled, the library brackets
 // the named kernels with hipEvents on the launch stream and accumulates their durations.
 struct KernelTimer {

@@ -175,13 +175,16 @@ int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const u
     }
     r = acc;
   } else {
+    // mode 2: the accumulator goes through an R-domain record after every third point (xyzzu_to_r, then xyzzu_from_r): what a
+    // bucket carried across the chunks of a streamed multiexp does
     zk::XYZZU<zk::FqParams> acc = zk::XYZZU<zk::FqParams>::zero();
     for (size_t i = 0; i < n; ++i) {
       zk::G1Affine p;
       std::memcpy(&p, affine_pts + 8 * i, 64);
       zk::xyzzu_add_mixed(acc, p.x, p.y, negate[i] != 0);
+      if (mode == 2 && i % 3 == 2) acc = zk::xyzzu_from_r(zk::xyzzu_to_r(acc));
     }
-    r = zk::xyzzu_to_std(acc);
+    r = mode == 2 ? zk::xyzzr_to_std(zk::xyzzu_to_r(acc)) : zk::xyzzu_to_std(acc);
   }
   std::memcpy(out_xyzz, &r, sizeof r);
   return ZK_OK;
@@ -298,13 +301,14 @@ int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const u
     }
     r = acc;
   } else {
-    zk::XYZZU2 acc = zk::XYZZU2::zero();
+    zk::XYZZU2 acc = zk::XYZZU2::zero();  // mode 2: through a record after every third point (see the G1 hook)
     for (size_t i = 0; i < n; ++i) {
       zk::G2Affine p;
       std::memcpy(&p, affine_pts + 16 * i, 128);
       zk::xyzzu2_add_mixed(acc, p.x, p.y, negate[i] != 0);
+      if (mode == 2 && i % 3 == 2) acc = zk::xyzzu_from_r(zk::xyzzu_to_r(acc));
     }
-    r = zk::xyzzu2_to_std(acc);
+    r = mode == 2 ? zk::xyzzr_to_std(zk::xyzzu_to_r(acc)) : zk::xyzzu2_to_std(acc);
   }
   std::memcpy(out_xyzz, &r, sizeof r);
   return ZK_OK;

@@ -6,10 +6,10 @@ namespace zk {
 
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup,
-                  bool scalars_mont) {
+                  bool scalars_mont, MsmChunks* chunks) {
   G1Jacobian r;
   int rc = msm_device<Fq>((const G1Affine*)d_bases, n_bases, base_offset, (const uint32_t*)d_scalars, n, d_density, d_dprefix, st, &r, err_index,
-                          false, nullptr, nullptr, wgroups, wgroup, scalars_mont);
+                          false, nullptr, nullptr, wgroups, wgroup, scalars_mont, chunks);
   if (rc == ZK_OK) std::memcpy(out_xyz, &r, sizeof r);
   return rc;
 }

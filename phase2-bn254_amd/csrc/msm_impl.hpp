@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
                                                                        const uint32_t* __restrict__ density, MsmGeom G, uint32_t w_lo,
                                                                        uint32_t w_hi, int scalars_mont, PartGeom P, uint64_t kstride,
                                                                        uint32_t* __restrict__ keys, uint16_t* __restrict__ tile_hist,
-                                                                       unsigned long long* __restrict__ err_scalar) {
+                                                                       unsigned long long* __restrict__ err_scalar, uint64_t i_bias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // counters are 16 bits wide (a super-tile has at most 16384 scalars), two per LDS word: half the LDS, two workgroups per CU,
   // and the dump below is a plain copy (little endian: even cell = low half)
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
       if (active && (s[7] >> 30)) {
         // not a canonical FrRepr (r < 2^254): its top digit would overflow the bucket field of the key.  Reported as bad
         // arguments (the lowest such exponent index), the exponent is skipped.
-        atomicMin(err_scalar, (unsigned long long)i);
+        atomicMin(err_scalar, (unsigned long long)(i + i_bias));
         active = false;
       }
       if (!active || any == 0) {  // multiexp.rs:93-96: zero exponent skips its base without looking at it
@@ -461,7 +461,8 @@ __global__ void __launch_bounds__(PART_THREADS) msm_digits_hist_kernel(const uin
 template <uint32_t RM>
 __global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* __restrict__ scalars, uint64_t n, const uint32_t* __restrict__ density,
                                                               MsmGeom G, uint32_t w_lo, uint32_t w_hi, int scalars_mont, uint64_t kstride,
-                                                              uint32_t* __restrict__ keys, unsigned long long* __restrict__ err_scalar) {
+                                                              uint32_t* __restrict__ keys, unsigned long long* __restrict__ err_scalar,
+                                                              uint64_t i_bias /* index of exponent 0 of this chunk in the whole call */) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t WL = w_hi - w_lo;
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* _
   }
   const uint32_t any = s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7];
   if (active && (s[7] >> 30)) {   // not a canonical FrRepr: see msm_digits_hist_kernel
-    atomicMin(err_scalar, (unsigned long long)i);
+    atomicMin(err_scalar, (unsigned long long)(i + i_bias));
     active = false;
   }
   if (!active || any == 0) {
@@ -1039,67 +1040,63 @@ __host__ __device__ __forceinline__ XYZZ<F> rec_to_std(const XYZZ<F>& r) { retur
 // lists the partition writes): a lane reads its indices FOUR AT A TIME with one 16-byte load.  Read one by
 // one, a lane touches each 128-byte line of its list 32 times, ~10^4 instructions apart, and by then the line has usually
 // left the caches (64 lanes x 16 waves x 32 CUs share an L2 that 52 GB of bases stream through): 8 touches instead of 32.
+template <class F>
+struct BucketAcc { using type = XYZZU<FqParams>; };
+template <>
+struct BucketAcc<Fq2> { using type = XYZZU2; };
+
+// acc += the signed points of one index list.  The accumulator is the caller's: zero for a fresh bucket, xyzzu_from_r(record)
+// for a bucket carried from an earlier chunk of a streamed multiexp (msm_accumulate_kernel<.., CARRY>).
 template <class F, bool A4 = false>
-__device__ __forceinline__ XYZZ<F> accumulate_run(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
-                                                  uint32_t stride, bool skip_zero, unsigned long long* __restrict__ err_base) {
+__device__ __forceinline__ typename BucketAcc<F>::type accumulate_run(typename BucketAcc<F>::type acc, const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                               uint32_t j, uint32_t e, uint32_t stride, bool skip_zero, unsigned long long* __restrict__ err_base) {
   // the all-zero record is the point at infinity (no curve point has y == 0).  skip_zero (dense mode, powersoftau's
   // dense_multiexp): it adds nothing.  Otherwise it is the reference's UnexpectedIdentity (source.rs:50-52: a selected base
   // with a non-zero exponent): the lowest such BASE index is reported and the record skipped.
-  if constexpr (std::is_same<F, Fq>::value) {
-    XYZZU<FqParams> acc = XYZZU<FqParams>::zero();
-    if (j >= e) return XYZZ<F>::zero();
-    // The gather of point k+1 is issued, as four back-to-back 16-byte loads, before the ~2200 ALU instructions of
-    // addition k: the four loads of a record then hit the same 128-byte line while it is still in cache (left to the
-    // scheduler they drift apart to their uses and the line is fetched more than once: +22 % HBM traffic).
-    // A4: this group of four indices, rotated so that q.x is the current one.  (A second group loaded one step ahead was
-    // measured too: it costs four more VGPRs -- 129, one over the 128 that allow four waves per SIMD.)
-    uint4 q = make_uint4(0, 0, 0, 0);
-    uint32_t v;
-    if constexpr (A4) {
-      q = *reinterpret_cast<const uint4*>(vals + j);
-      v = q.x;
-    } else {
-      v = vals[j];
-    }
-    Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
-    for (;;) {
-      const uint32_t jn = j + stride;
-      const bool more = jn < e;
-      uint32_t vn = 0;
-      Affine<F> pn = p;
-      if constexpr (A4) {
-        if ((jn & 3u) == 0) {  // uniform over the wave: every lane started on a multiple of 4
-          if (more) q = *reinterpret_cast<const uint4*>(vals + jn);
-        } else {
-          q.x = q.y; q.y = q.z; q.z = q.w;
-        }
-        vn = q.x;
-        if (more) pn = load_affine(bases + (vn & ~SIGN_BIT));
-      } else if (more) {
-        vn = vals[jn];
-        pn = load_affine(bases + (vn & ~SIGN_BIT));
-      }
-      if (!p.y.is_zero()) xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
-      else if (!skip_zero) atomicMin(err_base, (unsigned long long)(v & ~SIGN_BIT));
-      if (!more) break;
-      v = vn;
-      p = pn;
-      j = jn;
-    }
-    return xyzzu_to_r(acc);  // an R-domain record (curveu.hpp): what every consumer of G1 bucket sums below works on
+  // (precondition: j < e -- the callers deal with an empty list before they set an accumulator up)
+  // The gather of point k+1 is issued, as back-to-back 16-byte loads, before the ~2200 (G2: ~7000) ALU instructions of
+  // addition k: the loads of a record then hit the same 128-byte line while it is still in cache (left to the
+  // scheduler they drift apart to their uses and the line is fetched more than once: +22 % HBM traffic).
+  // A4: this group of four indices, rotated so that q.x is the current one.  (A second group loaded one step ahead was
+  // measured too: it costs four more VGPRs -- 129, one over the 128 that allow four waves per SIMD.)
+  uint4 q = make_uint4(0, 0, 0, 0);
+  uint32_t v;
+  if constexpr (A4) {
+    q = *reinterpret_cast<const uint4*>(vals + j);
+    v = q.x;
   } else {
-    XYZZU2 acc = XYZZU2::zero();
-    for (; j < e; j += stride) {
-      uint32_t v = vals[j];
-      Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
-      if (p.y.is_zero()) {
-        if (!skip_zero) atomicMin(err_base, (unsigned long long)(v & ~SIGN_BIT));
-        continue;
-      }
-      xyzzu2_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
-    }
-    return xyzzu_to_r(acc);
+    v = vals[j];
   }
+  Affine<F> p = load_affine(bases + (v & ~SIGN_BIT));
+  for (;;) {
+    const uint32_t jn = j + stride;
+    const bool more = jn < e;
+    uint32_t vn = 0;
+    Affine<F> pn = p;
+    if constexpr (A4) {
+      if ((jn & 3u) == 0) {  // uniform over the wave: every lane started on a multiple of 4
+        if (more) q = *reinterpret_cast<const uint4*>(vals + jn);
+      } else {
+        q.x = q.y; q.y = q.z; q.z = q.w;
+      }
+      vn = q.x;
+      if (more) pn = load_affine(bases + (vn & ~SIGN_BIT));
+    } else if (more) {
+      vn = vals[jn];
+      pn = load_affine(bases + (vn & ~SIGN_BIT));
+    }
+    if (!p.y.is_zero()) {
+      if constexpr (std::is_same<F, Fq>::value) xyzzu_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+      else xyzzu2_add_mixed(acc, p.x, p.y, (v & SIGN_BIT) != 0);
+    } else if (!skip_zero) {
+      atomicMin(err_base, (unsigned long long)(v & ~SIGN_BIT));
+    }
+    if (!more) break;
+    v = vn;
+    p = pn;
+    j = jn;
+  }
+  return acc;
 }
 
 // 4a. heavy buckets (longer than `heavy`: skewed scalars such as the many 0/1 witnesses of a Groth16 prover --
@@ -1143,7 +1140,11 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
     const uint32_t b = order[lo];
     const uint32_t j0 = first[b] + (item - item_off[lo]) * seg;
     const uint32_t e = j0 + seg < last[b] ? j0 + seg : last[b];
-    sh[threadIdx.x] = accumulate_run<F>(bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0, err_base);
+    if (j0 + threadIdx.x < e) {
+      sh[threadIdx.x] = xyzzu_to_r(accumulate_run<F>(BucketAcc<F>::type::zero(), bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0, err_base));  // an R-domain record (curveu.hpp): what every consumer of bucket sums below works on
+    } else {
+      sh[threadIdx.x] = XYZZ<F>::zero();
+    }
     __syncthreads();
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
       if (threadIdx.x < s) {
@@ -1161,7 +1162,8 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
 // bucket = sum of its segment sums (one workgroup per heavy bucket)
 template <class F>
 __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __restrict__ seg_sums, const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ item_off, uint32_t hb, XYZZ<F>* __restrict__ buckets) {
+                                                              const uint32_t* __restrict__ item_off, uint32_t hb, XYZZ<F>* __restrict__ buckets,
+                                                              int carry) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   for (uint32_t i = blockIdx.x; i < hb; i += gridDim.x) {
@@ -1179,14 +1181,20 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) store_vec(buckets + order[i], sh[0]);
+    if (threadIdx.x == 0) {
+      XYZZ<F> sum = sh[0];
+      if (carry) rec_add(sum, load_vec(buckets + order[i]));  // the bucket's sum over the earlier chunks
+      store_vec(buckets + order[i], sum);
+    }
     __syncthreads();
   }
 }
 
 // 4b. one lane per bucket, buckets taken in size order.  Both groups run on U-form arithmetic (curveu.hpp:
 //     29-bit lazy limbs, one v_mad_u64_u32 per partial product, no carry flags).
-template <class F, bool A4>
+//     CARRY: the launch continues buckets that an earlier chunk of the same (streamed) multiexp has written: a bucket without
+//     entries in this chunk is left alone, the others take their record up again (xyzzu_from_r: two products).
+template <class F, bool A4, bool CARRY>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                             const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
                                                             const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
@@ -1196,7 +1204,13 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
   if (i < hb && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
-  store_vec(buckets + b, accumulate_run<F, A4>(bases, vals, j, e, 1, skip_zero != 0, err_base));
+  if (j >= e) {
+    if constexpr (!CARRY) store_vec(buckets + b, XYZZ<F>::zero());
+    return;
+  }
+  typename BucketAcc<F>::type acc = BucketAcc<F>::type::zero();
+  if constexpr (CARRY) acc = xyzzu_from_r(load_vec(buckets + b));
+  store_vec(buckets + b, xyzzu_to_r(accumulate_run<F, A4>(acc, bases, vals, j, e, 1, skip_zero != 0, err_base)));
 }
 
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
@@ -1518,12 +1532,17 @@ template <class F>
 int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n,
                const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out,
                bool dense = false, const Affine<F>* d_bases2 = nullptr, Jacobian<F>* out2 = nullptr, uint32_t wgroups = 1,
-               uint32_t wgroup = 0, bool scalars_mont = false) {
+               uint32_t wgroup = 0, bool scalars_mont = false, MsmChunks* chunks = nullptr) {
   // wgroups > 1: only window group `wgroup` of `wgroups` equal groups is evaluated -- the partial  sum_{w in group} B^w T_w
   // of this point set; the partials of all groups (and of all point ranges) add up to the multiexp (shard.py).
   // dense == true: powersoftau's dense_multiexp contract (infinity bases add nothing, no Source errors);
   // d_bases2 != nullptr: a second base vector evaluated with the SAME exponents (merge_pairs), sharing the
   // digit extraction and the sorts.
+  // chunks != nullptr: a STREAMED multiexp (the host-buffer entry point uploads the exponents while the kernels run).  The
+  // exponents [cuts[c], cuts[c+1]) of chunk c are taken from the pointer chunks->acquire(c) hands out; geometry and bucket array
+  // are those of the WHOLE call: every chunk runs digits -> partition -> accumulate into the SAME buckets (the first chunk
+  // writes them, the others carry them on), and the reduction and the join run once.  d_scalars is ignored, d_density /
+  // d_dprefix cover the whole call.
   *out = Jacobian<F>::zero();
   if (out2) *out2 = Jacobian<F>::zero();
   *err_index_out = -1;
@@ -1532,11 +1551,21 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
   if (wgroups == 0 || wgroup >= wgroups) return ZK_ERR_BAD_ARGS;
+  const uint64_t whole[2] = {0, n};
+  const uint32_t n_chunks = chunks ? chunks->n_chunks : 1u;
+  const uint64_t* cuts = chunks ? chunks->cuts : whole;
+  if (n_chunks == 0 || cuts[0] != 0 || cuts[n_chunks] != n) return ZK_ERR_BAD_ARGS;
+  if (n_chunks > 1 && d_bases2 != nullptr) return ZK_ERR_BAD_ARGS;
+  uint64_t n_max = 0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    if (cuts[c + 1] <= cuts[c] || (c > 0 && (cuts[c] & 31))) return ZK_ERR_BAD_ARGS;  // (density words are not shared between chunks)
+    if (cuts[c + 1] - cuts[c] > n_max) n_max = cuts[c + 1] - cuts[c];
+  }
   const MsmGeom G = choose_geom(n, (int)(sizeof(F) / sizeof(Fq)), wgroups);
   if (G.W == 0 || G.W % wgroups) return ZK_ERR_BAD_ARGS;
   const uint32_t WL = G.W / wgroups, w_lo = wgroup * WL, w_hi = w_lo + WL;  // this call's windows
-  const uint64_t m = n * WL;
-  if (m > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
+  const uint64_t m_max = n_max * WL;
+  if (m_max > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
   const uint32_t n_buckets = WL * G.nb;
   // reduction: running-sum levels (msm_reduce_level_kernel, chunk length L) while more than MSM_FINAL_MAX
   // elements per window are left, then the bit-decomposition stage (msm_tree_kernel)
@@ -1557,49 +1586,68 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t final_bits = 1;
   while ((1u << final_bits) <= final_cnt - 1 + final_off) ++final_bits;
 
-  const PartGeom P = choose_part(n, WL, G.nb);
-  const uint64_t kstride = (n + 3) & ~3ull;  // distance between the key planes of two windows
-  if (P.st == 0) return ZK_ERR_BAD_ARGS;
-  const uint32_t ncell = WL * P.nbin;
-  // index lists: every bucket start is padded to a multiple of 4 entries (<= 3 per bucket), every bin region to 4
-  const uint64_t vals_cap = m + 3ull * n_buckets + 4ull * ncell + 4;
-  if (vals_cap > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;
-
+  // per chunk: its partition geometry, and what one lane may walk before its bucket counts as heavy
+  struct ChunkPlan {
+    uint64_t lo, n, m;
+    PartGeom P;
+    uint32_t ncell, heavy, heavy_seg, hb, max_items;
+  };
+  std::vector<ChunkPlan> plan(n_chunks);
+  uint64_t keys_cap = 0, tile_hist_b = 0, tile_off_b = 0, csum_b = 0;
+  uint32_t ncell_max = 0, hb_max = 0, items_max = 0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    ChunkPlan& C = plan[c];
+    C.lo = cuts[c];
+    C.n = cuts[c + 1] - cuts[c];
+    C.m = C.n * WL;
+    C.P = choose_part(C.n, WL, G.nb);
+    if (C.P.st == 0) return ZK_ERR_BAD_ARGS;
+    C.ncell = WL * C.P.nbin;
+    // index lists: every bucket start is padded to a multiple of 4 entries (<= 3 per bucket), every bin region to 4
+    const uint64_t vals_cap = C.m + 3ull * n_buckets + 4ull * C.ncell + 4;
+    if (vals_cap > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;
+    keys_cap = std::max(keys_cap, vals_cap);
+    tile_hist_b = std::max<uint64_t>(tile_hist_b, (uint64_t)C.P.n_st * ((C.ncell + 1) & ~1u) * 2);
+    tile_off_b = std::max<uint64_t>(tile_off_b, (uint64_t)C.P.n_st * C.ncell * 4);
+    csum_b = std::max<uint64_t>(csum_b, (uint64_t)C.P.n_chunk * C.ncell * 4);
+    ncell_max = std::max(ncell_max, C.ncell);
+    // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
+    // ... and, more to the point, when ONE lane walking it would outlast the whole launch: the lanes of a launch share ~2^18 lane
+    // slots (256 CUs x 4 SIMDs x 4 waves x 64), so a launch lasts about m / 2^18 additions per slot; a longer bucket is a straggler
+    // (it starts first -- buckets run in size order -- but finishes alone).  Prover-like exponents produce such buckets by the
+    // hundred (every byte-sized witness value lands in one of 255 buckets of window 0).
+    // Short calls are latency-bound instead: a lane adds a point to its bucket every ~8 us whatever else the device does (ten
+    // dependent field products), so a bucket of 100 entries among buckets of 6 holds the launch for 0.8 ms (measured at 2^18
+    // prover-like exponents: the 255 byte-valued buckets of window 0).  Hence a floor of 64, a margin of 16 over twice the mean,
+    // and segments short enough (heavy_seg) that a segment's 64 lanes add a handful of points each before the tree.
+    const uint64_t mean_len = C.n / G.nb + 1;
+    uint64_t heavy64 = mean_len * 8 + 1024;
+    const uint64_t heavy_cap = (C.m >> 17) > 64 ? (C.m >> 17) : 64;  // 8 us per entry against ~2^-17 x m x 8 us for the launch at full throughput
+    if (heavy64 > heavy_cap) heavy64 = heavy_cap;
+    if (heavy64 < 2 * mean_len + 16) heavy64 = 2 * mean_len + 16;   // never the ordinary buckets
+    C.heavy = (uint32_t)(heavy64 > 0xffffffffull ? 0xffffffffull : heavy64);
+    C.heavy_seg = 128;
+    while (C.heavy_seg < MSM_HEAVY_SEG && ((uint64_t)C.heavy_seg << 14) < C.m) C.heavy_seg <<= 1;
+    C.hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
+    if ((uint64_t)C.hb > C.m / C.heavy + 1) C.hb = (uint32_t)(C.m / C.heavy + 1);
+    C.max_items = (uint32_t)(C.m / C.heavy_seg) + C.hb;  // every heavy bucket adds at most one partial segment
+    hb_max = std::max(hb_max, C.hb);
+    items_max = std::max(items_max, C.max_items);
+  }
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   // the window-major keys of pass A are dead once pass B has run; pass C writes the index lists over them
-  size_t o_keys = take((size_t)vals_cap * 4), o_pairs = take((size_t)m * 8);
-  size_t o_tile_hist = take((size_t)P.n_st * ((ncell + 1) & ~1u) * 2), o_tile_off = take((size_t)P.n_st * ncell * 4);
-  size_t o_csum = take((size_t)P.n_chunk * ncell * 4), o_total = take((size_t)ncell * 4);
-  size_t o_bin_start = take((size_t)(ncell + 1) * 4), o_out_start = take((size_t)(ncell + 1) * 4);
+  size_t o_keys = take((size_t)keys_cap * 4), o_pairs = take((size_t)m_max * 8);
+  size_t o_tile_hist = take((size_t)tile_hist_b), o_tile_off = take((size_t)tile_off_b);
+  size_t o_csum = take((size_t)csum_b), o_total = take((size_t)ncell_max * 4);
+  size_t o_bin_start = take((size_t)(ncell_max + 1) * 4), o_out_start = take((size_t)(ncell_max + 1) * 4);
   // big bins (msm_bigbin_*): per-bucket counts and cursors (contiguous: one memset), the list of big bins, the plan
   size_t o_gcnt = take((size_t)n_buckets * 4), o_gcur = take((size_t)n_buckets * 4);
-  size_t o_big_col = take((size_t)ncell * 4), o_big_seg = take((size_t)ncell * 4), o_big_plan = take(sizeof(BigPlan));
+  size_t o_big_col = take((size_t)ncell_max * 4), o_big_seg = take((size_t)ncell_max * 4), o_big_plan = take(sizeof(BigPlan));
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
   size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
-  // a bucket is "heavy" when it is far longer than the mean; at most m / heavy buckets can be
-  // ... and, more to the point, when ONE lane walking it would outlast the whole launch: the lanes of a launch share ~2^18 lane
-  // slots (256 CUs x 4 SIMDs x 4 waves x 64), so a launch lasts about m / 2^18 additions per slot; a longer bucket is a straggler
-  // (it starts first -- buckets run in size order -- but finishes alone).  Prover-like exponents produce such buckets by the
-  // hundred (every byte-sized witness value lands in one of 255 buckets of window 0).
-  // Short calls are latency-bound instead: a lane adds a point to its bucket every ~8 us whatever else the device does (ten
-  // dependent field products), so a bucket of 100 entries among buckets of 6 holds the launch for 0.8 ms (measured at 2^18
-  // prover-like exponents: the 255 byte-valued buckets of window 0).  Hence a floor of 64, a margin of 16 over twice the mean,
-  // and segments short enough (heavy_seg) that a segment's 64 lanes add a handful of points each before the tree.
-  const uint64_t mean_len = n / G.nb + 1;
-  uint64_t heavy64 = mean_len * 8 + 1024;
-  const uint64_t per_slot = m >> 18;
-  const uint64_t heavy_cap = (m >> 17) > 64 ? (m >> 17) : 64;  // 8 us per entry against ~2^-17 x m x 8 us for the launch at full throughput
-  if (heavy64 > heavy_cap) heavy64 = heavy_cap;
-  if (heavy64 < 2 * mean_len + 16) heavy64 = 2 * mean_len + 16;   // never the ordinary buckets
-  const uint32_t heavy = (uint32_t)(heavy64 > 0xffffffffull ? 0xffffffffull : heavy64);
-  uint32_t heavy_seg = 128;
-  while (heavy_seg < MSM_HEAVY_SEG && ((uint64_t)heavy_seg << 14) < m) heavy_seg <<= 1;
-  uint32_t hb = n_buckets < MSM_HEAVY_BLOCKS ? n_buckets : MSM_HEAVY_BLOCKS;
-  if ((uint64_t)hb > m / heavy + 1) hb = (uint32_t)(m / heavy + 1);
-  const uint32_t max_items = (uint32_t)(m / heavy_seg) + hb;  // every heavy bucket adds at most one partial segment
-  size_t o_item_off = take((size_t)(hb + 1) * 4);
-  size_t o_seg_sums = take((size_t)max_items * sizeof(XYZZ<F>));
+  size_t o_item_off = take((size_t)(hb_max + 1) * 4);
+  size_t o_seg_sums = take((size_t)items_max * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
   size_t o_partA = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
   size_t o_partS = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
@@ -1654,123 +1702,155 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   unsigned long long* d_err = (unsigned long long*)(ws + o_err);
 
   ZK_HIP(hipMemsetAsync(d_err, 0xff, 16, st));
-  ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
-  ZK_HIP(hipMemsetAsync(gcnt, 0, o_big_col - o_gcnt, st));  // gcnt and gcur
+  lease.idle = false;
 
   static const bool debug = std::getenv("MI355ZK_DEBUG") != nullptr;
-  auto checkpoint = [&](const char* what) -> int {
+  auto checkpoint = [&](const char* what, const ChunkPlan& C) -> int {
     if (!debug) return 0;
     ZK_HIP(hipStreamSynchronize(st));
-    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu c=%u W=%u buckets=%u levels=%u part(lo=%u nbin=%u st=%u): %s done\n",
-                 (int)(sizeof(F) / sizeof(Fq)), (unsigned long long)n, G.c, WL, n_buckets, n_levels, P.lo_bits, P.nbin, P.st, what);
+    std::fprintf(stderr, "[mi355zk] msm<%d> n=%llu chunk@%llu+%llu c=%u W=%u buckets=%u levels=%u part(lo=%u nbin=%u st=%u): %s done\n",
+                 (int)(sizeof(F) / sizeof(Fq)), (unsigned long long)n, (unsigned long long)C.lo, (unsigned long long)C.n, G.c, WL, n_buckets,
+                 n_levels, C.P.lo_bits, C.P.nbin, C.P.st, what);
     return 0;
   };
   static const int slot_digits = prof_slot("msm_digits"), slot_scan = prof_slot("msm_part_scan"), slot_scatter = prof_slot("msm_scatter"),
                    slot_bucket = prof_slot("msm_bucket"), slot_sort = prof_slot("msm_sort"), slot_acc = prof_slot("msm_accumulate"),
                    slot_heavy = prof_slot("msm_accumulate_heavy"), slot_red = prof_slot("msm_reduce");
 
-  // "msm_sort" spans the whole partition after the digits (scan + scatter + bucket + size order), as it did for the library sort
-  prof_begin(slot_digits, st);
-  static const bool fused_a = std::getenv("MI355ZK_PART_FUSED_A") != nullptr;  // (the one-kernel pass A, kept for the comparison in DESIGN.md)
-  if (!fused_a) {
-    ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_plain_kernel<RM>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, d_density, G,
-                                                w_lo, w_hi, scalars_mont ? 1 : 0, kstride, keys, d_err + 1));
-    hipLaunchKernelGGL(msm_tile_hist_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)P.nbin * 4, st, keys, n, kstride, G.nb, WL, P, tile_hist);
-  } else {
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t per_cu = (size_t)((ncell + 1) / 2) * 4 <= PART_LDS_A ? 2u : 1u;     // 1024-lane workgroups per CU (LDS histograms)
-    const uint32_t grid = P.n_st < per_cu * (uint32_t)cus ? P.n_st : per_cu * (uint32_t)cus;
-    ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_hist_kernel<RM>, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_scalars, n,
-                                                d_density, G, w_lo, w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist, d_err + 1));
-  }
-  ZK_HIP(hipGetLastError());
-  prof_end(slot_digits, st);
-  if (checkpoint("digits")) return ZK_ERR_DEVICE;
-
-  prof_begin(slot_sort, st);
-  prof_begin(slot_scan, st);
-  hipLaunchKernelGGL(msm_colsum_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, P, ncell, csum);
-  hipLaunchKernelGGL(msm_colscan_kernel, dim3((ncell + 255) / 256), dim3(256), 0, st, csum, P, ncell, col_total);
-  hipLaunchKernelGGL(msm_binscan_kernel, dim3(1), dim3(PART_THREADS), 0, st, col_total, P, ncell, G.nb, bin_start, out_start);
-  hipLaunchKernelGGL(msm_tileoff_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, csum, bin_start, P, ncell, tile_off);
-  ZK_HIP(hipGetLastError());
-  prof_end(slot_scan, st);
-  prof_begin(slot_scatter, st);
-  {
-    static const char* env_x = std::getenv("MI355ZK_PART_XCDS");  // 1 disables the XCD-aware tile order
-    const uint32_t xcds = env_x && std::atoi(env_x) >= 1 ? (uint32_t)std::atoi(env_x) : 8u;
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)(2 * ((P.nbin + 3u) & ~3u) + 32) * 4 + (size_t)P.st * 8, st,
-                       keys, n, kstride, base_offset, d_density, d_dprefix, G.nb, WL, P, xcds, tile_off, pairs);
-  }
-  ZK_HIP(hipGetLastError());
-  prof_end(slot_scatter, st);
-  if (checkpoint("scatter")) return ZK_ERR_DEVICE;
-  prof_begin(slot_bucket, st);
-  {
-    const uint32_t nfl = (1u << P.lo_bits) < 4 ? 4 : (1u << P.lo_bits);
-    const size_t fixed = (size_t)(2 * nfl + 32) * 4;
-    // staging for the expected bin population with slack, at most what the CU has
-    uint64_t want = (uint64_t)(n / P.nbin) * 5 / 4 + 3ull * nfl + 4096;
-    const uint64_t cap_max = (PART_LDS_MAX - fixed) / 4;
-    if (want > cap_max) want = cap_max;
-    if (want > (uint64_t)PART_EC * PART_THREADS + 3ull * nfl) want = (uint64_t)PART_EC * PART_THREADS + 3ull * nfl;
-    const uint32_t stage_cap = (uint32_t)want & ~3u;
-    hipLaunchKernelGGL(msm_bucket_kernel, dim3(ncell), dim3(PART_THREADS), fixed + (size_t)stage_cap * 4, st, pairs, bin_start, out_start, G.nb, P,
-                       stage_cap, first, last, vals_b);
-    // the big bins (none for uniform exponents up to 2^26 points: the surplus workgroups of these launches exit at once)
-    const uint32_t max_seg = (uint32_t)(2 * (m / BIG_SEG) + 2);
-    hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
-    // (small grids: when there is no big bin -- uniform exponents -- the launches only cost their workgroups' start-up, and the
-    // place kernel's LDS allows one workgroup per CU anyway)
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t big_grid = max_seg < 2u * (uint32_t)n_cu ? max_seg : 2u * (uint32_t)n_cu;
-    const uint32_t place_grid = max_seg < (uint32_t)n_cu ? max_seg : (uint32_t)n_cu;
-    hipLaunchKernelGGL(msm_bigbin_count_kernel, dim3(big_grid), dim3(PART_THREADS), (size_t)nfl * 4, st, pairs, bin_start, big_plan, big_col, big_seg,
-                       G.nb, P, gcnt);
-    const size_t place_fixed = (size_t)(4 * nfl + 32) * 4, place_staged = place_fixed + (size_t)BIG_SEG * 4;
-    const int staged = place_staged <= PART_LDS_MAX ? 1 : 0;
-    hipLaunchKernelGGL(msm_bigbin_place_kernel, dim3(staged ? place_grid : big_grid), dim3(PART_THREADS), staged ? place_staged : place_fixed, st, pairs, bin_start, out_start,
-                       big_plan, big_col, big_seg, G.nb, P, staged, gcnt, gcur, first, last, vals_b);
-  }
-  ZK_HIP(hipGetLastError());
-  prof_end(slot_bucket, st);
-  if (checkpoint("bucket")) return ZK_ERR_DEVICE;
-  msm_order_by_size(first, last, n_buckets, size_hist, order, sizes_b, st);
-  ZK_HIP(hipGetLastError());
-  prof_end(slot_sort, st);
-  if (checkpoint("partition")) return ZK_ERR_DEVICE;
-
-  auto run_set = [&](const Affine<F>* bases_set, Jacobian<F>* result, bool last_set) -> int {
-    lease.idle = false;
-    {
-      prof_begin(slot_heavy, st);
-      hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, heavy_seg, item_off);
-      ZK_HIP(hipGetLastError());
-      // (grid-stride over the segments that exist; a short call must not pay for thousands of empty workgroups)
-      uint32_t heavy_grid = (uint32_t)((m >> 12) < 1024 ? 1024 : (m >> 12) > 16384 ? 16384 : (m >> 12));
-      if (heavy_grid > max_items) heavy_grid = max_items;
-      hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st,
-                         bases_set, vals_b, first, last, order, item_off, hb, heavy_seg, seg_sums, dense ? 1 : 0, d_err);
-      ZK_HIP(hipGetLastError());
-      hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off,
-                         hb, buckets);
-      ZK_HIP(hipGetLastError());
-      prof_end(slot_heavy, st);
-      prof_begin(slot_acc, st);
-      static const bool a4 = std::getenv("MI355ZK_ACC_NARROW") == nullptr;  // (the 4-byte index walk, kept for the traffic comparison in profiles/)
-      if (a4)
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order,
-                           heavy, hb, n_buckets, buckets, dense ? 1 : 0, d_err);
-      else
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3((n_buckets + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order,
-                           heavy, hb, n_buckets, buckets, dense ? 1 : 0, d_err);
-      ZK_HIP(hipGetLastError());
+  // ---- digits + partition of one chunk: index lists per (window, bucket) in vals_b, bounds first[] / last[], size order
+  auto partition_chunk = [&](const ChunkPlan& C, const uint32_t* d_sc) -> int {
+    const PartGeom& P = C.P;
+    const uint64_t nc = C.n, kstride = (nc + 3) & ~3ull;  // distance between the key planes of two windows
+    const uint32_t ncell = C.ncell;
+    // density words and prefix ranks of this chunk's exponents (cuts are multiples of 32); under FullDensity exponent i of the
+    // chunk owns base base_offset + lo + i
+    const uint32_t* dens = d_density ? d_density + (C.lo >> 5) : nullptr;
+    ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
+    ZK_HIP(hipMemsetAsync(gcnt, 0, o_big_col - o_gcnt, st));  // gcnt and gcur
+    // "msm_sort" spans the whole partition after the digits (scan + scatter + bucket + size order), as it did for the library sort
+    prof_begin(slot_digits, st);
+    static const bool fused_a = std::getenv("MI355ZK_PART_FUSED_A") != nullptr;  // (the one-kernel pass A, kept for the comparison in DESIGN.md)
+    if (!fused_a) {
+      ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_plain_kernel<RM>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, d_sc, nc, dens, G,
+                                                  w_lo, w_hi, scalars_mont ? 1 : 0, kstride, keys, d_err + 1, C.lo));
+      hipLaunchKernelGGL(msm_tile_hist_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)P.nbin * 4, st, keys, nc, kstride, G.nb, WL, P, tile_hist);
+    } else {
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const uint32_t per_cu = (size_t)((ncell + 1) / 2) * 4 <= PART_LDS_A ? 2u : 1u;     // 1024-lane workgroups per CU (LDS histograms)
+      const uint32_t grid = P.n_st < per_cu * (uint32_t)cus ? P.n_st : per_cu * (uint32_t)cus;
+      ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_hist_kernel<RM>, dim3(grid), dim3(PART_THREADS), (size_t)((ncell + 1) / 2) * 4, st, d_sc, nc,
+                                                  dens, G, w_lo, w_hi, scalars_mont ? 1 : 0, P, kstride, keys, tile_hist, d_err + 1, C.lo));
     }
-    prof_end(slot_acc, st);
-    if (checkpoint("accumulate")) return (int)ZK_ERR_DEVICE;
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_digits, st);
+    if (checkpoint("digits", C)) return ZK_ERR_DEVICE;
+    return ZK_OK;
+  };
+  auto partition_rest = [&](const ChunkPlan& C) -> int {
+    const PartGeom& P = C.P;
+    const uint64_t nc = C.n, kstride = (nc + 3) & ~3ull;
+    const uint32_t ncell = C.ncell;
+    const uint32_t* dens = d_density ? d_density + (C.lo >> 5) : nullptr;
+    const uint32_t* dpre = d_dprefix ? d_dprefix + (C.lo >> 5) : nullptr;
+    const uint64_t boff = base_offset + (d_density ? 0 : C.lo);
+    prof_begin(slot_sort, st);
+    prof_begin(slot_scan, st);
+    hipLaunchKernelGGL(msm_colsum_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, P, ncell, csum);
+    hipLaunchKernelGGL(msm_colscan_kernel, dim3((ncell + 255) / 256), dim3(256), 0, st, csum, P, ncell, col_total);
+    hipLaunchKernelGGL(msm_binscan_kernel, dim3(1), dim3(PART_THREADS), 0, st, col_total, P, ncell, G.nb, bin_start, out_start);
+    hipLaunchKernelGGL(msm_tileoff_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, csum, bin_start, P, ncell, tile_off);
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_scan, st);
+    prof_begin(slot_scatter, st);
+    {
+      static const char* env_x = std::getenv("MI355ZK_PART_XCDS");  // 1 disables the XCD-aware tile order
+      const uint32_t xcds = env_x && std::atoi(env_x) >= 1 ? (uint32_t)std::atoi(env_x) : 8u;
+      hipLaunchKernelGGL(msm_scatter_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)(2 * ((P.nbin + 3u) & ~3u) + 32) * 4 + (size_t)P.st * 8, st,
+                         keys, nc, kstride, boff, dens, dpre, G.nb, WL, P, xcds, tile_off, pairs);
+    }
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_scatter, st);
+    if (checkpoint("scatter", C)) return ZK_ERR_DEVICE;
+    prof_begin(slot_bucket, st);
+    {
+      const uint32_t nfl = (1u << P.lo_bits) < 4 ? 4 : (1u << P.lo_bits);
+      const size_t fixed = (size_t)(2 * nfl + 32) * 4;
+      // staging for the expected bin population with slack, at most what the CU has
+      uint64_t want = (uint64_t)(nc / P.nbin) * 5 / 4 + 3ull * nfl + 4096;
+      const uint64_t cap_max = (PART_LDS_MAX - fixed) / 4;
+      if (want > cap_max) want = cap_max;
+      if (want > (uint64_t)PART_EC * PART_THREADS + 3ull * nfl) want = (uint64_t)PART_EC * PART_THREADS + 3ull * nfl;
+      const uint32_t stage_cap = (uint32_t)want & ~3u;
+      hipLaunchKernelGGL(msm_bucket_kernel, dim3(ncell), dim3(PART_THREADS), fixed + (size_t)stage_cap * 4, st, pairs, bin_start, out_start, G.nb, P,
+                         stage_cap, first, last, vals_b);
+      // the big bins (none for uniform exponents up to 2^26 points: the surplus workgroups of these launches exit at once)
+      const uint32_t max_seg = (uint32_t)(2 * (C.m / BIG_SEG) + 2);
+      hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
+      // (small grids: when there is no big bin -- uniform exponents -- the launches only cost their workgroups' start-up, and the
+      // place kernel's LDS allows one workgroup per CU anyway)
+      int n_cu = 256;
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+      const uint32_t big_grid = max_seg < 2u * (uint32_t)n_cu ? max_seg : 2u * (uint32_t)n_cu;
+      const uint32_t place_grid = max_seg < (uint32_t)n_cu ? max_seg : (uint32_t)n_cu;
+      hipLaunchKernelGGL(msm_bigbin_count_kernel, dim3(big_grid), dim3(PART_THREADS), (size_t)nfl * 4, st, pairs, bin_start, big_plan, big_col, big_seg,
+                         G.nb, P, gcnt);
+      const size_t place_fixed = (size_t)(4 * nfl + 32) * 4, place_staged = place_fixed + (size_t)BIG_SEG * 4;
+      const int staged = place_staged <= PART_LDS_MAX ? 1 : 0;
+      hipLaunchKernelGGL(msm_bigbin_place_kernel, dim3(staged ? place_grid : big_grid), dim3(PART_THREADS), staged ? place_staged : place_fixed, st, pairs, bin_start, out_start,
+                         big_plan, big_col, big_seg, G.nb, P, staged, gcnt, gcur, first, last, vals_b);
+    }
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_bucket, st);
+    if (checkpoint("bucket", C)) return ZK_ERR_DEVICE;
+    msm_order_by_size(first, last, n_buckets, size_hist, order, sizes_b, st);
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_sort, st);
+    if (checkpoint("partition", C)) return ZK_ERR_DEVICE;
+    return ZK_OK;
+  };
 
+  // ---- bucket accumulation of the partitioned chunk over one base vector; carry: the buckets continue an earlier chunk
+  auto accumulate_chunk = [&](const ChunkPlan& C, const Affine<F>* bases_set, bool carry) -> int {
+    prof_begin(slot_heavy, st);
+    hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, C.hb, C.heavy, C.heavy_seg, item_off);
+    ZK_HIP(hipGetLastError());
+    // (grid-stride over the segments that exist; a short call must not pay for thousands of empty workgroups)
+    uint32_t heavy_grid = (uint32_t)((C.m >> 12) < 1024 ? 1024 : (C.m >> 12) > 16384 ? 16384 : (C.m >> 12));
+    if (heavy_grid > C.max_items) heavy_grid = C.max_items;
+    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st,
+                       bases_set, vals_b, first, last, order, item_off, C.hb, C.heavy_seg, seg_sums, dense ? 1 : 0, d_err);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(C.hb < 2048 ? C.hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off,
+                       C.hb, buckets, carry ? 1 : 0);
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_heavy, st);
+    prof_begin(slot_acc, st);
+    static const bool a4 = std::getenv("MI355ZK_ACC_NARROW") == nullptr;  // (the 4-byte index walk, kept for the traffic comparison in profiles/)
+    const dim3 grid((n_buckets + 255) / 256), block(256);
+    if (carry) {
+      if (a4)
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+                           buckets, dense ? 1 : 0, d_err);
+      else
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+                           buckets, dense ? 1 : 0, d_err);
+    } else {
+      if (a4)
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true, false>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+                           buckets, dense ? 1 : 0, d_err);
+      else
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, false>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+                           buckets, dense ? 1 : 0, d_err);
+    }
+    ZK_HIP(hipGetLastError());
+    prof_end(slot_acc, st);
+    if (checkpoint("accumulate", C)) return (int)ZK_ERR_DEVICE;
+    return ZK_OK;
+  };
+
+  // ---- bucket reduction, the copy back and the host join: once per base vector
+  auto finish_set = [&](Jacobian<F>* result, bool last_set) -> int {
     prof_begin(slot_red, st);
     {
       // wsums[w * n_out + k]:  k < n_levels: sum of A of level k;  k >= n_levels: bit sum j = k - n_levels of the last array
@@ -1820,7 +1900,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       }
     }
     prof_end(slot_red, st);
-    if (checkpoint("reduce")) return (int)ZK_ERR_DEVICE;
+    if (checkpoint("reduce", plan[0])) return (int)ZK_ERR_DEVICE;
 
     std::vector<XYZZ<F>> h_wsums((size_t)WL * n_out);
     unsigned long long h_errs[2] = {0, 0};
@@ -1892,9 +1972,31 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     *result = acc;
     return (int)ZK_OK;
   };
-  int rc_set = run_set(d_bases, out, d_bases2 == nullptr || out2 == nullptr);
+
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const ChunkPlan& C = plan[c];
+    const uint32_t* d_sc = d_scalars;
+    if (chunks) {
+      const void* p = nullptr;
+      rc = chunks->acquire(c, st, &p);  // (makes `st` wait for the chunk's upload)
+      if (rc) return rc;
+      d_sc = (const uint32_t*)p;
+    }
+    rc = partition_chunk(C, d_sc);
+    if (rc == ZK_OK && chunks) rc = chunks->digits_enqueued(c, st);  // the digit kernel is the only reader of the exponents
+    if (rc == ZK_OK) rc = partition_rest(C);
+    if (rc == ZK_OK) rc = accumulate_chunk(C, d_bases, c > 0);
+    if (rc) return rc;
+  }
+  const bool two_sets = d_bases2 != nullptr && out2 != nullptr;
+  int rc_set = finish_set(out, !two_sets);
   if (rc_set != ZK_OK) return rc_set;
-  if (d_bases2 != nullptr && out2 != nullptr) return run_set(d_bases2, out2, true);
+  if (two_sets) {
+    lease.idle = false;
+    rc = accumulate_chunk(plan[0], d_bases2, false);
+    if (rc) return rc;
+    return finish_set(out2, true);
+  }
   return ZK_OK;
 }
 
@@ -1954,8 +2056,8 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st, d_points,
                      vals, first, last, order, item_off, hb, MSM_HEAVY_SEG, seg_sums, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, hb,
-                     buckets);
-  hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
+                     buckets, 0);
+  hipLaunchKernelGGL((msm_accumulate_kernel<F, false, false>), dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
                      n_rows, buckets, 1, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(msm_to_affine_kernel<F>, dim3((n_rows + 255) / 256), dim3(256), 0, st, buckets, d_out, n_rows);
   ZK_HIP(hipGetLastError());

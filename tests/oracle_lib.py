@@ -219,6 +219,16 @@ class Group:
                                  _p32(density), C.c_size_t(density_bits or 0), C.c_int(threads), _p64(out))
         return rc, out
 
+    def dense_multiexp(self, bases, scalars, cpus=1):
+        """powersoftau::utils::dense_multiexp (powersoftau/src/utils.rs:189-292): one base per exponent, infinity bases add
+        nothing; `cpus` = num_cpus::get() (threads per region)."""
+        bases, scalars = _arr(bases), _arr(scalars)
+        n = scalars.size // 4
+        assert bases.size // self.aff == n
+        out = np.zeros(self.jac, np.uint64)
+        self._f("dense_multiexp")(_p64(bases), _p64(scalars), C.c_size_t(n), C.c_int(cpus), _p64(out))
+        return out
+
     def naive_multiexp(self, bases, scalars):
         bases, scalars = _arr(bases), _arr(scalars)
         out = np.zeros(self.jac, np.uint64)

@@ -66,3 +66,27 @@ def test_density_shorter_than_exponents_stops_at_zip():
     rc, a = O.G1.multiexp(bases, scalars, density=dens, density_bits=4)
     rc2, b = O.G1.multiexp(bases, scalars[:4], density=dens, density_bits=4)
     assert rc == 0 and rc2 == 0 and O.G1.eq(a, b)
+
+
+@pytest.mark.parametrize("group,n,cpus", [(1, 5, 1), (1, 31, 3), (1, 700, 1), (1, 700, 5), (1, 2500, 16), (2, 300, 4)])
+def test_dense_multiexp_like_powersoftau(group, n, cpus):
+    """powersoftau::utils::dense_multiexp (powersoftau/src/utils.rs:189-292) restated: all `cpus` threads on one region at a time
+    over chunks of n / cpus + 1 bases.  Same group element as bellman's multiexp over the same pairs (the reference's own test
+    of the two shapes is `dense == sparse`, multiexp.rs:517,589) and as the naive sum; exponents 0 and 1 take their shortcuts; a
+    base at infinity adds nothing (no Source, no UnexpectedIdentity)."""
+    G = O.G1 if group == 1 else O.G2
+    bases = inputs.bases_progression_cpu(group, n, seed=177 + n)
+    scalars = inputs.random_scalars(n, seed=178 + n)
+    scalars[0] = 0
+    scalars[1] = [1, 0, 0, 0]
+    if n > 8:
+        scalars[7] = [1, 0, 0, 0]
+    dense = G.dense_multiexp(bases, scalars, cpus=cpus)
+    rc, sparse = G.multiexp(bases, scalars, threads=2)
+    assert rc == 0 and G.eq(dense, sparse) and G.eq(dense, G.naive_multiexp(bases, scalars))
+    if n > 8:
+        holed = bases.copy()
+        holed[3] = 0                      # infinity: skipped silently
+        zeroed = scalars.copy()
+        zeroed[3] = 0
+        assert G.eq(G.dense_multiexp(holed, scalars, cpus=cpus), G.dense_multiexp(bases, zeroed, cpus=cpus))

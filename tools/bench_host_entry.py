@@ -22,14 +22,19 @@ for ln in a.log_n:
     del b, s, k
     zk.multiexp(w, (hb[:1024], 0), zk.FullDensity(), hs[:1024]).wait()   # warm the library (streams, workspace), not the cache of hb
     t = time.perf_counter()
+    got0 = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()             # NOT pinned: bases + scalars cross PCIe on every call
+    dt_unpinned = time.perf_counter() - t
+    zk.pin_bases(hb)                                                        # the shim's promise: this Arc<Vec<G>> is immutable
+    t = time.perf_counter()
     got = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()              # FIRST call: bases + scalars cross PCIe, streamed
     dt_first = time.perf_counter() - t
     t = time.perf_counter()
     for _ in range(a.iters): got2 = zk.multiexp(w, (hb, 0), zk.FullDensity(), hs).wait()   # bases cached on the device: scalars only
     dt = (time.perf_counter() - t) / a.iters
     aff = lambda p: bytes(np.asarray(__import__("oracle_lib").G1.to_affine(p)))  # noqa: E731
-    out[f"2e{ln}"] = {"first_call_ms": round(dt_first * 1e3, 2), "cached_bases_ms": round(dt * 1e3, 2),
+    zk.unpin_bases(hb)
+    out[f"2e{ln}"] = {"unpinned_call_ms": round(dt_unpinned * 1e3, 2), "first_call_ms": round(dt_first * 1e3, 2), "cached_bases_ms": round(dt * 1e3, 2),
                       "first_call_Mscalar_mul_per_s": round(n / dt_first / 1e6, 1), "cached_Mscalar_mul_per_s": round(n / dt / 1e6, 1),
                       "first_call_host_bytes": 96 * n, "first_call_GBs_incl_compute": round(96 * n / dt_first / 1e9, 2),
-                      "same_result_as_device_resident": bool(aff(got) == aff(want) and aff(got2) == aff(want))}
-print(json.dumps({"entry": "mi355zk_bn254_g1_msm (host buffers, pageable; streamed upload + bases cache)", **out}))
+                      "same_result_as_device_resident": bool(aff(got) == aff(want) and aff(got2) == aff(want) and aff(got0) == aff(want))}
+print(json.dumps({"entry": "mi355zk_bn254_g1_msm (host buffers, pageable; streamed upload into ONE bucket array + pinned-bases cache)", **out}))
