@@ -57,6 +57,7 @@ struct NttPassParams {
   // inter-pass twiddle  w^(tw_mul * k * (lo*g + gidx)) ; tw_mul == 0 -> none (last pass)
   uint64_t tw_mul;
   uint32_t tw_h;            // two-level split: w^e = A[e >> h] * B[e & (2^h - 1)]
+  uint32_t tw_full;         // 1: the first pass of a two-pass transform reads its twiddle w^(k * col) from a table indexed by the OUTPUT position
   uint32_t pre;             // first pass of coset_fft: element i *= g^i   (preA/preB, split pre_h)
   uint32_t pre_h;
   uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h)
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
                                                               const UTab* __restrict__ roots, const UTab* __restrict__ twA,
                                                               const UTab* __restrict__ twB, const UTab* __restrict__ preA,
                                                               const UTab* __restrict__ preB, const UTab* __restrict__ postA,
-                                                              const UTab* __restrict__ postB, FrU post_c) {
+                                                              const UTab* __restrict__ postB, FrU post_c, const UTab* __restrict__ twF) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr uint32_t np = 1u << LOG_NP;
   // twiddle-one products are skipped in stages 0 .. SKIP_MAX: rows longer than 2^10 give up stage 2 (a skipped stage doubles the
@@ -290,7 +291,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     FrU v = lds_load(lds, plane, g * pitch + swz(k));                     // < 30p, limbs < 4*2^29
     const uint64_t go = out_base + k * P.out_xs + g * P.out_gs;
     FrU w;
-    if (P.tw_mul != 0) {
+    if (P.tw_full) {
+      w = tab_load(twF + go);                                             // w^(k * col), streamed: one product instead of two
+    } else if (P.tw_mul != 0) {
       uint64_t ex = P.tw_mul * k * (lo * P.g + g);
       w = u_mul(tab_load(twA + (ex >> P.tw_h)), tab_load(twB + (ex & ((1ull << P.tw_h) - 1))));
     } else if (P.post == 2) {                                             // minv * ginv^k (icoset_fft, domain.rs:197-203)
@@ -316,6 +319,21 @@ __global__ void ntt_pow_table_kernel(UTab* tab, Fr base, uint64_t step, uint64_t
   for (int i = 0; i < 9; ++i) t.l[i] = u.l[i];
   t.l[9] = t.l[10] = t.l[11] = 0;
   tab[j] = t;
+}
+
+// The inter-pass twiddles of a two-pass transform N = N_1 * S, laid out like the first pass's OUTPUT: full[k * S + col] = w^(k * col)
+// (k < N_1, col < S), U-form, 2^261 domain -- from the two-level table w^e = A[e >> h] * B[e & mask].
+__global__ void ntt_full_twiddle_kernel(UTab* __restrict__ full, const UTab* __restrict__ A, const UTab* __restrict__ B, uint32_t h,
+                                        uint32_t log_s, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t k = i >> log_s, col = i & ((1ull << log_s) - 1), ex = k * col;
+  const FrU w = u_mul(tab_load(A + (ex >> h)), tab_load(B + (ex & ((1ull << h) - 1))));  // < 2p, N: what the pass computed per element before
+  UTab t;
+#pragma unroll
+  for (int l = 0; l < 9; ++l) t.l[l] = w.l[l];
+  t.l[9] = t.l[10] = t.l[11] = 0;
+  full[i] = t;
 }
 
 // a[i] *= c * gA[i >> h] * gB[i & mask]   (gA == nullptr: a[i] *= c);  c in the memory format
@@ -348,12 +366,19 @@ struct PowTables {
   UTab* A = nullptr;
   UTab* B = nullptr;
   UTab* roots[NTT_MAX_LOG_NP + 1] = {};  // roots[b][x] = (w^(N/2^b))^x, x < 2^(b-1)
+  UTab* full = nullptr;    // two-pass transforms up to NTT_FULL_TW_MAX_LOG: w^(k * col) at the first pass's output position (48 B per element)
+  uint32_t full_log_s = 0;
 };
+// Measured (round 3): 2^20 fft 0.1507 -> 0.1456 ms with the table (one product less per element of the first pass, 50 MB more to
+// stream); at 2^22 the 192 MiB table makes the transform SLOWER (0.564 -> 0.580 ms): the pass is VALU-bound only while its streams stay
+// inside the L2 / Infinity Cache.  Hence two-pass transforms up to 2^20 only.
+constexpr uint32_t NTT_FULL_TW_MAX_LOG = 20;
 
 std::mutex g_mu;
 std::map<Key, PowTables> g_tables;
 
-int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_roots, const uint32_t* bs, int nb, PowTables** out) {
+int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_roots, const uint32_t* bs, int nb, PowTables** out,
+                     uint32_t full_log_s = 0) {
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
   Key key;
@@ -368,6 +393,7 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
     for (auto& kv : g_tables) {
       (void)hipFree(kv.second.A);
       (void)hipFree(kv.second.B);
+      (void)hipFree(kv.second.full);
       for (auto* r : kv.second.roots) (void)hipFree(r);
     }
     g_tables.clear();
@@ -381,6 +407,7 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
     (void)hipStreamSynchronize(st);
     (void)hipFree(T.A);
     (void)hipFree(T.B);
+    (void)hipFree(T.full);
     for (auto* r : T.roots) (void)hipFree(r);
     g_tables.erase(key);
     return (int)ZK_ERR_DEVICE;
@@ -406,6 +433,19 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
       hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.roots[b], w, 1ull << (log_n - b), cnt);
       if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
     }
+  }
+  if (full_log_s != 0 && (T.full == nullptr || T.full_log_s != full_log_s)) {
+    if (T.full) {  // (another split of the same size: only when MI355ZK_NTT_LOGNP changes between calls)
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "sync");
+      (void)hipFree(T.full);
+      T.full = nullptr;
+    }
+    built = true;
+    const uint64_t cnt = 1ull << log_n;
+    if ((e = hipMalloc(&T.full, cnt * sizeof(UTab))) != hipSuccess) return fail(e, "full");
+    T.full_log_s = full_log_s;
+    hipLaunchKernelGGL(ntt_full_twiddle_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.full, T.A, T.B, T.h, full_log_s, cnt);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
   }
   if (built && (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");  // one-time: tables may be used from other streams later
   *out = &T;
@@ -457,6 +497,7 @@ void ntt_release_all() {
     (void)hipSetDevice(kv.first.dev);
     (void)hipFree(kv.second.A);
     (void)hipFree(kv.second.B);
+    (void)hipFree(kv.second.full);
     for (auto* r : kv.second.roots) (void)hipFree(r);
   }
   g_tables.clear();
@@ -500,7 +541,9 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   // "got a table pointer" and "enqueued the kernels that read it"
   std::lock_guard<std::mutex> run_lk(g_run_mu);
   PowTables* T = nullptr;
-  rc = build_pow_tables(st, log_n, omega, true, b, R, &T);
+  static const bool no_full = std::getenv("MI355ZK_NTT_NO_FULL_TW") != nullptr;  // (the two-level product, kept for the comparison in DESIGN.md)
+  const bool full_tw = R == 2 && log_n <= NTT_FULL_TW_MAX_LOG && !no_full;
+  rc = build_pow_tables(st, log_n, omega, true, b, R, &T, full_tw ? b[1] : 0);
   if (rc) return rc;
   PowTables* Tpre = nullptr;
   PowTables* Tpost = nullptr;
@@ -568,6 +611,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       P.load_x_fastest = (G == 1);
       P.tw_mul = (R == 1) ? 0 : Tm[p];
       P.tw_h = T->h;
+      P.tw_full = (full_tw && p == 0) ? 1u : 0u;  // (p == 0 of R == 2: Tm = 1, hi = 0, so the output position is k * S + col)
       tiles = Tm[p] * P.tiles_lo;
     } else {
       // last pass: G rows with adjacent k_1; hi = k_1 group, lo = middle digit (R == 3) else 0
@@ -614,11 +658,11 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     if (r4)                                                                                                                                \
       hipLaunchKernelGGL((ntt_pass_kernel<L, true>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
                          T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,  \
-                         post_cu);                                                                                                         \
+                         post_cu, T->full);                                                                                                \
     else                                                                                                                                   \
       hipLaunchKernelGGL((ntt_pass_kernel<L, false>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
                          T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,  \
-                         post_cu);                                                                                                         \
+                         post_cu, T->full);                                                                                                \
     break;
     switch (b[p]) {
       ZK_NTT_LAUNCH(1) ZK_NTT_LAUNCH(2) ZK_NTT_LAUNCH(3) ZK_NTT_LAUNCH(4) ZK_NTT_LAUNCH(5) ZK_NTT_LAUNCH(6) ZK_NTT_LAUNCH(7) ZK_NTT_LAUNCH(8)

@@ -64,6 +64,35 @@ def join_partials(partials: np.ndarray) -> np.ndarray:
 
 _RC = {"UnexpectedIdentity": 1, "IoError(UnexpectedEof)": 2}
 
+_XCHG = {}  # (device, words, world) -> (pinned send, device send, device recv, pinned recv): allocated once, reused by every step
+
+
+def _allgather_words(rec: np.ndarray, device, group, world: int) -> np.ndarray:
+    """all-gather of one small u64 record per rank -> (world, words).  device given (RCCL): the record goes through a PINNED
+    host buffer and the three transfers (H2D, all-gather, D2H) are queued on the current stream without a host wait in
+    between -- ONE synchronisation per exchange.  The Jacobian partial lives on the host on both sides of the exchange (the
+    window join before it and the EC additions after it are host arithmetic), so the device only relays it over xGMI."""
+    import torch
+    import torch.distributed as dist
+
+    words = rec.size
+    if device is None:
+        mine = torch.from_numpy(rec.view(np.int64))
+        gathered = torch.empty(world * words, dtype=torch.int64)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        return gathered.numpy().view(np.uint64).reshape(world, -1)
+    key = (str(device), words, world)
+    if key not in _XCHG:
+        _XCHG[key] = (torch.empty(words, dtype=torch.int64, pin_memory=True), torch.empty(words, dtype=torch.int64, device=device),
+                      torch.empty(world * words, dtype=torch.int64, device=device), torch.empty(world * words, dtype=torch.int64, pin_memory=True))
+    h_send, d_send, d_recv, h_recv = _XCHG[key]
+    h_send.numpy()[:] = rec.view(np.int64)
+    d_send.copy_(h_send, non_blocking=True)
+    dist.all_gather_into_tensor(d_recv, d_send, group=group)
+    h_recv.copy_(d_recv, non_blocking=True)
+    torch.cuda.current_stream(device).synchronize()
+    return h_recv.numpy().view(np.uint64).reshape(world, -1).copy()
+
 
 def exchange(fut, limbs: int, index_offset: int = 0, device=None, group=None) -> np.ndarray:
     """The exchange step WITH the error path: `fut` is this rank's ready future (bellman.multiexp(...)) of a `limbs`-word
@@ -92,12 +121,7 @@ def exchange(fut, limbs: int, index_offset: int = 0, device=None, group=None) ->
     if world == 1:
         allr = rec.reshape(1, -1)
     else:
-        mine = torch.from_numpy(rec.view(np.int64))
-        if device is not None:
-            mine = mine.to(device)
-        gathered = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
-        dist.all_gather_into_tensor(gathered, mine, group=group)
-        allr = gathered.cpu().numpy().view(np.uint64).reshape(world, -1)
+        allr = _allgather_words(rec, device, group, world)
     rcs = allr[:, limbs].astype(np.int64)
     if (rcs == 3).any():
         raise local_exc if local_exc is not None else RuntimeError("mi355zk: a peer rank failed inside its multiexp")
@@ -116,12 +140,7 @@ def allgather_join(partial: np.ndarray, device=None, group=None) -> np.ndarray:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return np.ascontiguousarray(partial, dtype=np.uint64)
-    mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64))
-    if device is not None:
-        mine = mine.to(device)
-    allp = torch.empty(world * mine.numel(), dtype=torch.int64, device=mine.device)
-    dist.all_gather_into_tensor(allp, mine, group=group)
-    return join_partials(allp.cpu().numpy().view(np.uint64).reshape(world, -1))
+    return join_partials(_allgather_words(np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1), device, group, world))
 
 
 def batch_exp_sharded(bases, exps, same_scalar: bool = False, gather: bool = True, group=None, fn=None):

@@ -21,15 +21,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(n_ranks, bases):
-    args = ["bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--log-n", "21", "--no-cpu-baseline", "--no-h2d-leg", "--bases", bases]
+def _run(n_ranks, bases, log_n=21):
+    args = ["bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--log-n", str(log_n), "--no-cpu-baseline", "--no-h2d-leg", "--no-secondary",
+            "--bases", bases]
     env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if n_ranks == 1:
         cmd = [sys.executable] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + args
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
@@ -44,3 +45,15 @@ def test_bench_result_is_identical_for_every_rank_count(bases):
         assert got["n_gpus"] == n and got["full_size_linearity_check"] and got["sharded_result_matches_unsharded"]
         assert got["result_affine_x_limb0"] == ref["result_affine_x_limb0"], (n, bases)
         assert got["config"]["bases_bytes_per_gpu"] * (n // min(n, 4)) == (1 << 21) * 64
+
+
+def test_eight_ranks_at_the_baseline_size():
+    """BASELINE config 4 at ITS size with the N = 8 control flow: 8 gloo ranks share the one device (each holds its 2^25-point
+    range: 2 GiB of bases, 1 GiB of exponents and its workspace -- 288 GB of HBM hold all eight), every rank runs its (point
+    range x window group) cell of the (2 x 4) plan at the real geometry, the partials go through the exchange step, and the
+    sum is the group element the single-GPU bench line reports for the same seed-per-shard input (x limb 0x5c2b6af288baf266:
+    BENCH_r01 / r02 / r03).  bench.py itself checks the sharded result against the unsharded evaluation and full-size linearity."""
+    got = _run(8, "random", log_n=26)
+    assert got["n_gpus"] == 8 and got["full_size_linearity_check"] and got["sharded_result_matches_unsharded"]
+    assert got["result_affine_x_limb0"] == "0x5c2b6af288baf266"
+    assert got["config"]["points_per_gpu"] == 1 << 25 and "2 point range(s) x 4 window group(s)" in got["config"]["parallelism"]

@@ -153,7 +153,7 @@ def test_deterministic_run_twice(zk, worker):
     assert O.G1.eq(a, b)
 
 
-def _dev_inputs(zk, log_n, seed):
+def _dev_inputs(zk, log_n, seed, group=1):
     """2^log_n bases k_i*G and scalars generated on the device (as bench.py does)."""
     import torch
 
@@ -163,10 +163,11 @@ def _dev_inputs(zk, log_n, seed):
     dev = torch.device("cuda", 0)
     scalars = bench.gen_scalars(n, seed, dev)
     k = bench.gen_scalars(n, seed + 1, dev)
-    bases = torch.empty((n, 8), dtype=torch.int64, device=dev)
-    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
-    rc = zk.lib.load().mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n,
-                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    bases = torch.empty((n, 8 * group), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW)
+    fn = zk.lib.load().mi355zk_bn254_g1_batch_mul_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_batch_mul_dev
+    rc = fn(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
     return bases, scalars, k
@@ -515,8 +516,6 @@ def test_baseline_size_2e26_closed_form_and_linearity(zk, worker):
 def test_window_group_partials_add_up(zk, worker, group, log_n):
     """Multi-GPU sharding by scalar windows (shard.plan): the partials of all (point range, window group) cells add up to the
     multiexp, for every split a power-of-two world produces, with a density map as well."""
-    if group == 2 and log_n == 20:
-        log_n = 16
     n = 1 << log_n
     G = O.G1 if group == 1 else O.G2
     if log_n <= 12:
@@ -531,9 +530,8 @@ def test_window_group_partials_add_up(zk, worker, group, log_n):
         assert rc == 0
         off = 3
     else:
-        bases, scalars, _ = _dev_inputs(zk, log_n, seed=1510) if group == 1 else (None, None, None)
-        if group == 2:
-            pytest.skip("covered at 2^12")
+        # the geometry N = 2 / 4 / 8 ranks really run (window count, bucket count, partition shape of a 2^20-point call)
+        bases, scalars, _ = _dev_inputs(zk, log_n, seed=1510, group=group)
         want = zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait()
         off = 0
     for world in (2, 4, 8):
