@@ -242,7 +242,15 @@ int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affin
 /* ---- per-point batch exponentiation out[i] = k[i] * P[i] (same_scalar == 0; powersoftau `batch_exp`,
  * batched_accumulator.rs:1130-1181) or out[i] = k[0] * P[i] (same_scalar != 0; phase2 contribute,
  * phase2/src/parameters.rs:423-470), normalised to affine like `batch_normalization` (ec.rs:251-299);
- * the all-zero record is infinity on both sides.  Asynchronous on `stream`. */
+ * the all-zero record is infinity on both sides.  Asynchronous on `stream`.
+ * PRECONDITION (G2): the points lie in the order-r subgroup.  The scalar is split over the twist's endomorphism psi
+ * (k P = k1 P + k2 psi(P), glv.hpp), and psi(P) = mu P holds in that subgroup only; the reference's wNAF `mul` is exact for ANY
+ * point of the twist, and its decoders (like this library's) check the curve equation, not the subgroup (ec.rs:1136-1344).  For
+ * an on-curve G2 point with a cofactor component the result here is NOT k P.  Honest ceremony data is always in the subgroup;
+ * a caller that processes untrusted G2 points and needs the reference's answer for such inputs must establish subgroup
+ * membership by its own means first (this entry point cannot be used for the test: it evaluates r P through the same
+ * split).  The same holds for the G2 point FFT and the G2 sparse matrix-vector product, which multiply by the same kernel.  G1 needs nothing: E(Fq) has prime order r, so phi(P) = lambda P for every point ON the curve -- but
+ * `checked = 0` decoding can admit off-curve G1 records, for which no endomorphism identity holds either. */
 int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
 int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
 

@@ -137,7 +137,8 @@ void prof_reset() {
 // the per-point `batch_exp` of the ceremony code (powersoftau/src/batched_accumulator.rs:1130-1181: point i
 // by its own tau-power; phase2/src/parameters.rs:423-470: every point by the same delta^-1) followed by the
 // normalisation to affine that `batch_normalization` performs there (ec.rs:251-299).  The reference uses
-// wNAF-4 and one inversion per chunk; the group element, hence the affine output, does not depend on the chain.
+// wNAF-4 and one inversion per chunk; for points of the order-r group the group element, hence the affine output, does not depend on
+// the chain (G2: the psi split below REQUIRES the subgroup -- glv.hpp, include/mi355zk.h).
 //   G1: signed binary (NAF: one addition per three bits instead of two) on the U-form JACOBIAN accumulator of
 //       curveu.hpp (a doubling is 1071 mads against 1467 in XYZZ), X and Y parked in the output record and Z in a
 //       scratch array, then batch_normalize_kernel: 16 points per lane share one inversion (Montgomery's trick),

@@ -1,8 +1,11 @@
 // GLV scalar decomposition for BN254 G1, used by the per-point scalar multiplications (batch_exp and what is built on it: the
 // terms of the QAP sums, the butterflies of the point FFT).  The curve y^2 = x^3 + 3 over Fq has the endomorphism
 //     phi(x, y) = (beta x, y) = lambda (x, y),      beta^3 = 1 in Fq,  lambda^2 + lambda + 1 = 0 mod r,
-// so k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128: half the doublings of a 254-bit ladder.  The group element -- hence the affine
-// output the reference's batch_exp / batch_normalization leave (ec.rs:251-299) -- does not depend on the chain that produced it.
+// so k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128: half the doublings of a 254-bit ladder.  For a point of the order-r group the
+// group element -- hence the affine output the reference's batch_exp / batch_normalization leave (ec.rs:251-299) -- does not depend on
+// the chain that produced it.  G1: E(Fq) has prime order, every on-curve point qualifies.  G2: the twist has a cofactor, psi(P) =
+// mu P holds in the order-r subgroup ONLY, and neither the reference's decoders nor ours test subgroup membership: for an on-curve
+// point with a cofactor component the split chain does NOT give k P (include/mi355zk.h states the precondition).
 //   lambda = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd,  beta = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
 //   lattice basis of {(x, y): x + y lambda = 0 mod r}:  v1 = (a1, -|b1|),  v2 = (a2, b2)
 //   k1 = k - c1 a1 - c2 a2,   k2 = c1 |b1| - c2 b2,   c1 = floor(k g1 / 2^256),  c2 = floor(k g2 / 2^256),

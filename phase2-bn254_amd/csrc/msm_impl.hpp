@@ -27,6 +27,7 @@
 // (ec.rs:45-85, 596-629), so parity is defined on the affine normalisation.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
 
 #include <cmath>
@@ -1573,7 +1574,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t lvl_cnt[MSM_MAX_LEVELS + 1], lvl_chunks[MSM_MAX_LEVELS + 1], lvl_logl[MSM_MAX_LEVELS + 1], n_levels = 0;
   uint64_t total_chunks = 1;
   uint32_t final_cnt = G.nb;
-  while (final_cnt > MSM_FINAL_MAX && n_levels < MSM_MAX_LEVELS) {
+  static const char* env_fmax = std::getenv("MI355ZK_MSM_FINAL_MAX");
+  const uint32_t final_max = env_fmax && std::atoi(env_fmax) >= 64 ? (uint32_t)std::atoi(env_fmax) : MSM_FINAL_MAX;
+  while (final_cnt > final_max && n_levels < MSM_MAX_LEVELS) {
     const uint32_t logl = (uint64_t)final_cnt * WL >= (1ull << 20) ? 3 : 2;
     lvl_cnt[n_levels] = final_cnt;
     lvl_logl[n_levels] = logl;
@@ -1908,6 +1911,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     ZK_HIP(hipMemcpyAsync(h_errs, d_err, 16, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     lease.idle = true;
+    static const bool trace_join = std::getenv("MI355ZK_TRACE_MSM") != nullptr;
+    const auto t_join0 = std::chrono::steady_clock::now();
     const unsigned long long h_err = h_errs[0];
     // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
     // flight, prover.rs:250-298) start while this thread joins its partial sums
@@ -1970,6 +1975,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       }
     }
     *result = acc;
+    if (trace_join)
+      std::fprintf(stderr, "[mi355zk] msm n=%llu: host join of %u window sums: %.1f us\n", (unsigned long long)n, WL * n_out,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_join0).count());
     return (int)ZK_OK;
   };
 

@@ -745,6 +745,49 @@ def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
     assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == int(sel[-1])
 
 
+def test_host_entry_streamed_g2_and_heavy_buckets_in_later_chunks(zk, worker):
+    """The streamed host-buffer call carries ONE bucket array across its chunks (msm_accumulate_kernel<.., CARRY>,
+    msm_heavy_combine_kernel with carry): G2 at 2^23 points (four chunks), and G1 with prover-like exponents whose byte-valued
+    and one-valued exponents sit in the SECOND half of the vector -- heavy buckets that only appear in the later chunks, continued
+    through the segment-parallel path.  Same group element as the device-resident single-pass call."""
+    import torch
+
+    import bench
+
+    dev = torch.device("cuda", 0)
+    # ---- G2
+    log_n = 23
+    bases, scalars, _ = _dev_inputs(zk, log_n, seed=2601, group=2)
+    want = O.G2.to_affine(zk.multiexp(worker, (bases, 0), zk.FullDensity(), scalars).wait())
+    hb, hs = bases.cpu().numpy().view(np.uint64), scalars.cpu().numpy().view(np.uint64)
+    zk.pin_bases(hb)
+    assert np.array_equal(O.G2.to_affine(zk.multiexp(worker, (hb, 0), zk.FullDensity(), hs).wait()), want)    # uploads the bases chunk by chunk
+    assert np.array_equal(O.G2.to_affine(zk.multiexp(worker, (hb, 0), zk.FullDensity(), hs).wait()), want)    # bases cached: growing chunks
+    zk.unpin_bases(hb)
+    del bases, scalars, hb, hs
+    # ---- G1, skew in the later chunks
+    n = 1 << 23
+    bases, scalars, _ = _dev_inputs(zk, 23, seed=2611)
+    sc = scalars.cpu().numpy().view(np.uint64).copy()
+    rng = np.random.default_rng(2612)
+    half = n // 2
+    kind = rng.random(half)
+    tail = sc[half:]
+    tail[kind < 0.4] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    tail[(kind >= 0.4) & (kind < 0.6)] = 0
+    small = (kind >= 0.6) & (kind < 0.8)
+    tail[small] = 0
+    tail[small, 0] = rng.integers(2, 256, size=int(small.sum()), dtype=np.uint64)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to(dev)
+    want = O.G1.to_affine(zk.multiexp(worker, (bases, 0), zk.FullDensity(), d_sc).wait())
+    hb = bases.cpu().numpy().view(np.uint64)
+    zk.pin_bases(hb)
+    zk.multiexp(worker, (hb[:4096], 0), zk.FullDensity(), sc[:4096]).wait()
+    for _ in range(2):
+        assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (hb, 0), zk.FullDensity(), sc).wait()), want)
+    zk.unpin_bases(None)
+
+
 def test_prover_like_exponents_at_2e22_take_the_big_bin_path(zk, worker):
     """A Groth16 witness at size: 40 % ones, 30 % zeros, 10 % bytes, the rest uniform.  Window 0 then sends ~half of all points
     into ONE coarse bin of the partition (far more than a workgroup holds in registers: the segmented msm_bigbin_* kernels) and
