@@ -1109,14 +1109,30 @@ __device__ __forceinline__ typename BucketAcc<F>::type accumulate_run(typename B
 constexpr uint32_t MSM_HEAVY_SEG = 4096;    // entries per segment at size; short calls cut finer (heavy_seg_for)
 constexpr uint32_t MSM_HEAVY_LANES = 64;   // one wave per segment: 64 strided partial sums of <= 64 points, then a 6-level tree
 
+// item_off: hb + 2 words.  [0 .. H]: exclusive scan of the segment counts over the H leading entries of the size order that can be
+// heavy, [H] = the number of segments; [hb + 1] = H.  The size order is a counting sort over msm_size_bin -- descending in the BIN, not
+// inside a bin -- so H = the entries whose bin is at least the bin of heavy + 1 (a binary search), and the exact test runs on those
+// only: uniform exponents have H = 0 and the three launches of the heavy path cost their start-up (0.02 ms instead of the 0.06 ms of
+// a scan over all hb entries).
 __global__ void __launch_bounds__(1024) msm_heavy_plan_kernel(const uint32_t* __restrict__ sizes_sorted, uint32_t hb, uint32_t heavy, uint32_t seg,
-                                                             uint32_t* __restrict__ item_off /* hb + 1 */) {
+                                                             uint32_t* __restrict__ item_off /* hb + 2 */) {
   __shared__ uint32_t scratch[32];
-  const uint32_t tot = block_scan_long(hb, scratch, [&](uint32_t i) {
+  const uint32_t bin_min = msm_size_bin(heavy == 0xffffffffu ? heavy : heavy + 1);
+  uint32_t lo = 0, hi = hb;  // first index whose bin is below bin_min (uniform over the workgroup: every lane walks the same path)
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (msm_size_bin(sizes_sorted[mid]) >= bin_min) lo = mid + 1;
+    else hi = mid;
+  }
+  const uint32_t H = lo;
+  const uint32_t tot = block_scan_long(H, scratch, [&](uint32_t i) {
     const uint32_t sz = sizes_sorted[i];
     return sz > heavy ? (sz + seg - 1) / seg : 0u;
   }, [&](uint32_t i, uint32_t ex) { item_off[i] = ex; });
-  if (threadIdx.x == 0) item_off[hb] = tot;
+  if (threadIdx.x == 0) {
+    item_off[H] = tot;
+    item_off[hb + 1] = H;
+  }
 }
 
 template <class F>
@@ -1127,6 +1143,7 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
                                                                   unsigned long long* __restrict__ err_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  hb = item_off[hb + 1];  // the leading entries that can be heavy (msm_heavy_plan_kernel)
   const uint32_t total = item_off[hb];
   // a fixed-size grid strides over the segments: dispatching one (mostly empty) workgroup per POSSIBLE segment
   // costs milliseconds at 2^26 points
@@ -1167,6 +1184,7 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __
                                                               int carry) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  hb = item_off[hb + 1];  // the leading entries that can be heavy (msm_heavy_plan_kernel)
   for (uint32_t i = blockIdx.x; i < hb; i += gridDim.x) {
     const uint32_t lo = item_off[i], hi = item_off[i + 1];
     if (hi == lo) continue;  // not heavy (uniform per workgroup)
@@ -1649,7 +1667,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_big_col = take((size_t)ncell_max * 4), o_big_seg = take((size_t)ncell_max * 4), o_big_plan = take(sizeof(BigPlan));
   size_t o_first = take((size_t)(n_buckets + 1) * 4), o_last = take((size_t)(n_buckets + 1) * 4), o_hist = take(MSM_SIZE_BINS * 4);
   size_t o_sizes_b = take((size_t)n_buckets * 4), o_ids_b = take((size_t)n_buckets * 4);
-  size_t o_item_off = take((size_t)(hb_max + 1) * 4);
+  size_t o_item_off = take((size_t)(hb_max + 2) * 4);
   size_t o_seg_sums = take((size_t)items_max * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
   size_t o_partA = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
@@ -2040,7 +2058,7 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   size_t o_vals = take((size_t)(nnz ? nnz : 1) * 4);
   size_t o_hist = take(MSM_SIZE_BINS * 4), o_sizes_b = take((size_t)n_rows * 4), o_order = take((size_t)n_rows * 4);
-  size_t o_item_off = take((size_t)(hb + 1) * 4);
+  size_t o_item_off = take((size_t)(hb + 2) * 4);
   size_t o_seg = take((size_t)max_items * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_rows * sizeof(XYZZ<F>));
   std::lock_guard<std::mutex> lk(g_ws_mu);
