@@ -926,8 +926,12 @@ inline PartGeom choose_part(uint64_t n, uint32_t WL, uint32_t nb) {
   }
   P.lo_bits = lo;
   P.nbin = nbin_of(lo);
+  // Super-tiles as large as LDS allows: a pass-B workgroup pays its scans and barriers once, whatever it moves (2^20 exponents, 16
+  // windows: 0.150 ms with 2048-element tiles, 0.049 ms with 16384; round 2 shrank the tiles until there were 512 of them PER WINDOW,
+  // which at 16 windows is 8192 workgroups of two elements per lane).  Smaller only while a launch would not even give every CU one
+  // workgroup (n_st * WL < 256: 2^16 exponents run 4096-element tiles).
   uint32_t st = PART_MAX_ST;
-  while (st > PART_THREADS && n / st < 512) st >>= 1;
+  while (st > PART_THREADS && (n / st) * WL < 256) st >>= 1;
   if (env_st) {
     const int v = std::atoi(env_st);
     if (v >= (int)PART_THREADS && v <= (int)PART_MAX_ST && v % (int)PART_THREADS == 0) st = (uint32_t)v;
