@@ -247,12 +247,18 @@ int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affin
  * (k P = k1 P + k2 psi(P), glv.hpp), and psi(P) = mu P holds in that subgroup only; the reference's wNAF `mul` is exact for ANY
  * point of the twist, and its decoders (like this library's) check the curve equation, not the subgroup (ec.rs:1136-1344).  For
  * an on-curve G2 point with a cofactor component the result here is NOT k P.  Honest ceremony data is always in the subgroup;
- * a caller that processes untrusted G2 points and needs the reference's answer for such inputs must establish subgroup
- * membership by its own means first (this entry point cannot be used for the test: it evaluates r P through the same
+ * a caller that processes untrusted G2 points and needs the reference's answer for such inputs tests them first with
+ * mi355zk_bn254_g2_subgroup_check_dev (this entry point cannot be used for the test: it evaluates r P through the same
  * split).  The same holds for the G2 point FFT and the G2 sparse matrix-vector product, which multiply by the same kernel.  G1 needs nothing: E(Fq) has prime order r, so phi(P) = lambda P for every point ON the curve -- but
  * `checked = 0` decoding can admit off-curve G1 records, for which no endomorphism identity holds either. */
 int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
 int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
+/* The test that establishes the precondition above: *bad_index = the lowest index of a G2 record that is on the twist but NOT in
+ * the order-r subgroup (-1: all n records are; the all-zero record is the identity).  psi(P) == mu P, mu P by a plain
+ * double-and-add (no split).  The reference has no counterpart -- its bn256 decoders do not test membership either -- so this
+ * is an addition for callers that handle untrusted G2 data, not a drop-in for anything.  Synchronises `stream`. */
+int mi355zk_bn254_g2_subgroup_check_dev(const void *d_points_affine, size_t n, void *stream, long long *bad_index);
+int mi355zk_selftest_g2_in_subgroup(const uint64_t affine_pt[16]);   /* host run of the same test: 1 / 0 */
 
 /* ---- host-side group helpers on Jacobian results: acc += other (CurveProjective::add_assign,
  * ec.rs:360-454) -- how per-GPU partial sums are joined after the all-gather -- and into_affine

@@ -135,6 +135,18 @@ def point_ifft(points):
 _ENC_SIZE = {(1, False): 64, (1, True): 32, (2, False): 128, (2, True): 64}
 
 
+def g2_subgroup_check(points) -> int:
+    """mi355zk_bn254_g2_subgroup_check_dev: -1 if every (n, 16) G2 record lies in the order-r subgroup, else the lowest index that
+    does not.  Not a reference function (pairing_ce's bn256 decoders check the curve equation only, ec.rs:1136-1344): it establishes
+    the precondition of the G2 scalar-multiplication kernels (their psi split is exact in the subgroup only) for untrusted data."""
+    import ctypes as C
+
+    assert _group(points) == 2
+    bad = C.c_longlong(-1)
+    _check(_lib.load().mi355zk_bn254_g2_subgroup_check_dev(_p(points.contiguous()), points.shape[0], _stream_ptr(), C.byref(bad)), "g2_subgroup_check")
+    return int(bad.value)
+
+
 def encode_points(points, compressed: bool):
     import torch
 

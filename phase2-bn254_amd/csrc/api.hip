@@ -598,6 +598,61 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
   return ZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// G2 subgroup membership.  The scalar multiplications above split their scalar over psi, which is multiplication by mu = q mod r
+// on the order-r subgroup ONLY (glv.hpp); neither the reference's decoders nor ours test membership (ec.rs:1136-1344 check the curve
+// equation).  For a BN curve  P in G2  <=>  psi(P) == mu P  (mu = 6 x^2: psi acts on the r-torsion of the twist as q, and q = mu mod
+// r; on the cofactor part it does not), so the test is one plain double-and-add by the 127-bit mu -- NO split, the point of the
+// test -- against psi(P): 127 doublings + 68 additions on the U-form Fq2 Jacobian, one inlined copy of each.
+static int mul_slot(void* stream, void** out);
+ZK_HD bool g2_in_subgroup(const Affine<Fq2>& p) {
+  if (p.is_zero()) return true;  // the identity
+  const uint32_t MU[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};  // glv2_split's constant
+  const FqU C266 = UPow2<FqParams, 266>::get();
+  const Fq2 cxs = glv2_cx(), cys = glv2_cy();
+  const Fq2U cxU{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};
+  const Fq2U cyU{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
+  const JacTabU2 e = jacu2_tab_from_affine(p.x, p.y);
+  JacU2 acc = JacU2::zero();
+#pragma unroll 1
+  for (int bit = 126; bit >= -1; --bit) {  // bit 126 is mu's top bit; the last trip (-1) subtracts psi(P) through the same call site
+    if (bit >= 0) acc = jacu2_double(acc);
+    const bool last = bit < 0;
+    const bool take = last || ((MU[bit < 0 ? 0 : bit >> 5] >> (bit & 31)) & 1u);
+    if (take) {
+      JacTabU2 t = e;
+      if (last) t = jacu2_tab_psi(e, cxU, cyU);
+      jacu2_add_tab(acc, t, last);         // last: acc - psi(P), infinity iff mu P == psi(P)
+    }
+  }
+  return acc.is_zero();
+}
+
+__global__ void __launch_bounds__(256) g2_subgroup_check_kernel(const Affine<Fq2>* __restrict__ pts, uint64_t n, unsigned long long* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!g2_in_subgroup(pts[i])) atomicMin(bad, (unsigned long long)i);
+}
+
+int g2_subgroup_check(const void* d_points, size_t n, void* stream, long long* bad_index) {
+  if (!bad_index || (!d_points && n)) return ZK_ERR_BAD_ARGS;
+  *bad_index = -1;
+  if (n == 0) return ZK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  void* d_bad = nullptr;
+  int rc = mul_slot(stream, &d_bad);  // (a 256-byte device slot from the per-stream ring below)
+  if (rc) return rc;
+  ZK_HIP(hipMemsetAsync(d_bad, 0xff, 8, st));
+  hipLaunchKernelGGL(g2_subgroup_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Affine<Fq2>*)d_points, (uint64_t)n,
+                     (unsigned long long*)d_bad);
+  ZK_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  ZK_HIP(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  if (h != ~0ull) *bad_index = (long long)h;
+  return ZK_OK;
+}
+
 // fixed base given by value on the host (input synthesis: P_i = k_i * G).  The 64 / 128-byte device copy of the base comes from a
 // per-(device, stream) ring of slots allocated once: hipMalloc / hipFree per call synchronise the whole device, and this entry is
 // the building block of per-point batch_exp synthesis (256 calls per bench input).  A slot is in flight only until its call's
@@ -1577,6 +1632,15 @@ int mi355zk_bn254_g2_point_fft_dev(void* d_points_affine, uint32_t log_n, int in
   return point_fft_g2(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
 }
 
+int mi355zk_bn254_g2_subgroup_check_dev(const void* d_points_affine, size_t n, void* stream, long long* bad_index) {
+  return g2_subgroup_check(d_points_affine, n, stream, bad_index);
+}
+int mi355zk_selftest_g2_in_subgroup(const uint64_t affine_pt[16]) {  // the same test on the HOST: 1 in the subgroup, 0 not, < 0 bad arguments
+  if (!affine_pt) return -1;
+  G2Affine p;
+  std::memcpy(&p, affine_pt, sizeof p);
+  return g2_in_subgroup(p) ? 1 : 0;
+}
 int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[8], const void* d_scalars, size_t n, void* stream) {
   return batch_mul<Fq>(d_out_affine, base_affine, d_scalars, n, stream);
 }

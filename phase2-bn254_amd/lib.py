@@ -80,6 +80,8 @@ SIGNATURES = {
     "mi355zk_bn254_g2_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mi355zk_bn254_g2_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "mi355zk_bn254_g2_subgroup_check_dev": (_i, [_vp, _sz, _vp, C.POINTER(C.c_longlong)]),
+    "mi355zk_selftest_g2_in_subgroup": (_i, [_vp]),
     "mi355zk_bn254_g1_add": (_i, [_vp, _vp]),
     "mi355zk_bn254_g2_add": (_i, [_vp, _vp]),
     "mi355zk_bn254_g1_to_affine": (_i, [_vp, _vp]),
