@@ -1457,7 +1457,7 @@ void mi355zk_shutdown(void) {
   msm_release_g2();
 }
 
-const char* mi355zk_version(void) { return "mi355zk 0.2 (gfx950)"; }
+const char* mi355zk_version(void) { return "mi355zk 0.3 (gfx950)"; }
 
 int mi355zk_bases_cache_pin(const void* host_bases, size_t n_bases, int group) { return bases_cache_pin(host_bases, n_bases, group); }
 void mi355zk_bases_cache_invalidate(const void* host_bases) {

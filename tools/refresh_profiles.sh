@@ -8,17 +8,19 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 timeout 400 $B > $O/bench_n1.json 2> $O/bench_n1.err
-timeout 200 $B --log-n 20 --steps 20 --warmup 3 > $O/bench_2e20.json 2>/dev/null
-timeout 400 rocprofv3 --kernel-trace -d /tmp/p_kt -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-h2d-leg > $O/kt.log 2>&1
+timeout 200 $B --log-n 20 --steps 20 --warmup 3 --no-secondary > $O/bench_2e20.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace -d /tmp/p_kt -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-h2d-leg --no-secondary > $O/kt.log 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_kt -name "*.db" | head -1) > $O/msm26_kernel_stats.txt
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg > $O/pf.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg > $O/pw.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg --no-secondary > $O/pf.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg --no-secondary > $O/pw.log 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_f -name "*.db" | head -1) --pmc > $O/msm26_pmc_fetch.txt
 python $R/tools/rocpd_summary.py $(find /tmp/p_w -name "*.db" | head -1) --pmc > $O/msm26_pmc_write.txt
-timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY -d /tmp/p_s -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg > $O/ps.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY -d /tmp/p_s -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg --no-secondary > $O/ps.log 2>&1
 python $R/tools/pmc_kernel.py $(find /tmp/p_s -name "*.db" | head -1) msm_accumulate_kernel > $O/msm26_accumulate_sq_pmc.txt
 timeout 300 rocprofv3 --kernel-trace -d /tmp/p_ntt -- python $R/tools/bench_ntt.py --check > $O/ntt20.json 2> $O/ntt.err
 python $R/tools/rocpd_summary.py $(find /tmp/p_ntt -name "*.db" | head -1) > $O/ntt20_kernel_stats.txt
+rm -rf /tmp/p_t20; timeout 300 rocprofv3 --kernel-trace -d /tmp/p_t20 -- python $R/tools/trace_one_msm.py > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_t20 -name "*.db" | head -1) --timeline 27 > $O/msm20_timeline.txt
 timeout 300 python $R/tools/bench_g2.py > $O/g2_2e20.json 2>/dev/null
 timeout 400 python $R/tools/bench_next_rows.py --log-n 20 > $O/next_rows_2e20.json 2>/dev/null
 timeout 300 python $R/tools/bench_contribute.py > $O/contribute_2e20.json 2>/dev/null
@@ -30,7 +32,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d /tmp/p_ns2 -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
 { python $R/tools/pmc_kernel.py $(find /tmp/p_ns1 -name "*.db" | head -1) ntt_pass_kernel; python $R/tools/pmc_kernel.py $(find /tmp/p_ns2 -name "*.db" | head -1) ntt_pass_kernel; } > $O/ntt20_pass_sq_pmc.txt 2>&1
 timeout 400 python $R/tools/bench_skew.py --log-n 26 --iters 2 > $O/skew_2e26.json 2>/dev/null
-timeout 400 $B --steps 5 --warmup 1 --bases tau --no-cpu-baseline > $O/bench_n1_tau.json 2>/dev/null
+timeout 400 $B --steps 5 --warmup 1 --bases tau --no-cpu-baseline --no-secondary > $O/bench_n1_tau.json 2>/dev/null
 $R/tools/bin/ubench_valu > $O/ubench_valu.txt 2>&1
 $R/tools/bin/ubench_gather > $O/ubench_gather.txt 2>&1
 $R/tools/bin/ubench_fieldmul > $O/ubench_fieldmul.txt 2>&1

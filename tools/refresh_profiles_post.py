@@ -4,7 +4,7 @@ profiles/ (round-tagged names) and rebuilds profiles/latest_pmc.json, which benc
 import json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh"); DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 def put(src, dst, header=None):
     body = open(os.path.join(SRC, src)).read()
     with open(os.path.join(DST, f"{tag}_{dst}"), "w") as f:
@@ -21,6 +21,7 @@ put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
     "# batch_exp_kernel = synthetic-input generation (outside the timed region); every msm_* launch is a full-size step\n"
     "# (1 warm-up + 3 timed + 2 of the linearity check); msm_accumulate_kernel is the dominant kernel of a step\n")
 put("ntt20_pass_sq_pmc.txt", "ntt20_pass_sq_pmc.txt", "# ntt_pass_kernel, 2^20 elements (2 passes of 1024-point rows, 256 tiles of 4 x 1024, one 1024-lane workgroup per CU), per dispatch,\n# rocprofv3 --pmc (two passes of 8 / 7 counters), tools/bench_ntt.py --log-n 20; SQ cycle counters tick once per 4 clocks\n")
+put("msm20_timeline.txt", "msm20_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_one_msm.py: the launches of ONE 2^20-point G1 multiexp in order (start offset, duration incl. the\n# profiler's serialisation, gap to the previous kernel); the host join (0.14 ms) follows the last copy\n")
 put("ntt20_kernel_stats.txt", "ntt20_kernel_stats.txt", "# rocprofv3 --kernel-trace -- python tools/bench_ntt.py --check   (MI355X, 2^20 Fr NTT, 20 iterations x 4 ops)\n")
 put("msm26_accumulate_sq_pmc.txt", "msm26_accumulate_sq_pmc.txt", "# rocprofv3 --pmc SQ_* (one pass, 8 counters) on msm_accumulate_kernel<Fq>, 2^26 points, MI355X\n")
 with open(os.path.join(DST, f"{tag}_msm26_pmc_hbm.txt"), "w") as f:
@@ -33,11 +34,13 @@ with open(os.path.join(DST, f"{tag}_msm26_pmc_hbm.txt"), "w") as f:
 def counter(path, kernel):
     for l in open(os.path.join(SRC, path)):
         if l.startswith(kernel + " "): return float(l.split()[3])
+    for l in open(os.path.join(SRC, path)):  # (template arguments beyond the field do not survive rocpd_summary's short())
+        if l.startswith(kernel.split("<")[0]) and "<Fq>" in l: return float(l.split()[3])
     raise SystemExit(f"{kernel} not in {path}")
 fetch = counter("msm26_pmc_fetch.txt", "zk::msm_accumulate_kernel<Fq>"); write = counter("msm26_pmc_write.txt", "zk::msm_accumulate_kernel<Fq>")
 sys.path.insert(0, ROOT)
 import bench
-json.dump({"round": 2, "workload_log_n": 26, "n_gpus": 1, "kernel": "msm_accumulate_kernel<Fq>", "FETCH_SIZE_KB_per_launch": fetch,
+json.dump({"round": 3, "workload_log_n": 26, "n_gpus": 1, "kernel": "msm_accumulate_kernel<Fq>", "FETCH_SIZE_KB_per_launch": fetch,
            "WRITE_SIZE_KB_per_launch": write, "hbm_bytes_per_launch": int((fetch + write) * 1024), "kernel_sources_sha": bench.kernel_sources_sha(),
            "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{tag}_msm26_pmc_hbm.txt); bytes = (FETCH_SIZE + WRITE_SIZE)*1024: "
                   "the kernel reads through 64-byte base gathers and 16-byte index-list loads, which FETCH_SIZE tallies exactly (one 64-byte "

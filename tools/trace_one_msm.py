@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Four 2^20-point G1 multiexps on device-resident inputs, nothing else: run under `rocprofv3 --kernel-trace` and read the launch
+order / durations of one call with `tools/rocpd_summary.py <db> --timeline 27` (profiles/*_msm20_timeline.txt)."""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch, ctypes as C
