@@ -1196,7 +1196,13 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   std::vector<uint64_t> cuts{0};
   static const char* env_grow = std::getenv("MI355ZK_HOST_CHUNK_GROWTH");  // percent, default 180
   static const char* env_first = std::getenv("MI355ZK_HOST_CHUNK_FIRST");  // log2 of the first chunk (bases on the device)
-  if (n >= 4 * HOST_CHUNK_MIN) {
+  // (test hook, read on every call: MI355ZK_HOST_CHUNK_TEST = exponents per chunk, a multiple of 32 -- cuts calls of ANY size, so
+  // that the chunked path can be held against the CPU oracle at sizes the oracle finishes in seconds)
+  const char* env_test = std::getenv("MI355ZK_HOST_CHUNK_TEST");
+  const uint64_t test_chunk = env_test ? (uint64_t)std::strtoull(env_test, nullptr, 10) & ~31ull : 0;
+  if (test_chunk >= 32) {
+    for (uint64_t lo = test_chunk; lo < n; lo += test_chunk) cuts.push_back(lo);
+  } else if (n >= 4 * HOST_CHUNK_MIN) {
     if (upload_bases) {
       // Bases travelling too (96 B per exponent): the link is the bottleneck and the kernels of a chunk finish long before the
       // next one has arrived; even chunks, small enough that the last one's kernels are a short tail behind the last byte.

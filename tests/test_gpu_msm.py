@@ -745,6 +745,66 @@ def test_host_entry_streamed_upload_and_bases_cache(zk, worker):
     assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == int(sel[-1])
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_streamed_chunks_against_the_oracle(zk, worker, group, monkeypatch):
+    """The chunked host-buffer call (one bucket array carried across the chunks, msm_accumulate_kernel<.., CARRY>) against the CPU
+    ORACLE, at a size the oracle finishes in seconds: MI355ZK_HOST_CHUNK_TEST cuts a 3000-exponent call into chunks of 512.
+    Density map with a source offset, exponents 0 and 1, a base repeated across chunk boundaries (the carried bucket meets its own
+    point again: the doubling branch), P and -P in different chunks (a carried bucket that becomes infinity); pinned and unpinned
+    vectors; UnexpectedIdentity in a later chunk and Eof keep the unchunked call's exponent index."""
+    import bn254_model as M
+
+    monkeypatch.setenv("MI355ZK_HOST_CHUNK_TEST", "512")
+    G = O.G1 if group == 1 else O.G2
+    n, off = 3000, 4
+    rng = np.random.default_rng(2700 + group)
+    bits = rng.random(n) < 0.7
+    sel = np.nonzero(bits)[0]
+    used = len(sel)
+    bases = inputs.bases_progression_cpu(group, used + off, seed=2701 + group)
+    scalars = inputs.random_scalars(n, seed=2702 + group)
+    scalars[::19] = 0
+    scalars[3::29] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    # the same base under the same exponent in chunks 0, 2 and 4 (same bucket in every window: P + P across a carry), and its
+    # negative under that exponent in chunk 5 ... twice, so that one pair cancels a carried bucket to infinity
+    r0, r2, r4, r5a, r5b = (int(np.searchsorted(sel, x)) for x in (40, 1100, 2100, 2600, 2700))
+    for r in (r2, r4):
+        bases[off + r] = bases[off + r0]
+        scalars[sel[r]] = scalars[sel[r0]]
+    neg = bases[off + r0].copy()
+    half = 4 * group
+    y = [M.from_limbs(neg[half + 4 * k: half + 4 * k + 4]) for k in range(group)]
+    for k in range(group):
+        neg[half + 4 * k: half + 4 * k + 4] = M.to_limbs((M.Q - y[k]) % M.Q)
+    for r in (r5a, r5b):
+        bases[off + r] = neg
+        scalars[sel[r]] = scalars[sel[r0]]
+    dens = GU.density_words(bits)
+    rc, want = G.multiexp(bases, scalars, density=dens, density_bits=n, base_offset=off, threads=4)
+    assert rc == 0
+    dm = zk.DensityTracker.from_bools(bits)
+    got = zk.multiexp(worker, (bases, off), dm, scalars).wait()                       # unpinned: the bases travel chunk by chunk
+    assert np.array_equal(G.to_affine(got), G.to_affine(want))
+    zk.pin_bases(bases)
+    for _ in range(2):                                                                 # pinned: first call fills the cache, second uses it
+        assert np.array_equal(G.to_affine(zk.multiexp(worker, (bases, off), dm, scalars).wait()), G.to_affine(want))
+    zk.unpin_bases(bases)
+    # FullDensity, more exponents than bases: Eof at the unchunked index, result of the prefix still correct up to there
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (bases, off), zk.FullDensity(), scalars).wait()
+    assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == used
+    # an identity base owned by an exponent of chunk 3
+    bad = bases.copy()
+    target = int(sel[np.searchsorted(sel, 1700)])
+    bad[off + int(np.searchsorted(sel, 1700))] = 0
+    assert scalars[target].any()
+    rc, _ = G.multiexp(bad, scalars, density=dens, density_bits=n, base_offset=off)
+    assert rc == 1
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(worker, (bad, off), dm, scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == target
+
+
 def test_host_entry_streamed_g2_and_heavy_buckets_in_later_chunks(zk, worker):
     """The streamed host-buffer call carries ONE bucket array across its chunks (msm_accumulate_kernel<.., CARRY>,
     msm_heavy_combine_kernel with carry): G2 at 2^23 points (four chunks), and G1 with prover-like exponents whose byte-valued
