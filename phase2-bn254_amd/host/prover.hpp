@@ -34,6 +34,19 @@ struct Parameters {  // mod.rs:216-238
   std::pair<SourceBuilder<G1Affine>, SourceBuilder<G1Affine>> get_a(size_t num_inputs, size_t) const { return {{a, 0}, {a, num_inputs}}; }
   std::pair<SourceBuilder<G1Affine>, SourceBuilder<G1Affine>> get_b_g1(size_t num_inputs, size_t) const { return {{b_g1, 0}, {b_g1, num_inputs}}; }
   std::pair<SourceBuilder<G2Affine>, SourceBuilder<G2Affine>> get_b_g2(size_t num_inputs, size_t) const { return {{b_g2, 0}, {b_g2, num_inputs}}; }
+  // The five vectors are immutable by type (shared_ptr<const vector>, the reference's Arc<Vec<G>>): pin() promises exactly that
+  // to the library (mi355zk_bases_cache_pin), so that the host-buffer multiexps of every later proof find the vectors on the device
+  // and only the exponents cross PCIe; unpin() ends the promise -- call it before the Parameters object (the last owner of the
+  // vectors) goes away.  Without pin() every multiexp uploads its bases again: correct, slower.
+  void pin() const {
+    auto one = [](const void* p, size_t n, int group) { if (n) (void)mi355zk_bases_cache_pin(p, n, group); };
+    one(h->data(), h->size(), 1); one(l->data(), l->size(), 1); one(a->data(), a->size(), 1); one(b_g1->data(), b_g1->size(), 1);
+    one(b_g2->data(), b_g2->size(), 2);
+  }
+  void unpin() const {
+    for (const void* p : {(const void*)h->data(), (const void*)l->data(), (const void*)a->data(), (const void*)b_g1->data(), (const void*)b_g2->data()})
+      if (p) mi355zk_bases_cache_invalidate(p);
+  }
 };
 
 struct ProvingAssignment {  // prover.rs:131-151; a, b, c, input_assignment, aux_assignment hold Montgomery Fr like Vec<Scalar<E>> / Vec<E::Fr>

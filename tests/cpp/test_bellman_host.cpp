@@ -251,6 +251,7 @@ int main() {
       params.vk = VerifyingKey{(*v1)[0], (*v1)[1], (*v1)[2], (*v2)[0], (*v2)[1]};
     }
     const FrRepr r = rand_scalar(gen), s = rand_scalar(gen);
+    params.pin();  // the shim's promise: these Arc<Vec<G>> are immutable -- the second proof below finds the bases on the device
     const Proof proof = create_proof(worker, params, pa, r, s);
 
     // ---- the same proof from the oracle
@@ -316,6 +317,7 @@ int main() {
     CHECK(std::memcmp(wc, &proof.c, 64) == 0);
     // a second proof on the same parameters (bases served from the device cache) is the same proof
     const Proof again = create_proof(worker, params, pa, r, s);
+    params.unpin();
     CHECK(std::memcmp(&again, &proof, sizeof proof) == 0);
   }
   std::puts("ok groth16_create_proof");

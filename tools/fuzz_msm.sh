@@ -5,6 +5,10 @@ rc=0
 for cfg in "" "C=4" "C=7" "C=11" "C=15" "R=3,6" "R=5,6" "R=3,9" "R=5,12"; do
   unset MI355ZK_MSM_C MI355ZK_MSM_RADIX
   case "$cfg" in C=*) export MI355ZK_MSM_C=${cfg#C=};; R=*) export MI355ZK_MSM_RADIX=${cfg#R=};; esac
+  unset MI355ZK_HOST_CHUNK_TEST
   timeout 300 python tools/fuzz_msm.py --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 || rc=1
+  # the same cases through the STREAMED call: chunks of 64 exponents accumulated into one carried bucket array
+  export MI355ZK_HOST_CHUNK_TEST=64
+  timeout 300 python tools/fuzz_msm.py --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 | sed 's/^fuzz:/fuzz (chunks of 64):/' || rc=1
 done
 exit $rc
