@@ -126,7 +126,10 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
     achieved = 64 * n / (pass_ms * 1e-3) / 1e9 if pass_ms else None
     entry = {"metric": "2^%d-element BN254 Fr NTT (EvaluationDomain fft / ifft / coset_fft), in place in HBM" % log_n, **ntt,
              "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                          # profiles/r03_ntt20_pmc_hbm.txt: WRITE_SIZE 32 MiB exactly + FETCH_SIZE 33.35 MB x 2 (the guide's correction for
+                          # coalesced streams) per pass, reported only for the size it was measured at
+                          "traffic": int((33352.8 * 2 + 32768.9) * 1024) if log_n == 20 else None,
                           "passes_per_transform": passes, "pass_ms": round(pass_ms, 4) if pass_ms else None,
                           "note": "algorithmic 64 B per element per pass (32 B read + 32 B written); the pass is VALU-issue bound (DESIGN.md 3)"}}
     if cpu:
