@@ -1358,6 +1358,48 @@ struct SmallWs {
 };
 std::mutex g_tws_mu;
 std::vector<SmallWs*> g_tws;  // the pool: as many entries as there have been concurrent calls
+
+// Pinned host buffers for the one copy that ends a multiexp (the window sums and the error words): into pageable memory the runtime
+// stages each copy (~20 us apiece at this size, twice per call); leased per call from a pool like the workspaces, grow-only.
+struct PinBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool busy = false;
+};
+std::mutex g_pin_mu;
+std::vector<PinBuf*> g_pin;
+struct PinLease {
+  PinBuf* b = nullptr;
+  ~PinLease() {
+    if (b == nullptr) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    b->busy = false;
+  }
+};
+int pin_acquire(size_t bytes, PinLease* lease) {
+  PinBuf* pick = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (PinBuf* b : g_pin)
+      if (!b->busy && (pick == nullptr || b->bytes > pick->bytes)) pick = b;
+    if (pick == nullptr) {
+      pick = new PinBuf();
+      g_pin.push_back(pick);
+    }
+    pick->busy = true;
+  }
+  lease->b = pick;
+  if (pick->bytes < bytes) {
+    if (pick->p) (void)hipHostFree(pick->p);
+    pick->p = nullptr;
+    pick->bytes = 0;
+    size_t want = 65536;
+    while (want < bytes) want <<= 1;
+    ZK_HIP(hipHostMalloc(&pick->p, want, hipHostMallocDefault));
+    pick->bytes = want;
+  }
+  return ZK_OK;
+}
 struct SmallWsLease {
   SmallWs* w = nullptr;
   hipStream_t st = nullptr;
@@ -1420,6 +1462,15 @@ int tws_acquire(int dev, size_t bytes, hipStream_t st, SmallWsLease* lease, void
 }
 
 void ws_release_all() {
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (PinBuf* b : g_pin) {
+      if (b->busy) continue;
+      if (b->p) (void)hipHostFree(b->p);
+      b->p = nullptr;
+      b->bytes = 0;
+    }
+  }
   {
     std::lock_guard<std::mutex> lk(g_tws_mu);
     for (SmallWs* t : g_tws) {
@@ -1678,11 +1729,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_partS = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
   const uint32_t n_out = n_levels + final_bits;  // per window: one A-sum per level, then one sum per bit
   size_t o_wsums = take((size_t)WL * n_out * sizeof(XYZZ<F>));
+  size_t o_err = take(16);  // [0] lowest identity base index, [1] lowest index of a non-canonical exponent -- right behind the window sums: ONE copy brings both back
   // slice sums of msm_tree_kernel (two ping-pong halves): n_out jobs per window, slices of the longest job
   const uint32_t tree_cnt = n_levels ? lvl_chunks[0] : final_cnt;
   const uint64_t tree_tmp = (uint64_t)n_out * ((tree_cnt + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE);
   size_t o_sumtmp = take((size_t)WL * tree_tmp * 2 * sizeof(XYZZ<F>));
-  size_t o_err = take(16);  // [0] lowest identity base index, [1] lowest index of a non-canonical exponent
 
   int rc = part_configure(dev);
   if (rc) return rc;
@@ -1927,11 +1978,14 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     prof_end(slot_red, st);
     if (checkpoint("reduce", plan[0])) return (int)ZK_ERR_DEVICE;
 
-    std::vector<XYZZ<F>> h_wsums((size_t)WL * n_out);
-    unsigned long long h_errs[2] = {0, 0};
-    ZK_HIP(hipMemcpyAsync(h_wsums.data(), wsums, (size_t)WL * n_out * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipMemcpyAsync(h_errs, d_err, 16, hipMemcpyDeviceToHost, st));
+    const size_t back_bytes = (o_err - o_wsums) + 16;  // the window sums, their alignment padding, the two error words
+    PinLease pin;
+    if (int prc = pin_acquire(back_bytes, &pin)) return prc;
+    ZK_HIP(hipMemcpyAsync(pin.b->p, wsums, back_bytes, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    const XYZZ<F>* h_wsums = reinterpret_cast<const XYZZ<F>*>(pin.b->p);
+    unsigned long long h_errs[2];
+    std::memcpy(h_errs, (const char*)pin.b->p + (o_err - o_wsums), 16);
     lease.idle = true;
     static const bool trace_join = std::getenv("MI355ZK_TRACE_MSM") != nullptr;
     const auto t_join0 = std::chrono::steady_clock::now();
