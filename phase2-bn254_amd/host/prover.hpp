@@ -5,7 +5,7 @@
 //   bellman/src/groth16/prover.rs:131-151  ProvingAssignment (what synthesis leaves behind)
 //   bellman/src/groth16/prover.rs:202-343  create_proof
 // The eight multiexps are QUEUED before the first wait, as the reference queues them on its CpuPool (prover.rs:250-298): here from
-// eight std::async threads over the host-buffer entry points, whose bases cache keeps the parameter vectors on the device from the
+// eight std::async threads over the host-buffer entry points, whose bases cache keeps the parameter vectors of pinned Parameters (Parameters::pin) on the device from the
 // second proof on.  (prover.py is the twin that keeps the polynomials in HBM between the domain steps.)
 #pragma once
 
