@@ -1362,28 +1362,37 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   return result;
 }
 
+// best_fft / the domain operations on a HOST array (what a bellman shim calls with `&mut [Scalar<E>]`): upload, transform in place
+// on the device, copy back.  Device buffer and stream are leased from the pools of the host-buffer entry points -- round 2
+// hipMalloc'ed and hipFree'd per call (both synchronise the whole device, i.e. every other thread's multiexp) and ran on the null
+// stream.  `a` is written by the final copy only: on a device failure (rc < 0) the caller's array is untouched and it can fall
+// back to its own serial_fft.
 int ntt_host(uint64_t* a, uint32_t log_n, int op, const uint64_t* omega) {
   if (!a) return ZK_ERR_BAD_ARGS;
   if (log_n > 28) return ZK_ERR_BAD_ARGS;
-  size_t bytes = (size_t)32 << log_n;
-  void* d = nullptr;
-  ZK_HIP(hipMalloc(&d, bytes));
-  int rc;
-  hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(d); ZK_HIP(e); }
+  const size_t bytes = (size_t)32 << log_n;
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  StageLease stage_lease;
+  HostStage* S = host_stage(dev, &stage_lease);
+  if (S == nullptr) return ZK_ERR_DEVICE;
+  DensityPool::Lease buf;   // (a grow-only device buffer pool; the lease synchronises the stream before the buffer is handed on)
+  int rc = buf.acquire(dev, bytes, S->compute);
+  if (rc) return rc;
+  void* d = buf.b->p;
+  ZK_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, S->compute));
   if (omega) {
     Fr w;
     std::memcpy(&w, omega, 32);
-    rc = ntt_run((Fr*)d, log_n, w, nullptr);
+    rc = ntt_run((Fr*)d, log_n, w, S->compute);
   } else {
-    rc = domain_op_dev((Fr*)d, log_n, op, nullptr);
+    rc = domain_op_dev((Fr*)d, log_n, op, S->compute);
   }
-  if (rc == ZK_OK) {
-    e = hipMemcpy(a, d, bytes, hipMemcpyDeviceToHost);  // synchronises with the null stream
-    if (e != hipSuccess) { (void)hipFree(d); ZK_HIP(e); }
-  }
-  (void)hipFree(d);
-  return rc;
+  if (rc != ZK_OK) return rc;
+  ZK_HIP(hipStreamSynchronize(S->compute));  // a failed kernel surfaces here, before the caller's array is touched
+  ZK_HIP(hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, S->compute));
+  ZK_HIP(hipStreamSynchronize(S->compute));
+  return ZK_OK;
 }
 
 }  // namespace
