@@ -3,7 +3,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 // Return codes of the C ABI (include/mi355zk.h).
 #define ZK_OK 0
@@ -35,6 +41,77 @@ struct MsmChunks {
   // the digit kernel of chunk c -- the only reader of its exponents -- has been enqueued on `st`
   virtual int digits_enqueued(uint32_t c, hipStream_t st) = 0;
   virtual ~MsmChunks() {}
+};
+
+// A few persistent HOST threads for the window join that ends a multiexp (msm_impl.hpp): the ~200 window sums of a call are
+// independent until the final chain of doublings, and on G2 their join is 0.5 ms of host arithmetic -- 9 % of a 2^20 call.
+// run(n, fn) executes fn(0) .. fn(n - 1) on the calling thread and up to HELPERS helpers and returns when all are done; it
+// returns false WITHOUT running anything when another caller is using the helpers (the prover joins eight multiexps at once:
+// those callers take the single-threaded path rather than queue here).
+class JoinPool {
+ public:
+  static constexpr unsigned HELPERS = 7;
+  template <class Fn>
+  bool run(uint32_t count, Fn&& f) {
+    if (!owner_.try_lock()) return false;
+    struct Release { std::mutex& m; ~Release() { m.unlock(); } } release{owner_};
+    const std::function<void(uint32_t)> fn(std::forward<Fn>(f));
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      if (threads_.empty()) for (unsigned t = 0; t < HELPERS; ++t) threads_.emplace_back([this] { worker(); });
+      idle_cv_.wait(lk, [&] { return active_ == 0; });  // nobody is still inside work() of an earlier job
+      fn_ = &fn;
+      n_ = count;
+      done_.store(0);
+      next_.store(0);  // (last: a helper that sees the new counter sees the new job)
+      ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    while (done_.load(std::memory_order_acquire) < count) std::this_thread::yield();  // helpers finishing their last item
+    return true;
+  }
+  ~JoinPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const uint32_t i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      ++active_;
+      lk.unlock();
+      work();
+      lk.lock();
+      if (--active_ == 0) idle_cv_.notify_all();
+    }
+  }
+  std::mutex owner_, mu_;
+  std::condition_variable cv_, idle_cv_;
+  std::vector<std::thread> threads_;
+  const std::function<void(uint32_t)>* fn_ = nullptr;
+  uint32_t n_ = 0;
+  std::atomic<uint32_t> next_{0}, done_{0};
+  unsigned active_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
 };
 
 // Lightweight per-kernel timing used by bench.py's roofline leg: when enabled, the library brackets
