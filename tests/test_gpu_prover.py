@@ -116,3 +116,7 @@ def test_create_proof_matches_the_oracle(zk, worker, log_m, concurrent):
     assert np.array_equal(got_a, O.G1.to_affine(g_a))
     assert np.array_equal(got_b, O.G2.to_affine(g_b))
     assert np.array_equal(got_c, O.G1.to_affine(g_c))
+    # the ProvingAssignment is not consumed: EvaluationDomain.from_coeffs copies its input (the reference moves the Vec into the
+    # domain, domain.rs:52), so a second proof from the same assignment is the same proof
+    again = P.create_proof(worker, params, assignment, r, s, concurrent=concurrent)
+    assert np.array_equal(again[0], got_a) and np.array_equal(again[1], got_b) and np.array_equal(again[2], got_c)
