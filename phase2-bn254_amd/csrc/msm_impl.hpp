@@ -1552,13 +1552,27 @@ MsmGeom make_geom_radix(uint32_t rmul, uint32_t rshift) {
   return G;
 }
 
-double geom_cost(double W, double nbk, double field_bits, uint64_t n) {
+// top_values: the number of digit values the TOP window can take (2^254 / B^(W-1), or 2^width): a layout whose top window is
+// much narrower than the others sends n / top_values points into each of its buckets.
+double geom_cost(double W, double nbk, double field_bits, uint64_t n, double top_values) {
   // per (point, window): one mixed add (10 units) + one radix-sort pass per 8 key bits (0.7 units each,
   // measured); per bucket: ~45 units of reduction
   double cost = W * ((10.0 + 0.7 * std::ceil(field_bits / 8.0)) * (double)n + 45.0 * nbk);
   // occupancy term: fewer than ~2^17 bucket lanes leaves CUs idle during accumulation
   double lanes = W * nbk;
   if (lanes < 131072.0) cost *= (1.0 + 0.5 * (131072.0 / lanes - 1.0));
+  // A top window whose buckets pass the heavy threshold (msm_device: max(64, 2 * mean + 16) for a short call) takes the
+  // segment-parallel path IN FRONT of the accumulation: ~0.18 ms of a 1-ms call at 2^16 points (B = 13 * 2^10: 169 top values, 388
+  // points per top bucket: profiles/r03_msm16_timeline.txt).  A constant the size of that detour: decisive for short calls, nothing
+  // at 2^20 and beyond (where the segments also run at throughput).
+  // Below that threshold a lane still walks the top bucket alone, ~8 us per point whatever the rest of the launch does (2^15
+  // points, B = 3 * 2^12: 46 points per top bucket among buckets of 5: the launch lasts 0.44 ms instead of 0.2): ~5e5 units per
+  // point a top bucket holds beyond what the ordinary buckets' tail reaches anyway.
+  const double mean = (double)n / nbk;
+  const double heavy = std::max(64.0, 2.0 * mean + 16.0);
+  const double top_len = (double)n / top_values;
+  if (top_len > heavy) cost += 1.2e7;
+  else if (top_len > 2.0 * mean + 16.0) cost += (top_len - (2.0 * mean + 16.0)) * 5e5;
   return cost;
 }
 
@@ -1580,7 +1594,9 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
   for (uint32_t c = 4; c <= 24; ++c) {
     double W = std::ceil((254.0 + 1.0) / c);  // (W-1)*c + (c-1) >= 254
     if ((uint32_t)W % wgroups) continue;
-    double cost = geom_cost(W, std::ldexp(1.0, (int)c - 1), c, n);
+    // (make_geom: the top window keeps what the W - 1 equal windows leave of the 254 bits, at most c - 1)
+    const MsmGeom Gc = make_geom(c);
+    double cost = geom_cost(W, std::ldexp(1.0, (int)c - 1), c, n, std::ldexp(1.0, (int)Gc.width[Gc.W - 1]));
     if (cost < best) { best = cost; best_c = c; }
   }
   MsmGeom G{};
@@ -1591,7 +1607,8 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
     for (uint32_t rshift = 4; rshift <= 22; ++rshift) {
       MsmGeom R = make_geom_radix(rmul, rshift);
       if (R.W > 64 || R.c > 24 || R.W % wgroups) continue;
-      double cost = geom_cost(R.W, R.nb, R.c, n);
+      const double top_values = std::exp2(254.0 - (R.W - 1.0) * std::log2(std::ldexp((double)rmul, (int)rshift)));
+      double cost = geom_cost(R.W, R.nb, R.c, n, top_values);
       if (cost < 0.985 * best) { best = cost / 0.985; G = R; }
     }
   return G;

@@ -6,7 +6,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch, ctypes as C
 import phase2_bn254_amd as zk, inputs, bench
 L = zk.lib.load(); w = zk.Worker(0); dev = torch.device("cuda", 0)
-n = 1 << 20
+n = 1 << int(os.environ.get("TRACE_LOG_N", "20"))
 k = bench.gen_scalars(n, 5, dev); s = bench.gen_scalars(n, 6, dev)
 b = torch.empty((n, 8), dtype=torch.int64, device=dev)
 gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
