@@ -1588,6 +1588,17 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
     int v = std::atoi(env);
     if (v >= 2 && v <= 24) return make_geom((uint32_t)v);
   }
+  // Short calls (n < 2^20, all windows on one GPU): MEASURED choice.  The launch no longer fills the device there and the model
+  // below -- throughput of additions, 45 units per bucket -- misses what a call costs: the reduce is a chain of dependent additions
+  // whose length depends on c alone (c = 10: 0.12 ms ... 16: 0.40, 17: 0.62) and the accumulation reaches its throughput only from
+  // ~2^19 bucket lanes on.  profiles/r03_small_n_window_sweep.txt: every c at every size; the table is its minimum (8 - 15 % per call
+  // against the model's choice; power-of-two windows, whose top window is as wide as the others).
+  if (wgroups == 1 && n < (1ull << 20)) {
+    uint32_t lg = 0;
+    while ((1ull << lg) < n) ++lg;
+    const uint32_t c = lg <= 10 ? 10u : lg <= 12 ? 11u : lg == 13 ? 12u : lg == 14 ? 13u : lg <= 17 ? 15u : 16u;
+    return make_geom(c);
+  }
   // wgroups > 1: the windows are dealt out to that many ranks, so W must divide evenly (per-rank cost ~ total / wgroups)
   uint32_t best_c = 0;
   double best = 1e300;
