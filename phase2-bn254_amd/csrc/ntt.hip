@@ -525,12 +525,13 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   // factor the index: R passes of b[p] bits, b[0] most significant digit (DESIGN.md "NTT")
   uint32_t b[3];
   static const char* lognp_env = std::getenv("MI355ZK_NTT_LOGNP");
-  // rows of 2^10 by default; 2^11 / 2^12 where that saves a whole pass: 2^21 and 2^22 in two passes (0.372 -> 0.305 ms, 0.715 ->
-  // 0.59 ms), 2^23 as 12 + 11 (1.36 -> 1.23 ms), 2^24 as 12 + 12 (2.58 -> 2.41 ms).  The one- and two-row tiles of those passes move
-  // 32- / 64-byte runs; the kernel's XCD grouping of neighbouring tiles is what makes them pay (2^24 without it: 2.72 ms).
+  // rows of 2^10 by default; 2^11 / 2^12 where that saves a whole pass: 2^21 and 2^22 in two passes (0.372 -> 0.294 ms, 0.715 ->
+  // 0.57 ms), 2^23 as 12 + 11 (1.36 -> 1.18 ms).  The one- and two-row tiles of those passes move 32- / 64-byte runs; the kernel's
+  // XCD grouping of neighbouring tiles is what makes them pay.  2^24 ran as 12 + 12 in round 2 (2.43 ms); with two 2048-element
+  // workgroups per CU three passes of 2^8-point rows are faster (2.32 ms) than two passes whose 4096-point rows own a CU each.
   int row_bits = NTT_LOG_NP;
   if (log_n == 21 || log_n == 22) row_bits = 11;
-  if (log_n == 23 || log_n == 24) row_bits = 12;
+  if (log_n == 23) row_bits = 12;
   if (lognp_env && std::atoi(lognp_env) >= 10 && std::atoi(lognp_env) <= 12) row_bits = std::atoi(lognp_env);
   int R = (int)((log_n + row_bits - 1) / row_bits);
   for (int p = 0; p < R; ++p) b[p] = log_n / R + ((uint32_t)p < log_n % R ? 1 : 0);
@@ -570,11 +571,13 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     scratch = (Fr*)sb.p;
   }
 
-  // tile size: 4096 elements (144 KiB of LDS: one workgroup per CU).  2048-element tiles (two workgroups per CU, whose load /
-  // compute / store phases could overlap) were measured -- env MI355ZK_NTT_TILE=2048 -- and are 2-5 % SLOWER at 2^16 / 2^20 / 2^24:
-  // the pass is bound by VALU issue, not by the serialised phases.
+  // tile size: 2048 elements (72 KiB of LDS, 512 lanes with a group of four each: TWO workgroups per CU, whose barriers tie eight
+  // waves instead of sixteen and whose load / compute / store phases may drift apart) for transforms of 2^20 and more; rows of 2^12
+  // are a tile of their own.  Round 2 measured 2048-element tiles 2-5 % SLOWER -- but with radix-2 stages on 1024-lane workgroups,
+  // of which the registers (125 VGPRs) admit one per CU: that was never two workgroups per CU.  With a lane per group of four:
+  // 2^20 0.1474 -> 0.1443 ms (ifft 0.1418 -> 0.1386), 2^22 0.569 -> 0.544 (ifft 0.536 -> 0.498).  env MI355ZK_NTT_TILE = 4096 / 2048 / 1024.
   static const char* env_tile = std::getenv("MI355ZK_NTT_TILE");
-  uint64_t tile_elems = NTT_TILE_ELEMS;
+  uint64_t tile_elems = log_n >= 20 ? 2048 : NTT_TILE_ELEMS;
   if (env_tile && (std::atoi(env_tile) == 2048 || std::atoi(env_tile) == 4096 || std::atoi(env_tile) == 1024)) tile_elems = (uint64_t)std::atoi(env_tile);
   // S[p] = prod_{q>p} N_q ; Tm[p] = prod_{q<p} N_q
   uint64_t S[3], Tm[3];
@@ -652,7 +655,13 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     // more), radix-2 for the narrow tiles of short transforms, whose passes are latency-bound and want two butterflies per lane
     // rather than half the lanes idle; env MI355ZK_NTT_RADIX = 2 / 4 forces one)
     static const char* radix_env = std::getenv("MI355ZK_NTT_RADIX");
-    const bool r4 = radix_env ? std::atoi(radix_env) == 4 : (uint64_t)P.g * np >= 4ull * NTT_THREADS;  // a full tile: a group of four per lane
+    // a full tile (>= 2048 elements): a lane per group of four
+    const bool r4 = radix_env ? std::atoi(radix_env) == 4 : (uint64_t)P.g * np >= 2048;
+    if (r4) {
+      threads = (uint32_t)((P.g * np) / 4);
+      if (threads > NTT_THREADS) threads = NTT_THREADS;
+      if (threads < 64) threads = 64;
+    }
 #define ZK_NTT_LAUNCH(L)                                                                                                                   \
   case L:                                                                                                                                  \
     if (r4)                                                                                                                                \
