@@ -1596,7 +1596,10 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
   if (wgroups == 1 && n < (1ull << 20)) {
     uint32_t lg = 0;
     while ((1ull << lg) < n) ++lg;
-    const uint32_t c = lg <= 10 ? 10u : lg <= 12 ? 11u : lg == 13 ? 12u : lg == 14 ? 13u : lg <= 17 ? 15u : 16u;
+    uint32_t c = lg <= 10 ? 10u : lg <= 12 ? 11u : lg == 13 ? 12u : lg == 14 ? 13u : lg <= 17 ? 15u : 16u;
+    // G2 (profiles/r03_small_n_window_sweep.txt, second half): an addition costs three times G1's and so does every step of the
+    // reduce chain -- one bit narrower between 2^14 and 2^18 (2^14: 1.43 -> 1.33 ms, 2^16: 1.71 -> 1.61, 2^18: 2.54 -> 2.49)
+    if (group == 2) c = lg <= 10 ? 10u : lg == 11 ? 11u : lg <= 14 ? 12u : lg <= 16 ? 14u : lg <= 18 ? 15u : 16u;
     return make_geom(c);
   }
   // wgroups > 1: the windows are dealt out to that many ranks, so W must divide evenly (per-rank cost ~ total / wgroups)
