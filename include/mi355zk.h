@@ -85,7 +85,13 @@ int mi355zk_bn254_g1_msm(const uint8_t *bases, size_t n_bases, size_t base_offse
  * fingerprint of sampled records is re-checked on every call as a second line of defence.  LRU-bounded by env
  * MI355ZK_BASES_CACHE_GB (default 64, 0 = off); env MI355ZK_BASES_CACHE_IMPLICIT=1 treats every vector as pinned. */
 int mi355zk_bases_cache_pin(const void *host_bases, size_t n_bases, int group);
+/* the same promise, and the library may also keep the vector's WINDOW TABLE on the device (table mode, below: n_windows times the
+ * vector, inside MI355ZK_BASES_CACHE_GB): host-buffer calls over it that are not cut into chunks (< 2^23 exponents) then run in
+ * table mode from the second call on -- what a prover wants for the h / l / a / b vectors of its Parameters. */
+int mi355zk_bases_cache_pin_tables(const void *host_bases, size_t n_bases, int group);
 void mi355zk_bases_cache_invalidate(const void *host_bases);
+/* diagnostics: 1 when a device copy of the vector at host_bases is cached (its size, and the size of its window table or 0), else 0 */
+int mi355zk_bases_cache_info(const void *host_bases, size_t *device_bytes, size_t *table_bytes);
 /* Same for G = G2Affine (prover.rs:297-298). */
 int mi355zk_bn254_g2_msm(const uint8_t *bases, size_t n_bases, size_t base_offset,
                          const uint64_t *scalars, size_t n_scalars,
@@ -136,6 +142,26 @@ int mi355zk_bn254_g1_msm_ex_dev(const void *d_bases, size_t n_bases, size_t base
 int mi355zk_bn254_g2_msm_ex_dev(const void *d_bases, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
                                 const uint32_t *density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
                                 void *stream, uint64_t out_xyz[24]);
+/* ---- TABLE MODE: multiexps over a base vector that does not change between calls -- the `Arc<Vec<G>>` of groth16::Parameters
+ * (bellman/src/groth16/mod.rs:216-238: every proof of a circuit queries the same h / l / a / b_g1 / b_g2) -- evaluated against a
+ * precomputed WINDOW TABLE of that vector:  table[w * n_bases + i] = 2^(shift of window w) * bases[i]  for the n_windows windows of
+ * mi355zk_msm_table_geometry(n_bases).  A digit of any window then belongs to the bucket of its value in ONE bucket set shared
+ * by all windows: one reduction instead of one per window, and a wider window (fewer additions) on the 2^19 .. 2^24-point calls a
+ * prover makes (nothing to gain at 2^26).  Same contract, result and errors as mi355zk_bn254_g{1,2}_msm_ex_dev
+ * with window_groups = 1 (multiexp.rs:330-355; `base_offset` / `density` as there), at n_windows times the base memory.
+ *   table_geometry:   window_bits / n_windows for a vector of n_bases points (group 1 = G1, 2 = G2): the table holds
+ *                     n_windows * n_bases affine records (64 B / 128 B each).
+ *   table_build_dev:  fills d_table (table_bytes >= n_windows * n_bases * record) from d_bases; d_table may start with the
+ *                     bases themselves (d_table == d_bases: window 0 is the vector).  Synchronises `stream`.  One-time work.
+ *                     G2: the multiplications by 2^k run through the psi split -- the subgroup precondition of batch_exp_dev.
+ *   msm_table_dev:    the multiexp; `n_bases` is the length of the ORIGINAL vector (the table's window stride). */
+int mi355zk_msm_table_geometry(size_t n_bases, int group, uint32_t *window_bits, uint32_t *n_windows);
+int mi355zk_bn254_g1_msm_table_build_dev(const void *d_bases, size_t n_bases, void *d_table, size_t table_bytes, void *stream);
+int mi355zk_bn254_g2_msm_table_build_dev(const void *d_bases, size_t n_bases, void *d_table, size_t table_bytes, void *stream);
+int mi355zk_bn254_g1_msm_table_dev(const void *d_table, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
+                                   const uint32_t *density, size_t density_bits, uint32_t flags, void *stream, uint64_t out_xyz[12]);
+int mi355zk_bn254_g2_msm_table_dev(const void *d_table, size_t n_bases, size_t base_offset, const void *d_scalars, size_t n_scalars,
+                                   const uint32_t *density, size_t density_bits, uint32_t flags, void *stream, uint64_t out_xyz[24]);
 /* exponent index at which the last failing multiexp of this thread raised its error, or -1 */
 long long mi355zk_last_error_index(void);
 /* bits of the bucket field (c for the power-of-two window layouts, ceil(log2(B/2 + 1)) for the mixed-radix ones) and

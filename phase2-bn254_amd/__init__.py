@@ -17,6 +17,7 @@ from .bellman import (  # noqa: F401
     DensityTracker,
     EvaluationDomain,
     FullDensity,
+    MsmTable,
     SynthesisError,
     Worker,
     multiexp,

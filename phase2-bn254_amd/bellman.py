@@ -141,12 +141,13 @@ class _Ready:
         return self._value
 
 
-def pin_bases(arr) -> None:
+def pin_bases(arr, tables: bool = False) -> None:
     """mi355zk_bases_cache_pin: declare the HOST base vector `arr` ((n, 8) / (n, 16) u64, C-contiguous) immutable until
     unpin_bases(arr) -- the `Arc<Vec<G>>` of a Parameters object (groth16/mod.rs:216-238).  Host-buffer multiexps over it then
     keep their uploaded copy on the device.  Without the promise every call uploads its bases again."""
     assert not _is_torch(arr) and arr.flags["C_CONTIGUOUS"] and arr.dtype == np.uint64
-    rc = _lib.load().mi355zk_bases_cache_pin(arr.ctypes.data_as(C.c_void_p), arr.shape[0], {8: 1, 16: 2}[arr.shape[1]])
+    fn = _lib.load().mi355zk_bases_cache_pin_tables if tables else _lib.load().mi355zk_bases_cache_pin  # tables: + the window table (table mode)
+    rc = fn(arr.ctypes.data_as(C.c_void_p), arr.shape[0], {8: 1, 16: 2}[arr.shape[1]])
     if rc != 0:
         raise ValueError("mi355zk_bases_cache_pin: bad arguments")
 
@@ -154,6 +155,30 @@ def pin_bases(arr) -> None:
 def unpin_bases(arr=None) -> None:
     """mi355zk_bases_cache_invalidate: the promise ends (before rewriting or freeing the vector); None: every vector."""
     _lib.load().mi355zk_bases_cache_invalidate(arr.ctypes.data_as(C.c_void_p) if arr is not None else None)
+
+
+class MsmTable:
+    """The window table of a device-resident base vector (mi355zk_bn254_g{1,2}_msm_table_build_dev): pass `(table, offset)` to
+    multiexp() where `(bases, offset)` would go -- same result and errors, evaluated in table mode (one bucket set for all windows).
+    For vectors that stay put between calls: the `Arc<Vec<G>>` of groth16::Parameters (groth16/mod.rs:216-238)."""
+
+    def __init__(self, bases):
+        import torch
+
+        assert _is_torch(bases) and bases.is_cuda and bases.is_contiguous() and bases.shape[1] in (8, 16)
+        lib = _lib.load()
+        self.n_bases, self.limbs = int(bases.shape[0]), int(bases.shape[1])
+        self.group = {8: 1, 16: 2}[self.limbs]
+        c, w = C.c_uint32(), C.c_uint32()
+        if lib.mi355zk_msm_table_geometry(self.n_bases, self.group, C.byref(c), C.byref(w)) != 0:
+            raise ValueError("mi355zk_msm_table_geometry: bad arguments")
+        self.window_bits, self.n_windows = int(c.value), int(w.value)
+        self.table = torch.empty((self.n_windows * self.n_bases, self.limbs), dtype=torch.int64, device=bases.device)
+        fn = lib.mi355zk_bn254_g1_msm_table_build_dev if self.group == 1 else lib.mi355zk_bn254_g2_msm_table_build_dev
+        with torch.cuda.device(bases.device):
+            rc = fn(C.c_void_p(bases.data_ptr()), self.n_bases, C.c_void_p(self.table.data_ptr()), self.table.numel() * 8, _stream_ptr())
+        if rc != 0:
+            raise DeviceError(f"mi355zk msm_table_build rc={rc}")
 
 
 def multiexp(pool: Worker, bases, density_map, exponents, window_group=None, scalars_montgomery: bool = False) -> _Ready:
@@ -171,7 +196,19 @@ def multiexp(pool: Worker, bases, density_map, exponents, window_group=None, sca
         assert qs == n_exp  # multiexp.rs:347-352
     words, dbits = density_map.words()
     lib = _lib.load()
-    if _is_torch(arr):
+    if isinstance(arr, MsmTable):
+        import torch
+
+        if window_group is not None and tuple(window_group) != (1, 0):
+            raise ValueError("table mode evaluates all windows in one bucket set: no window groups")
+        assert exponents.is_cuda and exponents.is_contiguous()
+        out = np.zeros(12 * arr.group, dtype=np.uint64)
+        fn = lib.mi355zk_bn254_g1_msm_table_dev if arr.group == 1 else lib.mi355zk_bn254_g2_msm_table_dev
+        with torch.cuda.device(arr.table.device):
+            rc = fn(C.c_void_p(arr.table.data_ptr()), arr.n_bases, offset, C.c_void_p(exponents.data_ptr()), n_exp,
+                    words.ctypes.data_as(C.c_void_p) if words is not None else None, dbits,
+                    _lib.MSM_SCALARS_MONTGOMERY if scalars_montgomery else 0, _stream_ptr(), out.ctypes.data_as(C.c_void_p))
+    elif _is_torch(arr):
         import torch
 
         assert arr.is_cuda and exponents.is_cuda and arr.is_contiguous() and exponents.is_contiguous()

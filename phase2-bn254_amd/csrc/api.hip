@@ -31,10 +31,11 @@ int ntt_configure();
 // msm.hip
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont,
-                  MsmChunks* chunks);
+                  MsmChunks* chunks, uint64_t table_stride = 0, uint32_t table_c = 0);
+void msm_table_geometry(uint64_t n_bases, int group, uint32_t* c, uint32_t* W, uint8_t width[64]);
 int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup, bool scalars_mont,
-                  MsmChunks* chunks);
+                  MsmChunks* chunks, uint64_t table_stride = 0, uint32_t table_c = 0);
 int msm_g1_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 int msm_g2_dense_device(const void* d_bases, const void* d_bases2, const void* d_scalars, uint64_t n, hipStream_t st, uint64_t* out_xyz, uint64_t* out2_xyz);
 // point_fft.hip
@@ -696,6 +697,37 @@ int batch_mul(void* d_out, const uint64_t* base_raw, const void* d_scalars, size
   return ZK_OK;
 }
 
+// Window table of a base vector for table-mode multiexps (msm_impl.hpp: msm_device with table_stride != 0):
+//   table[w * n + i] = 2^(width[0] + .. + width[w-1]) * bases[i],  w < W,  affine records (the identity stays the identity).
+// Window w + 1 is window w multiplied by 2^width[w] -- the shared-scalar batch_exp (one inversion per 16 / 8 points); one-time work
+// per pinned parameter vector, W - 1 passes of n scalar multiplications.
+template <int GROUP>
+int msm_table_build(const void* d_bases, size_t n, void* d_table, size_t table_bytes, void* stream) {
+  using F = typename std::conditional<GROUP == 1, Fq, Fq2>::type;
+  if (n == 0) return ZK_OK;
+  if (!d_bases || !d_table || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  uint32_t c = 0, W = 0;
+  uint8_t width[64];
+  msm_table_geometry(n, GROUP, &c, &W, width);
+  if ((uint64_t)W * n > 0x7fffffffull || table_bytes < (size_t)W * n * sizeof(Affine<F>)) return ZK_ERR_BAD_ARGS;
+  hipStream_t st = (hipStream_t)stream;
+  char* t = (char*)d_table;
+  const size_t plane = n * sizeof(Affine<F>);
+  if ((const void*)t != d_bases) ZK_HIP(hipMemcpyAsync(t, d_bases, plane, hipMemcpyDeviceToDevice, st));
+  // the W - 1 multipliers 2^width[w], as canonical FrRepr, in ONE device buffer (freed after the closing synchronisation)
+  std::vector<uint64_t> ks((size_t)W * 4, 0);
+  for (uint32_t w = 0; w + 1 < W; ++w) ks[(size_t)w * 4 + (width[w] >> 6)] = 1ull << (width[w] & 63);
+  void* d_ks = nullptr;
+  ZK_HIP(hipMalloc(&d_ks, ks.size() * 8));
+  int rc = ZK_OK;
+  if (hipMemcpyAsync(d_ks, ks.data(), ks.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = ZK_ERR_DEVICE;
+  for (uint32_t w = 0; rc == ZK_OK && w + 1 < W; ++w)
+    rc = batch_exp<F>(t + (size_t)(w + 1) * plane, t + (size_t)w * plane, 0, (const char*)d_ks + (size_t)w * 32, 1, n, stream);
+  if (hipStreamSynchronize(st) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_DEVICE;
+  (void)hipFree(d_ks);
+  return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // domain constants (host arithmetic, same field code as the kernels)
 namespace {
@@ -845,7 +877,8 @@ struct DensityPool {
 template <int GROUP>
 int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                   const uint32_t* density, size_t density_bits, void* stream, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0,
-                  uint32_t flags = 0, MsmChunks* chunks = nullptr) {
+                  uint32_t flags = 0, MsmChunks* chunks = nullptr, bool table = false) {
+  // table: d_bases is the window table msm_table_build made of a vector of n_bases points (table mode, msm_impl.hpp)
   // chunks != nullptr: the exponents are handed over chunk by chunk while the call runs (msm_host_entry); d_scalars is unused
   t_last_err_index = -1;
   if (!out_xyz || (n_scalars && !d_scalars && !chunks) || (n_bases && !d_bases)) return ZK_ERR_BAD_ARGS;
@@ -875,8 +908,12 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
   long long err_index = -1;
   const bool mont = (flags & MI355ZK_MSM_SCALARS_MONTGOMERY) != 0;
   if (chunks && (chunks->n_chunks == 0 || chunks->cuts[chunks->n_chunks] != n)) return ZK_ERR_BAD_ARGS;
-  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont, chunks);
-  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont, chunks);
+  uint32_t tc = 0, tW = 0;
+  if (table) msm_table_geometry(n_bases, GROUP, &tc, &tW, nullptr);
+  const uint64_t tstride = table ? (uint64_t)n_bases : 0;
+  if (table && n_bases == 0 && n > 0) return ZK_ERR_BAD_ARGS;
+  if (GROUP == 1) rc = msm_g1_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont, chunks, tstride, tc);
+  else rc = msm_g2_device(d_bases, n_bases, base_offset, d_scalars, n, d_density, d_prefix, st, out_xyz, &err_index, wgroups, wgroup, mont, chunks, tstride, tc);
   if (rc == ZK_ERR_UNEXPECTED_IDENTITY) {
     // the kernels report the lowest BASE index that was the identity under a non-zero exponent; the exponent that owns it
     // is the (index - base_offset)-th selected one (source.rs:101-118): itself under FullDensity
@@ -925,6 +962,12 @@ struct BasesEntry {
   uint64_t tick = 0;
   bool ready = false;      // fully uploaded
   std::mutex fill_mu;      // held by the call that uploads it
+  // the vector's WINDOW TABLE (table mode, msm_impl.hpp), for vectors pinned with mi355zk_bases_cache_pin_tables: built by the first
+  // call that finds the entry ready, counted against the cache's capacity, freed with the entry
+  bool want_table = false, table_failed = false;
+  void* table = nullptr;
+  size_t table_bytes = 0;
+  std::mutex table_mu;
 };
 std::mutex g_bc_mu;
 std::vector<std::shared_ptr<BasesEntry>> g_bc;
@@ -956,18 +999,22 @@ struct BasesPin {
   const void* host;
   size_t n;
   int group;
+  bool tables;
 };
 std::vector<BasesPin> g_bc_pins;  // under g_bc_mu
 bool bases_cache_implicit() {
   static const char* env = std::getenv("MI355ZK_BASES_CACHE_IMPLICIT");
   return env && env[0] == '1';
 }
-int bases_cache_pin(const void* host, size_t n, int group) {
+int bases_cache_pin(const void* host, size_t n, int group, bool tables = false) {
   if (!host || n == 0 || (group != 1 && group != 2)) return ZK_ERR_BAD_ARGS;
   std::lock_guard<std::mutex> lk(g_bc_mu);
   for (auto& p : g_bc_pins)
-    if (p.host == host && p.n == n && p.group == group) return ZK_OK;
-  g_bc_pins.push_back(BasesPin{host, n, group});
+    if (p.host == host && p.n == n && p.group == group) {
+      p.tables = p.tables || tables;
+      return ZK_OK;
+    }
+  g_bc_pins.push_back(BasesPin{host, n, group, tables});
   return ZK_OK;
 }
 // returns the entry (locked for filling when *fill == true: the caller uploads and then sets ready) or nullptr (cache off / not
@@ -976,11 +1023,13 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
   *fill = false;
   const size_t cap = bases_cache_cap();
   if (cap == 0 || bytes > cap) return nullptr;
-  if (!bases_cache_implicit()) {
+  bool want_table = false;
+  {
     std::lock_guard<std::mutex> lk(g_bc_mu);
     bool pinned = false;
-    for (auto& p : g_bc_pins) pinned = pinned || (p.host == host && p.n == n && p.group == group);
-    if (!pinned) return nullptr;
+    for (auto& p : g_bc_pins)
+      if (p.host == host && p.n == n && p.group == group) { pinned = true; want_table = want_table || p.tables; }
+    if (!pinned && !bases_cache_implicit()) return nullptr;
   }
   const uint64_t fp = bases_fingerprint((const uint8_t*)host, bytes, group == 1 ? 64 : 128);
   std::shared_ptr<BasesEntry> hit;
@@ -988,7 +1037,7 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
     std::lock_guard<std::mutex> lk(g_bc_mu);
     for (auto& e : g_bc)
       if (e->host == host && e->n == n && e->group == group && e->dev == dev && e->fp == fp) { hit = e; break; }
-    if (hit) hit->tick = ++g_bc_tick;
+    if (hit) { hit->tick = ++g_bc_tick; hit->want_table = hit->want_table || want_table; }
   }
   if (hit) {
     std::lock_guard<std::mutex> wait_fill(hit->fill_mu);  // another thread may still be uploading it
@@ -996,11 +1045,11 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
     return nullptr;                                       // its upload failed: go uncached
   }
   auto e = std::make_shared<BasesEntry>();
-  e->host = host; e->n = n; e->group = group; e->dev = dev; e->fp = fp; e->bytes = bytes;
+  e->host = host; e->n = n; e->group = group; e->dev = dev; e->fp = fp; e->bytes = bytes; e->want_table = want_table;
   {
     std::lock_guard<std::mutex> lk(g_bc_mu);
     size_t used = 0;
-    for (auto& x : g_bc) used += x->bytes;
+    for (auto& x : g_bc) used += x->bytes + x->table_bytes;
     while (used + bytes > cap && !g_bc.empty()) {           // evict least recently used entries nobody is filling
       size_t victim = g_bc.size();
       for (size_t i = 0; i < g_bc.size(); ++i)
@@ -1008,8 +1057,9 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
       if (victim == g_bc.size()) break;
       (void)hipSetDevice(g_bc[victim]->dev);  // the victim may live on another GPU of this process
       (void)hipFree(g_bc[victim]->d);
+      (void)hipFree(g_bc[victim]->table);
       (void)hipSetDevice(dev);
-      used -= g_bc[victim]->bytes;
+      used -= g_bc[victim]->bytes + g_bc[victim]->table_bytes;
       g_bc.erase(g_bc.begin() + (long)victim);
     }
     if (used + bytes > cap) return nullptr;
@@ -1026,7 +1076,9 @@ void bases_drop(const std::shared_ptr<BasesEntry>& e) {  // a failed upload
   for (size_t i = 0; i < g_bc.size(); ++i)
     if (g_bc[i] == e) { g_bc.erase(g_bc.begin() + (long)i); break; }
   (void)hipFree(e->d);
-  e->d = nullptr;
+  (void)hipFree(e->table);
+  e->d = e->table = nullptr;
+  e->table_bytes = 0;
 }
 
 // two staging buffers for scalar chunks, a bases buffer for uncached calls, the two streams.  Leased from a pool for the duration
@@ -1100,6 +1152,7 @@ void bases_cache_invalidate(const void* host) {
     if ((host == nullptr || g_bc[i]->host == host) && g_bc[i]->ready && g_bc[i].use_count() == 1) {
       (void)hipSetDevice(g_bc[i]->dev);
       (void)hipFree(g_bc[i]->d);
+      (void)hipFree(g_bc[i]->table);
       g_bc.erase(g_bc.begin() + (long)i);
     } else {
       if (host == nullptr || g_bc[i]->host == host) g_bc[i]->fp ^= 0x9e3779b97f4a7c15ull;  // in use: never matched again
@@ -1112,7 +1165,7 @@ void bases_cache_invalidate(const void* host) {
 void host_entry_release_all() {
   {
     std::lock_guard<std::mutex> lk(g_bc_mu);
-    for (auto& e : g_bc) { (void)hipSetDevice(e->dev); (void)hipFree(e->d); }
+    for (auto& e : g_bc) { (void)hipSetDevice(e->dev); (void)hipFree(e->d); (void)hipFree(e->table); }
     g_bc.clear();
   }
   std::lock_guard<std::mutex> lk(g_stage_mu);
@@ -1129,6 +1182,35 @@ void host_entry_release_all() {
     b->p = nullptr;
     b->bytes = 0;
   }
+}
+
+// the window table of a ready cache entry whose vector was pinned with tables: built by the first call that asks (the others wait on
+// table_mu), inside the cache's capacity (no eviction for it: a table that does not fit is not built and the calls stay plain)
+template <int GROUP>
+const void* bases_table(const std::shared_ptr<BasesEntry>& e, hipStream_t st) {
+  if (!e || !e->want_table || !e->ready) return nullptr;
+  std::lock_guard<std::mutex> lk(e->table_mu);
+  if (e->table) return e->table;
+  if (e->table_failed) return nullptr;
+  uint32_t c = 0, W = 0;
+  msm_table_geometry(e->n, GROUP, &c, &W, nullptr);
+  const size_t bytes = (size_t)W * e->bytes;
+  e->table_failed = true;  // (until it has worked)
+  if ((uint64_t)W * e->n > 0x7fffffffull) return nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_bc_mu);
+    size_t used = 0;
+    for (auto& x : g_bc) used += x->bytes + x->table_bytes;
+    if (used + bytes > bases_cache_cap()) return nullptr;
+  }
+  void* t = nullptr;
+  if (hipMalloc(&t, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (msm_table_build<GROUP>(e->d, e->n, t, bytes, (void*)st) != ZK_OK) { (void)hipFree(t); return nullptr; }
+  std::lock_guard<std::mutex> g(g_bc_mu);
+  e->table = t;
+  e->table_bytes = bytes;
+  e->table_failed = false;
+  return t;
 }
 
 constexpr uint64_t HOST_CHUNK_UPLOAD = 1ull << 23;  // exponents per chunk of a streamed call whose bases travel too (link-bound)
@@ -1332,8 +1414,10 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   bool aborted = false;
   if (n_chunks > 0) {
     std::thread copier(copy_fn);
-    result = msm_dev_entry<GROUP>(d_bases, n_bases, base_offset, nullptr, n_scalars, density, density_bits, (void*)S->compute, result_xyz, 1, 0, 0,
-                                  &feed);
+    // a vector pinned WITH TABLES, already on the device, in a call that is not cut: table mode
+    const void* d_table = (n_chunks == 1 && entry && !fill) ? bases_table<GROUP>(entry, S->compute) : nullptr;
+    result = msm_dev_entry<GROUP>(d_table ? d_table : d_bases, n_bases, base_offset, nullptr, n_scalars, density, density_bits, (void*)S->compute, result_xyz,
+                                  1, 0, 0, &feed, d_table != nullptr);
     err_idx = t_last_err_index;
     if (trace) std::fprintf(stderr, "[mi355zk] host entry: result at %.2f ms (%llu chunks)\n", ms_now(), (unsigned long long)n_chunks);
     {
@@ -1475,6 +1559,19 @@ void mi355zk_shutdown(void) {
 const char* mi355zk_version(void) { return "mi355zk 0.3 (gfx950)"; }
 
 int mi355zk_bases_cache_pin(const void* host_bases, size_t n_bases, int group) { return bases_cache_pin(host_bases, n_bases, group); }
+int mi355zk_bases_cache_pin_tables(const void* host_bases, size_t n_bases, int group) { return bases_cache_pin(host_bases, n_bases, group, true); }
+int mi355zk_bases_cache_info(const void* host_bases, size_t* device_bytes, size_t* table_bytes) {
+  size_t d = 0, t = 0;
+  int found = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_bc_mu);
+    for (auto& e : g_bc)
+      if (e->host == host_bases && e->ready) { d += e->bytes; t += e->table_bytes; found = 1; }
+  }
+  if (device_bytes) *device_bytes = d;
+  if (table_bytes) *table_bytes = t;
+  return found;
+}
 void mi355zk_bases_cache_invalidate(const void* host_bases) {
   int dev = 0;
   const bool have = hipGetDevice(&dev) == hipSuccess;
@@ -1523,6 +1620,30 @@ int mi355zk_bn254_g2_msm_ex_dev(const void* d_bases, size_t n_bases, size_t base
                                 void* stream, uint64_t out_xyz[24]) {
   if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
   return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+}
+int mi355zk_msm_table_geometry(size_t n_bases, int group, uint32_t* window_bits, uint32_t* n_windows) {
+  if ((group != 1 && group != 2) || n_bases >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  uint32_t c = 0, W = 0;
+  msm_table_geometry(n_bases ? n_bases : 1, group, &c, &W, nullptr);
+  if (window_bits) *window_bits = c;
+  if (n_windows) *n_windows = W;
+  return ZK_OK;
+}
+int mi355zk_bn254_g1_msm_table_build_dev(const void* d_bases, size_t n_bases, void* d_table, size_t table_bytes, void* stream) {
+  return msm_table_build<1>(d_bases, n_bases, d_table, table_bytes, stream);
+}
+int mi355zk_bn254_g2_msm_table_build_dev(const void* d_bases, size_t n_bases, void* d_table, size_t table_bytes, void* stream) {
+  return msm_table_build<2>(d_bases, n_bases, d_table, table_bytes, stream);
+}
+int mi355zk_bn254_g1_msm_table_dev(const void* d_table, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                                   const uint32_t* density, size_t density_bits, uint32_t flags, void* stream, uint64_t out_xyz[12]) {
+  if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
+  return msm_dev_entry<1>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
+}
+int mi355zk_bn254_g2_msm_table_dev(const void* d_table, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
+                                   const uint32_t* density, size_t density_bits, uint32_t flags, void* stream, uint64_t out_xyz[24]) {
+  if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
+  return msm_dev_entry<2>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
 }
 int mi355zk_bn254_g1_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
   if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;

@@ -6,10 +6,10 @@ namespace zk {
 
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup,
-                  bool scalars_mont, MsmChunks* chunks) {
+                  bool scalars_mont, MsmChunks* chunks, uint64_t table_stride, uint32_t table_c) {
   G1Jacobian r;
   int rc = msm_device<Fq>((const G1Affine*)d_bases, n_bases, base_offset, (const uint32_t*)d_scalars, n, d_density, d_dprefix, st, &r, err_index,
-                          false, nullptr, nullptr, wgroups, wgroup, scalars_mont, chunks);
+                          false, nullptr, nullptr, wgroups, wgroup, scalars_mont, chunks, table_stride, table_c);
   if (rc == ZK_OK) std::memcpy(out_xyz, &r, sizeof r);
   return rc;
 }
@@ -18,6 +18,15 @@ void msm_geometry(uint64_t n, uint32_t wgroups, uint32_t* c, uint32_t* W) {
   MsmGeom G = choose_geom(n, 1, wgroups ? wgroups : 1);
   *c = G.c;
   *W = G.W;
+}
+
+// table mode (msm_device): the window layout a table of n_bases points is built for -- width[w] bits per window, window w scaled by
+// 2^(width[0] + .. + width[w-1])
+void msm_table_geometry(uint64_t n_bases, int group, uint32_t* c, uint32_t* W, uint8_t width[64]) {
+  const MsmGeom G = make_geom(table_window_bits(n_bases, group));
+  *c = G.c;
+  *W = G.W;
+  if (width) for (uint32_t w = 0; w < 64; ++w) width[w] = w < G.W ? G.width[w] : 0;
 }
 
 // powersoftau::utils::dense_multiexp (powersoftau/src/utils.rs:189-292): bases.len() == exponents.len(), infinity

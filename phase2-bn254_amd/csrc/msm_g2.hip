@@ -5,10 +5,10 @@ namespace zk {
 
 int msm_g2_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[24], long long* err_index, uint32_t wgroups, uint32_t wgroup,
-                  bool scalars_mont, MsmChunks* chunks) {
+                  bool scalars_mont, MsmChunks* chunks, uint64_t table_stride, uint32_t table_c) {
   G2Jacobian r;
   int rc = msm_device<Fq2>((const G2Affine*)d_bases, n_bases, base_offset, (const uint32_t*)d_scalars, n, d_density, d_dprefix, st, &r, err_index,
-                          false, nullptr, nullptr, wgroups, wgroup, scalars_mont, chunks);
+                          false, nullptr, nullptr, wgroups, wgroup, scalars_mont, chunks, table_stride, table_c);
   if (rc == ZK_OK) std::memcpy(out_xyz, &r, sizeof r);
   return rc;
 }

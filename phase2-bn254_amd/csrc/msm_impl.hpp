@@ -465,8 +465,12 @@ __global__ void __launch_bounds__(256) msm_digits_plain_kernel(const uint32_t* _
                                                               uint32_t* __restrict__ keys, unsigned long long* __restrict__ err_scalar,
                                                               uint64_t i_bias /* index of exponent 0 of this chunk in the whole call */) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   const uint32_t WL = w_hi - w_lo;
+  if (i >= n) {
+    // the (at most three) slots between the key planes: "no bucket", so that a table-mode call can read the planes as ONE array
+    if (i < kstride) for (uint32_t wl = 0; wl < WL; ++wl) keys[(uint64_t)wl * kstride + i] = G.nb;
+    return;
+  }
   bool active = true;
   if (density != nullptr) active = (density[i >> 5] >> (i & 31)) & 1;
   uint32_t s[9];
@@ -595,7 +599,8 @@ __global__ void __launch_bounds__(256) msm_tileoff_kernel(const uint16_t* __rest
 __global__ void __launch_bounds__(PART_THREADS) msm_scatter_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint64_t kstride, uint64_t base_offset,
                                                                    const uint32_t* __restrict__ density, const uint32_t* __restrict__ dprefix,
                                                                    uint32_t nb, uint32_t WL, PartGeom P, uint32_t xcds,
-                                                                   const uint32_t* __restrict__ tile_off, uint2* __restrict__ pairs) {
+                                                                   const uint32_t* __restrict__ tile_off, uint2* __restrict__ pairs,
+                                                                   uint64_t flat_stride, uint64_t table_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t nbin4 = (P.nbin + 3u) & ~3u;
   uint32_t* loff = reinterpret_cast<uint32_t*>(smem);             // nbin: counts, then exclusive offsets inside the tile
@@ -662,12 +667,18 @@ __global__ void __launch_bounds__(PART_THREADS) msm_scatter_kernel(const uint32_
       const uint32_t idx = 4u * (k4 * PART_THREADS + threadIdx.x) + e;
       const uint32_t b = key[k] & KEY_NONE_MASK;
       if (idx < cnt && b < nb) {
-        const uint64_t i = i0 + idx;
+        uint64_t i = i0 + idx, tw = 0;
+        if (flat_stride != 0) {  // table mode: position = window * flat_stride + exponent; the window's copy of the bases starts at window * table_stride
+          tw = i / flat_stride;
+          i -= tw * flat_stride;
+          tw *= table_stride;
+        }
         uint64_t bi = base_offset + i;
         if (density != nullptr) {
           const uint32_t wd = density[i >> 5];
           bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
         }
+        bi += tw;
         staging[loff[b >> P.lo_bits] + rank[k]] = make_uint2(key[k], (uint32_t)bi);
       }
     }
@@ -1339,6 +1350,27 @@ __global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J, XYZZ
   if (threadIdx.x == 0) store_vec(out + ((uint64_t)w * J.n_jobs + job) * out_stride + slice, acc);
 }
 
+// Table mode, error path only: the accumulation reports the lowest TABLE index that held the identity, which orders by window
+// first; the reference reports the lowest EXPONENT (source.rs:50-52).  One pass over the exponents and their bases (the table's first
+// window) finds it: the lowest base index that is the identity under a selected, non-zero exponent.
+template <class F>
+__global__ void __launch_bounds__(256) msm_identity_scan_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ scalars, uint64_t n,
+                                                               uint64_t base_offset, const uint32_t* __restrict__ density,
+                                                               const uint32_t* __restrict__ dprefix, unsigned long long* __restrict__ err_base) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t bi = base_offset + i;
+  if (density != nullptr) {
+    const uint32_t wd = density[i >> 5];
+    if (!((wd >> (i & 31)) & 1u)) return;
+    bi = base_offset + dprefix[i >> 5] + __popc(wd & ((1u << (i & 31)) - 1u));
+  }
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  const uint4 s0 = sp[0], s1 = sp[1];
+  if ((s0.x | s0.y | s0.z | s0.w | s1.x | s1.y | s1.z | s1.w) == 0) return;
+  if (load_affine(bases + bi).y.is_zero()) atomicMin(err_base, (unsigned long long)bi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 
@@ -1628,6 +1660,26 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
   return G;
 }
 
+// Window width of a TABLE-MODE call (msm_device, table_stride != 0) over a base vector of n_bases points: one bucket set serves all
+// windows, so the reduction is paid once and the window may be wider than choose_geom's (fewer windows = fewer additions); what
+// limits it is the length of the one reduce chain and the bucket lists getting short.  Measured (profiles/r03_table_mode.txt);
+// override: env MI355ZK_MSM_TABLE_C.  Power-of-two windows only: table[w] = 2^shift_w * P.
+uint32_t table_window_bits(uint64_t n_bases, int group) {
+  static const char* env = std::getenv("MI355ZK_MSM_TABLE_C");
+  if (env) {
+    int v = std::atoi(env);
+    if (v >= 4 && v <= 24) return (uint32_t)v;
+  }
+  uint32_t lg = 0;
+  while ((1ull << lg) < n_bases) ++lg;
+  // Only the smallest c of every window count matters (17: 15 windows, 19: 14, 20: 13, 22: 12, 24: 11).  Every bucket of the one set
+  // is populated (the top window's unsigned digits reach all of them), so the reduce runs at its full length: c = 22 costs 1.0 ms,
+  // 23: 1.6, 24: 2.8.  Short vectors need bucket LANES before anything else (2^16 points at the plain call's c = 15: 16 k lanes, 1.18 ms
+  // against 0.72 at c = 17) -- and gain nothing over the plain call below 2^19.
+  if (group == 2) return lg <= 18 ? 17u : lg == 19 ? 19u : 20u;   // (a G2 reduce step costs three G1 steps: 15 - 25 % over the plain call from 2^16 on)
+  return lg <= 16 ? 17u : lg <= 22 ? 20u : 22u;
+}
+
 // the partition kernels use up to the whole 160 KiB of LDS (dynamic): raise the limit once per device
 std::mutex g_part_cfg_mu;
 std::map<int, int> g_part_cfg;
@@ -1654,7 +1706,12 @@ template <class F>
 int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n,
                const uint32_t* d_density, const uint32_t* d_dprefix, hipStream_t st, Jacobian<F>* out, long long* err_index_out,
                bool dense = false, const Affine<F>* d_bases2 = nullptr, Jacobian<F>* out2 = nullptr, uint32_t wgroups = 1,
-               uint32_t wgroup = 0, bool scalars_mont = false, MsmChunks* chunks = nullptr) {
+               uint32_t wgroup = 0, bool scalars_mont = false, MsmChunks* chunks = nullptr, uint64_t table_stride = 0, uint32_t table_c = 0) {
+  // table_stride != 0: TABLE MODE.  d_bases is a window table of the base vector -- table[w * table_stride + i] = 2^shift_w * bases[i]
+  // for the windows of make_geom(table_c) (msm_table_build) -- so a digit of ANY window goes to the bucket of its value in ONE
+  // bucket set shared by all windows: the W key planes the digit kernel writes are read as ONE array of W * kstride (digit, table
+  // index) pairs, partitioned as a single window, accumulated into 2^(c-1) buckets and reduced once; the join is the window sum
+  // itself.  What it buys: one window's reduction instead of W, and with it a wider window (fewer additions) on short calls.
   // wgroups > 1: only window group `wgroup` of `wgroups` equal groups is evaluated -- the partial  sum_{w in group} B^w T_w
   // of this point set; the partials of all groups (and of all point ranges) add up to the multiexp (shard.py).
   // dense == true: powersoftau's dense_multiexp contract (infinity bases add nothing, no Source errors);
@@ -1673,6 +1730,8 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
   if (wgroups == 0 || wgroup >= wgroups) return ZK_ERR_BAD_ARGS;
+  const bool tmode = table_stride != 0;
+  if (tmode && (wgroups != 1 || (chunks != nullptr && chunks->n_chunks != 1) || d_bases2 != nullptr || table_c < 4 || table_c > 24 || base_offset > table_stride)) return ZK_ERR_BAD_ARGS;
   const uint64_t whole[2] = {0, n};
   const uint32_t n_chunks = chunks ? chunks->n_chunks : 1u;
   const uint64_t* cuts = chunks ? chunks->cuts : whole;
@@ -1683,10 +1742,12 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     if (cuts[c + 1] <= cuts[c] || (c > 0 && (cuts[c] & 31))) return ZK_ERR_BAD_ARGS;  // (density words are not shared between chunks)
     if (cuts[c + 1] - cuts[c] > n_max) n_max = cuts[c + 1] - cuts[c];
   }
-  const MsmGeom G = choose_geom(n, (int)(sizeof(F) / sizeof(Fq)), wgroups);
+  const MsmGeom G = tmode ? make_geom(table_c) : choose_geom(n, (int)(sizeof(F) / sizeof(Fq)), wgroups);
   if (G.W == 0 || G.W % wgroups) return ZK_ERR_BAD_ARGS;
-  const uint32_t WL = G.W / wgroups, w_lo = wgroup * WL, w_hi = w_lo + WL;  // this call's windows
-  const uint64_t m_max = n_max * WL;
+  const uint32_t WD = G.W / wgroups, w_lo = wgroup * WD, w_hi = w_lo + WD;  // this call's windows (digit planes)
+  const uint32_t WL = tmode ? 1u : WD;                                      // bucket sets: one per window, or ONE in table mode
+  if (tmode && (uint64_t)G.W * table_stride > 0x7fffffffull) return ZK_ERR_BAD_ARGS;  // (an index-list entry is a 31-bit base index + sign)
+  const uint64_t m_max = tmode ? ((n_max + 3) & ~3ull) * WD : n_max * WL;
   if (m_max > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;  // pair positions are u32
   const uint32_t n_buckets = WL * G.nb;
   // reduction: running-sum levels (msm_reduce_level_kernel, chunk length L) while more than MSM_FINAL_MAX
@@ -1712,7 +1773,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
 
   // per chunk: its partition geometry, and what one lane may walk before its bucket counts as heavy
   struct ChunkPlan {
-    uint64_t lo, n, m;
+    uint64_t lo, n, m, np;  // np: length of the array the partition sees (table mode: all key planes as one)
     PartGeom P;
     uint32_t ncell, heavy, heavy_seg, hb, max_items;
   };
@@ -1723,8 +1784,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     ChunkPlan& C = plan[c];
     C.lo = cuts[c];
     C.n = cuts[c + 1] - cuts[c];
-    C.m = C.n * WL;
-    C.P = choose_part(C.n, WL, G.nb);
+    C.np = tmode ? ((C.n + 3) & ~3ull) * WD : C.n;
+    C.m = C.np * WL;
+    C.P = choose_part(C.np, WL, G.nb);
     if (C.P.st == 0) return ZK_ERR_BAD_ARGS;
     C.ncell = WL * C.P.nbin;
     // index lists: every bucket start is padded to a multiple of 4 entries (<= 3 per bucket), every bin region to 4
@@ -1744,7 +1806,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     // dependent field products), so a bucket of 100 entries among buckets of 6 holds the launch for 0.8 ms (measured at 2^18
     // prover-like exponents: the 255 byte-valued buckets of window 0).  Hence a floor of 64, a margin of 16 over twice the mean,
     // and segments short enough (heavy_seg) that a segment's 64 lanes add a handful of points each before the tree.
-    const uint64_t mean_len = C.n / G.nb + 1;
+    const uint64_t mean_len = C.m / n_buckets + 1;
     uint64_t heavy64 = mean_len * 8 + 1024;
     const uint64_t heavy_cap = (C.m >> 17) > 64 ? (C.m >> 17) : 64;  // 8 us per entry against ~2^-17 x m x 8 us for the launch at full throughput
     if (heavy64 > heavy_cap) heavy64 = heavy_cap;
@@ -1855,10 +1917,12 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     prof_begin(slot_digits, st);
     static const bool fused_a = std::getenv("MI355ZK_PART_FUSED_A") != nullptr;  // (the one-kernel pass A, kept for the comparison in DESIGN.md)
     if (!fused_a) {
-      ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_plain_kernel<RM>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, d_sc, nc, dens, G,
+      ZK_DISPATCH_RMUL(G.rmul, hipLaunchKernelGGL(msm_digits_plain_kernel<RM>, dim3((unsigned)((kstride + 255) / 256)), dim3(256), 0, st, d_sc, nc, dens, G,
                                                   w_lo, w_hi, scalars_mont ? 1 : 0, kstride, keys, d_err + 1, C.lo));
-      hipLaunchKernelGGL(msm_tile_hist_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)P.nbin * 4, st, keys, nc, kstride, G.nb, WL, P, tile_hist);
+      hipLaunchKernelGGL(msm_tile_hist_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)P.nbin * 4, st, keys, C.np, tmode ? C.np : kstride, G.nb, WL, P,
+                         tile_hist);
     } else {
+      if (tmode) return (int)ZK_ERR_BAD_ARGS;
       int cus = 256;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       const uint32_t per_cu = (size_t)((ncell + 1) / 2) * 4 <= PART_LDS_A ? 2u : 1u;     // 1024-lane workgroups per CU (LDS histograms)
@@ -1891,7 +1955,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       static const char* env_x = std::getenv("MI355ZK_PART_XCDS");  // 1 disables the XCD-aware tile order
       const uint32_t xcds = env_x && std::atoi(env_x) >= 1 ? (uint32_t)std::atoi(env_x) : 8u;
       hipLaunchKernelGGL(msm_scatter_kernel, dim3(P.n_st * WL), dim3(PART_THREADS), (size_t)(2 * ((P.nbin + 3u) & ~3u) + 32) * 4 + (size_t)P.st * 8, st,
-                         keys, nc, kstride, boff, dens, dpre, G.nb, WL, P, xcds, tile_off, pairs);
+                         keys, C.np, tmode ? C.np : kstride, boff, dens, dpre, G.nb, WL, P, xcds, tile_off, pairs, tmode ? kstride : 0ull, table_stride);
     }
     ZK_HIP(hipGetLastError());
     prof_end(slot_scatter, st);
@@ -1901,7 +1965,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       const uint32_t nfl = (1u << P.lo_bits) < 4 ? 4 : (1u << P.lo_bits);
       const size_t fixed = (size_t)(2 * nfl + 32) * 4;
       // staging for the expected bin population with slack, at most what the CU has
-      uint64_t want = (uint64_t)(nc / P.nbin) * 5 / 4 + 3ull * nfl + 4096;
+      uint64_t want = (uint64_t)(C.np / P.nbin) * 5 / 4 + 3ull * nfl + 4096;
       const uint64_t cap_max = (PART_LDS_MAX - fixed) / 4;
       if (want > cap_max) want = cap_max;
       if (want > (uint64_t)PART_EC * PART_THREADS + 3ull * nfl) want = (uint64_t)PART_EC * PART_THREADS + 3ull * nfl;
@@ -1973,6 +2037,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     return ZK_OK;
   };
 
+  const uint32_t* d_sc_first = d_scalars;
   // ---- bucket reduction, the copy back and the host join: once per base vector
   auto finish_set = [&](Jacobian<F>* result, bool last_set) -> int {
     prof_begin(slot_red, st);
@@ -2037,7 +2102,19 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     lease.idle = true;
     static const bool trace_join = std::getenv("MI355ZK_TRACE_MSM") != nullptr;
     const auto t_join0 = std::chrono::steady_clock::now();
-    const unsigned long long h_err = h_errs[0];
+    unsigned long long h_err = h_errs[0];
+    if (tmode && h_err != ~0ull && h_errs[1] == ~0ull) {
+      // (error path) the lowest identity BASE index, by exponent order: see msm_identity_scan_kernel
+      lease.idle = false;
+      ZK_HIP(hipMemsetAsync(d_err, 0xff, 8, st));
+      hipLaunchKernelGGL(msm_identity_scan_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, d_sc_first, n, base_offset, d_density,
+                         d_dprefix, d_err);
+      ZK_HIP(hipGetLastError());
+      ZK_HIP(hipMemcpyAsync(pin.b->p, d_err, 8, hipMemcpyDeviceToHost, st));
+      ZK_HIP(hipStreamSynchronize(st));
+      std::memcpy(&h_err, pin.b->p, 8);
+      lease.idle = true;
+    }
     // the device is done with the workspace: let the next multiexp (another host thread -- the prover keeps 8 in
     // flight, prover.rs:250-298) start while this thread joins its partial sums
     if (last_set && lk.owns_lock()) lk.unlock();
@@ -2082,6 +2159,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       }
       T[wl] = horner(by_exp);
     });
+    auto wshift = [&](uint32_t w) -> uint32_t { return tmode ? 0u : G.shift[w]; };  // (table mode: the table carries the shifts)
     if (parallel && G.rmul == 1) {
       // sum_w 2^shift_w T_w: Horner over the windows from the top one down, then the shift of the group's lowest window
       acc = T[WL - 1];
@@ -2091,11 +2169,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       }
       for (uint32_t r = 0; r < G.shift[w_lo]; ++r) jac_double(acc);
     } else if (G.rmul == 1) {
-      std::vector<Jacobian<F>> by_exp((size_t)G.shift[w_hi - 1] + e_k[n_out - 1] + 1, Jacobian<F>::zero());
+      std::vector<Jacobian<F>> by_exp((size_t)wshift(w_lo + WL - 1) + e_k[n_out - 1] + 1, Jacobian<F>::zero());
       for (uint32_t wl = 0; wl < WL; ++wl)
         for (uint32_t k = 0; k < n_out; ++k) {
           const XYZZ<F>& pt = h_wsums[(size_t)wl * n_out + k];
-          if (!pt.is_zero()) jac_add(by_exp[G.shift[w_lo + wl] + e_k[k]], rec_to_jacobian(pt));
+          if (!pt.is_zero()) jac_add(by_exp[wshift(w_lo + wl) + e_k[k]], rec_to_jacobian(pt));
         }
       acc = horner(by_exp);
     } else {
@@ -2140,6 +2218,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       if (rc) return rc;
       d_sc = (const uint32_t*)p;
     }
+    d_sc_first = d_sc;  // (table mode runs a single chunk: its exponents, for the error path's rescan)
     rc = partition_chunk(C, d_sc);
     if (rc == ZK_OK && chunks) rc = chunks->digits_enqueued(c, st);  // the digit kernel is the only reader of the exponents
     if (rc == ZK_OK) rc = partition_rest(C);

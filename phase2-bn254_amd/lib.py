@@ -24,6 +24,8 @@ SIGNATURES = {
     "mi355zk_shutdown": (None, []),
     "mi355zk_version": (C.c_char_p, []),
     "mi355zk_bases_cache_pin": (_i, [_vp, _sz, _i]),
+    "mi355zk_bases_cache_pin_tables": (_i, [_vp, _sz, _i]),
+    "mi355zk_bases_cache_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "mi355zk_bases_cache_invalidate": (None, [_vp]),
     "mi355zk_bn254_g1_msm": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_msm": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp]),
@@ -33,6 +35,11 @@ SIGNATURES = {
     "mi355zk_bn254_g2_msm_part_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _vp, _vp]),
     "mi355zk_bn254_g1_msm_ex_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _u32, _vp, _vp]),
     "mi355zk_bn254_g2_msm_ex_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _u32, _u32, _vp, _vp]),
+    "mi355zk_msm_table_geometry": (_i, [_sz, _i, C.POINTER(_u32), C.POINTER(_u32)]),
+    "mi355zk_bn254_g1_msm_table_build_dev": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "mi355zk_bn254_g2_msm_table_build_dev": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "mi355zk_bn254_g1_msm_table_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _vp, _vp]),
+    "mi355zk_bn254_g2_msm_table_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _vp, _vp]),
     "mi355zk_bn254_g1_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g2_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g1_merge_pairs_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
