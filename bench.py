@@ -179,6 +179,19 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
                               "kernel_ms": {kk: (round(v, 4) if v is not None else None) for kk, v in kern.items()},
                               "note": "integer-ALU bound (DESIGN.md 4); %d B per scalar-mul algorithmic" % bytes_per}}
+        # the same call in TABLE MODE (include/mi355zk.h: a precomputed window table of the base vector, one bucket set for all
+        # windows) -- for vectors that do not change between calls, like the Parameters a prover queries; same affine point
+        tb = zk.MsmTable(b)
+        zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
+        t = time.perf_counter()
+        for _ in range(iters):
+            res_t = zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
+        dt_t = (time.perf_counter() - t) / iters
+        Gt = O.G1 if group == 1 else O.G2
+        entry["table_mode"] = {"value": round(n / dt_t / 1e6, 2), "unit": "Mscalar-mul/s", "ms": round(dt_t * 1e3, 3), "window_bits": tb.window_bits,
+                               "windows": tb.n_windows, "table_MB": round(tb.table.numel() * 8 / 2**20, 1),
+                               "same_point": bool(np.array_equal(Gt.to_affine(res_t), Gt.to_affine(res)))}
+        del tb
         if cpu:
             ns = n if group == 1 else n >> 2
             hb = b[:ns].cpu().numpy().view(np.uint64)

@@ -38,8 +38,12 @@ struct Parameters {  // mod.rs:216-238
   // to the library (mi355zk_bases_cache_pin), so that the host-buffer multiexps of every later proof find the vectors on the device
   // and only the exponents cross PCIe; unpin() ends the promise -- call it before the Parameters object (the last owner of the
   // vectors) goes away.  Without pin() every multiexp uploads its bases again: correct, slower.
-  void pin() const {
-    auto one = [](const void* p, size_t n, int group) { if (n) (void)mi355zk_bases_cache_pin(p, n, group); };
+  // pin(true): the library may also keep each vector's WINDOW TABLE on the device (mi355zk_bases_cache_pin_tables): the multiexps of
+  // the third proof on run in table mode -- one bucket set for all windows, include/mi355zk.h -- at 13 - 15 times the device memory.
+  void pin(bool tables = false) const {
+    auto one = [tables](const void* p, size_t n, int group) {
+      if (n) (void)(tables ? mi355zk_bases_cache_pin_tables(p, n, group) : mi355zk_bases_cache_pin(p, n, group));
+    };
     one(h->data(), h->size(), 1); one(l->data(), l->size(), 1); one(a->data(), a->size(), 1); one(b_g1->data(), b_g1->size(), 1);
     one(b_g2->data(), b_g2->size(), 2);
   }

@@ -36,6 +36,17 @@ class Parameters:
     def __init__(self, vk, h, l, a, b_g1, b_g2):  # noqa: E741
         self.vk, self.h, self.l, self.a, self.b_g1, self.b_g2 = vk, h, l, a, b_g1, b_g2
 
+    def with_tables(self, g1_min: int = 1 << 19, g2_min: int = 1 << 16) -> "Parameters":
+        """The same parameters with WINDOW TABLES (bellman.MsmTable: table mode, include/mi355zk.h) in place of the vectors long
+        enough to gain from them -- the vectors of a circuit's Parameters are the same for every proof, which is what a table needs.
+        Costs n_windows (13 - 15) times the vector's memory; the proofs are byte-identical."""
+        from .bellman import MsmTable
+
+        def tab(v, lo):
+            return MsmTable(v) if not isinstance(v, MsmTable) and int(v.shape[0]) >= lo else v
+
+        return Parameters(self.vk, tab(self.h, g1_min), tab(self.l, g1_min), tab(self.a, g1_min), tab(self.b_g1, g1_min), tab(self.b_g2, g2_min))
+
     def get_vk(self, _num_inputs):
         return self.vk
 

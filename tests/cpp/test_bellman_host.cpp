@@ -317,8 +317,18 @@ int main() {
     CHECK(std::memcmp(wc, &proof.c, 64) == 0);
     // a second proof on the same parameters (bases served from the device cache) is the same proof
     const Proof again = create_proof(worker, params, pa, r, s);
-    params.unpin();
     CHECK(std::memcmp(&again, &proof, sizeof proof) == 0);
+    // pinned WITH TABLES: the next proof builds the window tables of the cached vectors and runs its multiexps in table mode, the one
+    // after that finds them -- the same proof every time
+    params.pin(true);
+    const Proof third = create_proof(worker, params, pa, r, s);
+    const Proof fourth = create_proof(worker, params, pa, r, s);
+    size_t dev_bytes = 0, tab_bytes = 0;
+    CHECK(mi355zk_bases_cache_info(params.h->data(), &dev_bytes, &tab_bytes) == 1 && tab_bytes > dev_bytes);
+    params.unpin();
+    CHECK(mi355zk_bases_cache_info(params.h->data(), &dev_bytes, &tab_bytes) == 0);
+    CHECK(std::memcmp(&third, &proof, sizeof proof) == 0);
+    CHECK(std::memcmp(&fourth, &proof, sizeof proof) == 0);
   }
   std::puts("ok groth16_create_proof");
   return 0;

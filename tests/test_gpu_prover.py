@@ -120,3 +120,8 @@ def test_create_proof_matches_the_oracle(zk, worker, log_m, concurrent):
     # domain, domain.rs:52), so a second proof from the same assignment is the same proof
     again = P.create_proof(worker, params, assignment, r, s, concurrent=concurrent)
     assert np.array_equal(again[0], got_a) and np.array_equal(again[1], got_b) and np.array_equal(again[2], got_c)
+    # Parameters with window tables (table mode: every vector long enough here by lowering the thresholds): the same proof
+    tabled = params.with_tables(g1_min=1, g2_min=1)
+    assert isinstance(tabled.h, zk.MsmTable) and isinstance(tabled.b_g2, zk.MsmTable)
+    third = P.create_proof(worker, tabled, assignment, r, s, concurrent=concurrent)
+    assert np.array_equal(third[0], got_a) and np.array_equal(third[1], got_b) and np.array_equal(third[2], got_c)

@@ -11,6 +11,7 @@ import phase2_bn254_amd as zk, inputs, oracle_lib as O, bn254_model as M
 
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-n", type=int, default=3000)
+ap.add_argument("--table", action="store_true", help="evaluate through TABLE MODE (MsmTable of the device-resident vector); MI355ZK_MSM_TABLE_C selects the table's window width")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 w = zk.Worker(0)
@@ -49,12 +50,17 @@ for case in range(a.cases):
     if pool == 2: bases = pools[g][np.where(rng.random(offset + nb_needed) < 0.5, 0, 12)]  # P and -P only
     rc_o, want = G.multiexp(bases, sc, density=dens_words, density_bits=n if use_density else None, base_offset=offset, threads=4)
     try:
-        got = zk.multiexp(w, (bases, offset), dm, sc).wait()
+        if a.table:
+            import torch
+            dv = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).cuda()
+            got = zk.multiexp(w, (zk.MsmTable(dv(bases)), offset), dm, dv(sc)).wait()
+        else:
+            got = zk.multiexp(w, (bases, offset), dm, sc).wait()
         ok = rc_o == 0 and np.array_equal(G.to_affine(got), G.to_affine(want))
     except zk.SynthesisError as e:
         ok = rc_o != 0
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: g={g} n={n} pool={pool} scal={scal_kind} density={use_density} offset={offset} rc_o={rc_o}")
-print(f"fuzz: {a.cases - bad}/{a.cases} ok  (C={os.environ.get('MI355ZK_MSM_C')}, RADIX={os.environ.get('MI355ZK_MSM_RADIX')})")
+print(f"fuzz{' (table mode)' if a.table else ''}: {a.cases - bad}/{a.cases} ok  (C={os.environ.get('MI355ZK_MSM_C')}, RADIX={os.environ.get('MI355ZK_MSM_RADIX')}, TABLE_C={os.environ.get('MI355ZK_MSM_TABLE_C')})")
 sys.exit(1 if bad else 0)

@@ -11,4 +11,11 @@ for cfg in "" "C=4" "C=7" "C=11" "C=15" "R=3,6" "R=5,6" "R=3,9" "R=5,12"; do
   export MI355ZK_HOST_CHUNK_TEST=64
   timeout 300 python tools/fuzz_msm.py --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 | sed 's/^fuzz:/fuzz (chunks of 64):/' || rc=1
 done
+# table mode (one bucket set for all windows over a window table of the vector), several table window widths
+unset MI355ZK_MSM_C MI355ZK_MSM_RADIX MI355ZK_HOST_CHUNK_TEST
+for tc in "" 4 7 11 17 20; do
+  unset MI355ZK_MSM_TABLE_C
+  [ -n "$tc" ] && export MI355ZK_MSM_TABLE_C=$tc
+  timeout 600 python tools/fuzz_msm.py --table --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 || rc=1
+done
 exit $rc
