@@ -1312,30 +1312,40 @@ constexpr uint32_t MSM_MAX_LEVELS = 8;
 constexpr uint32_t MSM_MAX_JOBS = MSM_MAX_LEVELS + 24;
 template <class F>
 struct TreeJobs {
-  const XYZZ<F>* in[MSM_MAX_JOBS];   // job j sums in[j][w * stride[j] + x], x < cnt[j] (bit[j] < 0), or only the x with
-  uint32_t cnt[MSM_MAX_JOBS];        // bit bit[j] of (x + off) set
+  // job j sums the elements x < cnt[j] of  in[j] + w * stride[j] + rep * rep_stride[j]  taken elem_stride[j] apart (bit[j] < 0), or
+  // only the x with bit bit[j] of (x + off[j]) set; a job is a FAMILY of reps[j] such sums (the rows / the columns of the 2-D tail);
+  // an element exists while rep * rep_stride + x * elem_stride < limit[j]
+  const XYZZ<F>* in[MSM_MAX_JOBS];
+  XYZZ<F>* out[MSM_MAX_JOBS];        // slice sum of (w, rep, slice) -> out[j][(w * out_w[j] + rep) * slices(j) + slice]
+  uint32_t cnt[MSM_MAX_JOBS];
   uint32_t stride[MSM_MAX_JOBS];
+  uint32_t reps[MSM_MAX_JOBS], rep_stride[MSM_MAX_JOBS], elem_stride[MSM_MAX_JOBS], limit[MSM_MAX_JOBS];
+  uint32_t out_w[MSM_MAX_JOBS];
+  uint32_t off[MSM_MAX_JOBS];
   int32_t bit[MSM_MAX_JOBS];
-  uint32_t first_block[MSM_MAX_JOBS + 1];  // prefix sums of the slice counts: blocks per window = first_block[n_jobs]
-  uint32_t n_jobs, off;
+  uint32_t first_block[MSM_MAX_JOBS + 1];  // prefix sums of reps * slices: blocks per window = first_block[n_jobs]
+  uint32_t n_jobs;
 };
-// out[(w * n_jobs + job) * out_stride + slice]
 template <class F>
-__global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J, XYZZ<F>* __restrict__ out, uint32_t out_stride) {
+__global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t per_w = J.first_block[J.n_jobs];
   const uint32_t w = blockIdx.x / per_w, r = blockIdx.x % per_w;
   uint32_t job = 0;
   while (job + 1 < J.n_jobs && J.first_block[job + 1] <= r) ++job;
-  const uint32_t slice = r - J.first_block[job];
   const uint32_t count = J.cnt[job];
+  const uint32_t slices = (count + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
+  const uint32_t idx = r - J.first_block[job];
+  const uint32_t rp = idx / slices, slice = idx % slices;
   const int32_t bit = J.bit[job];
-  const XYZZ<F>* P = J.in[job] + (uint64_t)w * J.stride[job];
+  const uint32_t off = J.off[job], es = J.elem_stride[job];
+  const uint32_t rbase = rp * J.rep_stride[job], limit = J.limit[job];
+  const XYZZ<F>* P = J.in[job] + (uint64_t)w * J.stride[job] + rbase;
   const uint32_t x0 = slice * MSM_TREE_SLICE + threadIdx.x, x1 = x0 + 256;
   XYZZ<F> acc = XYZZ<F>::zero(), other = XYZZ<F>::zero();
-  if (x0 < count && (bit < 0 || (((x0 + J.off) >> bit) & 1))) acc = load_vec(P + x0);
-  if (x1 < count && (bit < 0 || (((x1 + J.off) >> bit) & 1))) other = load_vec(P + x1);
+  if (x0 < count && (uint64_t)rbase + (uint64_t)x0 * es < limit && (bit < 0 || (((x0 + off) >> bit) & 1))) acc = load_vec(P + (uint64_t)x0 * es);
+  if (x1 < count && (uint64_t)rbase + (uint64_t)x1 * es < limit && (bit < 0 || (((x1 + off) >> bit) & 1))) other = load_vec(P + (uint64_t)x1 * es);
   // ONE inlined xyzz_add for the pair and for every tree level (code size).  Lanes [s, 2s) publish, lanes [0, s)
   // consume; the regions written in consecutive rounds are disjoint from the ones still being read, so one
   // barrier per round.
@@ -1347,7 +1357,7 @@ __global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J, XYZZ
     __syncthreads();
     other = threadIdx.x < s ? sh[threadIdx.x + s] : XYZZ<F>::zero();
   }
-  if (threadIdx.x == 0) store_vec(out + ((uint64_t)w * J.n_jobs + job) * out_stride + slice, acc);
+  if (threadIdx.x == 0) store_vec(J.out[job] + ((uint64_t)w * J.out_w[job] + rp) * slices + slice, acc);
 }
 
 // Table mode, error path only: the accumulation reports the lowest TABLE index that held the identity, which orders by window
@@ -1758,7 +1768,19 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t final_cnt = G.nb;
   static const char* env_fmax = std::getenv("MI355ZK_MSM_FINAL_MAX");
   const uint32_t final_max = env_fmax && std::atoi(env_fmax) >= 64 ? (uint32_t)std::atoi(env_fmax) : MSM_FINAL_MAX;
+  // 2-D TAIL (round 3): once at most 2^17 elements are left over all windows (and at most 2^18 per window), the weighted sum of the
+  // last array S is finished in TWO tree launches instead of further levels and a bit decomposition of what they leave:
+  //   x = r * cols + c:   sum_x (x + off) S[x] = cols * sum_r r R_r + sum_c (c + off) C_c,   R_r / C_c = the row / column sums,
+  // launch 1 = the rows, the columns (<= 512 elements each) and the levels' A[] as plain tree sums, launch 2 = the bit decompositions of
+  // R and C (and the A[] slice sums).  A running-sum level costs 2L dependent additions and a launch however few lanes it has left;
+  // the tail is a chain: table mode (ONE window of 2^19 buckets) 0.545 -> 0.424 ms at 2^20.
+  // env MI355ZK_MSM_NO_TAIL2D restores the levels-to-1024 schedule for the comparison.
+  static const bool no_tail2d = std::getenv("MI355ZK_MSM_NO_TAIL2D") != nullptr;
   while (final_cnt > final_max && n_levels < MSM_MAX_LEVELS) {
+    // (rows and columns of at least 128 elements: a tree workgroup spends nine rounds on its slice however few elements it holds, so
+    // 16 windows x 8192 elements as 64 x 128 made the 2^20 reduce SLOWER, 0.40 -> 0.71 ms; G1 only: a G2 tree round costs three G1
+    // rounds and the two launches gained nothing over the levels, 1.36 -> 1.38 ms)
+    if (!no_tail2d && sizeof(F) == sizeof(Fq) && (uint64_t)final_cnt * WL <= (1ull << 17) && final_cnt >= (1u << 15) && final_cnt <= (1u << 18)) break;
     const uint32_t logl = (uint64_t)final_cnt * WL >= (1ull << 20) ? 3 : 2;
     lvl_cnt[n_levels] = final_cnt;
     lvl_logl[n_levels] = logl;
@@ -1768,8 +1790,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     ++n_levels;
   }
   const uint32_t final_off = n_levels == 0 ? 1u : 0u;  // bucket x of a window has weight x + 1; chunk sums have weight ch
-  uint32_t final_bits = 1;
-  while ((1u << final_bits) <= final_cnt - 1 + final_off) ++final_bits;
+  const bool tail2d = !no_tail2d && sizeof(F) == sizeof(Fq) && final_cnt >= (1u << 15) && final_cnt <= (1u << 18) && (uint64_t)final_cnt * WL <= (1ull << 17);
+  uint32_t cols_log = 0;
+  if (tail2d) {
+    uint32_t lg = 0;
+    while ((1u << lg) < final_cnt) ++lg;
+    cols_log = (lg + 1) / 2;
+  }
+  const uint32_t t_cols = tail2d ? 1u << cols_log : final_cnt, t_rows = tail2d ? (final_cnt + t_cols - 1) / t_cols : 0;
+  uint32_t final_bits = 1;                                   // bits of the column index (of the whole index without the 2-D tail)
+  while ((1u << final_bits) <= t_cols - 1 + final_off) ++final_bits;
+  uint32_t row_bits = 0;                                     // bits of the row index
+  while (t_rows > 1 && (1u << row_bits) <= t_rows - 1) ++row_bits;
 
   // per chunk: its partition geometry, and what one lane may walk before its bucket counts as heavy
   struct ChunkPlan {
@@ -1837,7 +1869,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   size_t o_buckets = take((size_t)n_buckets * sizeof(XYZZ<F>));
   size_t o_partA = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
   size_t o_partS = take((size_t)WL * total_chunks * sizeof(XYZZ<F>));
-  const uint32_t n_out = n_levels + final_bits;  // per window: one A-sum per level, then one sum per bit
+  const uint32_t n_out = n_levels + final_bits + row_bits;  // per window: one A-sum per level, then one sum per (column) bit, then one per row bit
+  if (n_out + 2 > MSM_MAX_JOBS) return ZK_ERR_BAD_ARGS;
+  size_t o_rc = take((size_t)WL * (t_rows + t_cols) * sizeof(XYZZ<F>));  // 2-D tail: row sums, then column sums, per window
   size_t o_wsums = take((size_t)WL * n_out * sizeof(XYZZ<F>));
   size_t o_err = take(16);  // [0] lowest identity base index, [1] lowest index of a non-canonical exponent -- right behind the window sums: ONE copy brings both back
   // slice sums of msm_tree_kernel (two ping-pong halves): n_out jobs per window, slices of the longest job
@@ -2059,31 +2093,85 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
         in = S;
         o += lvl_chunks[lv];
       }
-      for (uint32_t j = 0; j < final_bits; ++j) {
-        J.in[n_levels + j] = in;
-        J.cnt[n_levels + j] = J.stride[n_levels + j] = final_cnt;
-        J.bit[n_levels + j] = (int32_t)j;
+      // jobs of the first tree launch: the levels' A[] (plain sums), then either the bit decomposition of the last array S (`in`)
+      // or, with the 2-D tail, its row and column sums; the second launch then carries the bit decompositions of those
+      XYZZ<F>* rc = (XYZZ<F>*)(ws + o_rc);
+      auto plain = [&](uint32_t j) { J.reps[j] = 1; J.rep_stride[j] = 0; J.elem_stride[j] = 1; J.limit[j] = 0xffffffffu; J.off[j] = 0; };
+      for (uint32_t lv = 0; lv < n_levels; ++lv) plain(lv);
+      uint32_t n_jobs = n_levels;
+      if (!tail2d) {
+        for (uint32_t j = 0; j < final_bits; ++j, ++n_jobs) {
+          plain(n_jobs);
+          J.in[n_jobs] = in;
+          J.cnt[n_jobs] = J.stride[n_jobs] = final_cnt;
+          J.bit[n_jobs] = (int32_t)j;
+          J.off[n_jobs] = final_off;
+        }
+      } else {
+        // rows: t_rows sums of t_cols consecutive elements; columns: t_cols sums of t_rows elements t_cols apart
+        J.in[n_jobs] = in; J.cnt[n_jobs] = t_cols; J.stride[n_jobs] = final_cnt; J.bit[n_jobs] = -1; J.off[n_jobs] = 0;
+        J.reps[n_jobs] = t_rows; J.rep_stride[n_jobs] = t_cols; J.elem_stride[n_jobs] = 1; J.limit[n_jobs] = final_cnt;
+        ++n_jobs;
+        J.in[n_jobs] = in; J.cnt[n_jobs] = t_rows; J.stride[n_jobs] = final_cnt; J.bit[n_jobs] = -1; J.off[n_jobs] = 0;
+        J.reps[n_jobs] = t_cols; J.rep_stride[n_jobs] = 1; J.elem_stride[n_jobs] = t_cols; J.limit[n_jobs] = final_cnt;
+        ++n_jobs;
       }
-      J.n_jobs = n_out;
-      J.off = final_off;
       const size_t lds = 256 * sizeof(XYZZ<F>);
       XYZZ<F>* dst = sumtmp;
-      for (;;) {
+      for (uint32_t launch = 0;; ++launch) {
+        const bool families = tail2d && launch == 0;  // (this launch leaves R and C behind: another one must follow)
         uint32_t left = 1;  // longest row of slice sums this launch leaves
-        for (uint32_t j = 0; j < n_out; ++j) {
+        uint64_t o_dst = 0;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
           const uint32_t sl = (J.cnt[j] + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
-          J.first_block[j + 1] = J.first_block[j] + sl;
+          J.first_block[j + 1] = J.first_block[j] + J.reps[j] * sl;
           if (sl > left) left = sl;
         }
-        const bool last = left == 1;
-        hipLaunchKernelGGL(msm_tree_kernel<F>, dim3(J.first_block[n_out] * WL), dim3(256), lds, st, J, last ? wsums : dst, left);
+        const bool last = left == 1 && !families;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+          const uint32_t sl = (J.cnt[j] + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
+          if (families && j >= n_levels) {            // rows -> rc[w][0 .. t_rows), columns -> rc[w][t_rows .. t_rows + t_cols)
+            J.out[j] = rc + (j == n_levels ? 0 : t_rows);
+            J.out_w[j] = t_rows + t_cols;
+          } else if (last) {
+            J.out[j] = wsums + j;
+            J.out_w[j] = n_out;
+          } else {
+            J.out[j] = dst + o_dst;                   // WL x sl slice sums of this job
+            J.out_w[j] = 1;
+            o_dst += (uint64_t)WL * sl;
+          }
+        }
+        J.n_jobs = n_jobs;
+        hipLaunchKernelGGL(msm_tree_kernel<F>, dim3(J.first_block[n_jobs] * WL), dim3(256), lds, st, J);
         ZK_HIP(hipGetLastError());
         if (last) break;
-        for (uint32_t j = 0; j < n_out; ++j) {  // next launch: plain sums of the rows of slice sums
-          J.in[j] = dst + (uint64_t)j * left;
-          J.cnt[j] = (J.cnt[j] + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
-          J.stride[j] = n_out * left;
+        // next launch: plain sums of the rows of slice sums ...
+        for (uint32_t j = 0; j < (families ? n_levels : n_jobs); ++j) {
+          const uint32_t sl = (J.cnt[j] + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE;
+          J.in[j] = J.out[j];
+          J.cnt[j] = J.stride[j] = sl;
           J.bit[j] = -1;
+          plain(j);
+        }
+        if (families) {
+          // ... and the bit decompositions of the column sums (weights c + off, 2^e) and of the row sums (weights r, 2^(cols_log + e))
+          n_jobs = n_levels;
+          for (uint32_t j = 0; j < final_bits; ++j, ++n_jobs) {
+            plain(n_jobs);
+            J.in[n_jobs] = rc + t_rows;
+            J.cnt[n_jobs] = t_cols;
+            J.stride[n_jobs] = t_rows + t_cols;
+            J.bit[n_jobs] = (int32_t)j;
+            J.off[n_jobs] = final_off;
+          }
+          for (uint32_t j = 0; j < row_bits; ++j, ++n_jobs) {
+            plain(n_jobs);
+            J.in[n_jobs] = rc;
+            J.cnt[n_jobs] = t_rows;
+            J.stride[n_jobs] = t_rows + t_cols;
+            J.bit[n_jobs] = (int32_t)j;
+          }
         }
         dst = dst == sumtmp ? sumtmp + (uint64_t)WL * tree_tmp : sumtmp;
       }
@@ -2136,6 +2224,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       e_lv += lvl_logl[lv];
     }
     for (uint32_t j = 0; j < final_bits; ++j) e_k[n_levels + j] = e_lv + j;
+    for (uint32_t j = 0; j < row_bits; ++j) e_k[n_levels + final_bits + j] = e_lv + cols_log + j;   // (2-D tail: the row index weighs cols = 2^cols_log)
+    uint32_t e_max = 0;
+    for (uint32_t k = 0; k < n_out; ++k) e_max = std::max(e_max, e_k[k]);
     auto horner = [](std::vector<Jacobian<F>>& by_exp) {  // sum_t 2^t by_exp[t]
       Jacobian<F> acc = by_exp.back();
       for (int t = (int)by_exp.size() - 2; t >= 0; --t) {
@@ -2152,7 +2243,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     static const bool join_serial = std::getenv("MI355ZK_MSM_JOIN_SERIAL") != nullptr;
     std::vector<Jacobian<F>> T(WL);
     const bool parallel = !join_serial && WL >= 4 && join_pool.run(WL, [&](uint32_t wl) {
-      std::vector<Jacobian<F>> by_exp((size_t)e_k[n_out - 1] + 1, Jacobian<F>::zero());
+      std::vector<Jacobian<F>> by_exp((size_t)e_max + 1, Jacobian<F>::zero());
       for (uint32_t k = 0; k < n_out; ++k) {
         const XYZZ<F>& pt = h_wsums[(size_t)wl * n_out + k];
         if (!pt.is_zero()) jac_add(by_exp[e_k[k]], rec_to_jacobian(pt));
@@ -2169,7 +2260,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       }
       for (uint32_t r = 0; r < G.shift[w_lo]; ++r) jac_double(acc);
     } else if (G.rmul == 1) {
-      std::vector<Jacobian<F>> by_exp((size_t)wshift(w_lo + WL - 1) + e_k[n_out - 1] + 1, Jacobian<F>::zero());
+      std::vector<Jacobian<F>> by_exp((size_t)wshift(w_lo + WL - 1) + e_max + 1, Jacobian<F>::zero());
       for (uint32_t wl = 0; wl < WL; ++wl)
         for (uint32_t k = 0; k < n_out; ++k) {
           const XYZZ<F>& pt = h_wsums[(size_t)wl * n_out + k];
@@ -2194,7 +2285,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
           jac_add(acc, T[w - (int)w_lo]);
           continue;
         }
-        std::vector<Jacobian<F>> by_exp((size_t)e_k[n_out - 1] + 1, Jacobian<F>::zero());
+        std::vector<Jacobian<F>> by_exp((size_t)e_max + 1, Jacobian<F>::zero());
         for (uint32_t k = 0; k < n_out; ++k) {
           const XYZZ<F>& pt = h_wsums[(size_t)(w - (int)w_lo) * n_out + k];
           if (!pt.is_zero()) jac_add(by_exp[e_k[k]], rec_to_jacobian(pt));
