@@ -27,7 +27,7 @@ timeout 300 python $R/tools/bench_contribute.py > $O/contribute_2e20.json 2>/dev
 timeout 400 python $R/tools/bench_host_entry.py --log-n 20 24 26 > $O/host_entry.json 2>/dev/null
 timeout 400 python $R/tools/bench_shard_cells.py > $O/shard_cells_2e26.json 2>/dev/null
 for ln in 16 20 24; do timeout 300 python $R/tools/bench_ntt.py --log-n $ln; done > $O/ntt_16_20_24.json 2>/dev/null
-for ln in 12 14 18 19 21 22 23 26 28; do timeout 300 python $R/tools/bench_ntt.py --log-n $ln; done > $O/ntt_other_sizes.json 2>/dev/null
+for ln in 12 14 18 19 21 22 23 25 26 28; do timeout 300 python $R/tools/bench_ntt.py --log-n $ln; done > $O/ntt_other_sizes.json 2>/dev/null
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAIT_ANY -d /tmp/p_ns1 -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d /tmp/p_ns2 -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
 { python $R/tools/pmc_kernel.py $(find /tmp/p_ns1 -name "*.db" | head -1) ntt_pass_kernel; python $R/tools/pmc_kernel.py $(find /tmp/p_ns2 -name "*.db" | head -1) ntt_pass_kernel; } > $O/ntt20_pass_sq_pmc.txt 2>&1
@@ -37,7 +37,8 @@ $R/tools/bin/ubench_valu > $O/ubench_valu.txt 2>&1
 $R/tools/bin/ubench_gather > $O/ubench_gather.txt 2>&1
 $R/tools/bin/ubench_fieldmul > $O/ubench_fieldmul.txt 2>&1
 $R/tools/bin/ubench_wave_bucket > $O/ubench_wave_bucket.txt 2>&1
-for lm in 16 20; do timeout 200 python $R/tools/bench_prover.py --log-m $lm; done > $O/prover.json 2>/dev/null
+for lm in 16 20 22; do timeout 300 python $R/tools/bench_prover.py --log-m $lm; done > $O/prover.json 2>/dev/null
+{ for ln in 19 20 22 23; do timeout 300 python $R/tools/bench_table.py --log-n $ln --iters 10; done; for ln in 16 20 22; do timeout 300 python $R/tools/bench_table.py --group 2 --log-n $ln --iters 8; done; } > $O/table_mode.json 2>/dev/null
 for ln in 16 20; do timeout 200 python $R/tools/bench_skew.py --log-n $ln --iters 10; done > $O/skew_small.json 2>/dev/null
 rm -rf /tmp/p_g; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_g -- $R/tools/bin/ubench_gather > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_g -name "*.db" | head -1) --pmc > $O/ubench_gather_fetch_size.txt

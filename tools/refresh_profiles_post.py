@@ -14,13 +14,13 @@ put("bench_n1.json", "bench_n1.json"); put("bench_2e20.json", "bench_2e20.json")
 put("next_rows_2e20.json", "next_rows_2e20.json"); put("ntt20.json", "ntt20.json")
 put("contribute_2e20.json", "contribute_2e20.json"); put("host_entry.json", "host_entry.json"); put("shard_cells_2e26.json", "shard_cells_2e26.json")
 put("ntt_16_20_24.json", "ntt_16_20_24.json"); put("skew_2e26.json", "skew_2e26.json"); put("bench_n1_tau.json", "bench_n1_tau.json")
-put("ubench_valu.txt", "ubench_valu.txt"); put("ntt_other_sizes.json", "ntt_other_sizes.json"); put("ubench_fieldmul.txt", "ubench_fieldmul.txt"); put("ubench_wave_bucket.txt", "ubench_wave_bucket.txt"); put("prover.json", "prover.json"); put("skew_small.json", "skew_16_20.json")
+put("table_mode.json", "table_mode.json"); put("ubench_valu.txt", "ubench_valu.txt"); put("ntt_other_sizes.json", "ntt_other_sizes.json"); put("ubench_fieldmul.txt", "ubench_fieldmul.txt"); put("ubench_wave_bucket.txt", "ubench_wave_bucket.txt"); put("prover.json", "prover.json"); put("skew_small.json", "skew_16_20.json")
 put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
     "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, 2^26-point G1 MSM)\n"
     "# summarised from the rocpd database with tools/rocpd_summary.py (ROCm 7.2 rocprofv3 writes rocpd; same numbers as --stats)\n"
     "# batch_exp_kernel = synthetic-input generation (outside the timed region); every msm_* launch is a full-size step\n"
     "# (1 warm-up + 3 timed + 2 of the linearity check); msm_accumulate_kernel is the dominant kernel of a step\n")
-put("ntt20_pass_sq_pmc.txt", "ntt20_pass_sq_pmc.txt", "# ntt_pass_kernel, 2^20 elements (2 passes of 1024-point rows, 256 tiles of 4 x 1024, one 1024-lane workgroup per CU), per dispatch,\n# rocprofv3 --pmc (two passes of 8 / 7 counters), tools/bench_ntt.py --log-n 20; SQ cycle counters tick once per 4 clocks\n")
+put("ntt20_pass_sq_pmc.txt", "ntt20_pass_sq_pmc.txt", "# ntt_pass_kernel, 2^20 elements (2 passes of 1024-point rows, 512 tiles of 2 x 1024, two 512-lane workgroups per CU), per dispatch,\n# rocprofv3 --pmc (two passes of 8 / 7 counters), tools/bench_ntt.py --log-n 20; SQ cycle counters tick once per 4 clocks\n")
 put("msm20_timeline.txt", "msm20_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_one_msm.py: the launches of ONE 2^20-point G1 multiexp in order (start offset, duration incl. the\n# profiler's serialisation, gap to the previous kernel); the host join (0.14 ms) follows the last copy\n")
 put("ntt20_kernel_stats.txt", "ntt20_kernel_stats.txt", "# rocprofv3 --kernel-trace -- python tools/bench_ntt.py --check   (MI355X, 2^20 Fr NTT, 20 iterations x 4 ops)\n")
 put("msm26_accumulate_sq_pmc.txt", "msm26_accumulate_sq_pmc.txt", "# rocprofv3 --pmc SQ_* (one pass, 8 counters) on msm_accumulate_kernel<Fq>, 2^26 points, MI355X\n")
