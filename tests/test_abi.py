@@ -103,3 +103,30 @@ def test_window_geometry_is_sane():
         # c = bits of the bucket field: nb <= 2^c - 1 slots per window, digits in base B = 2 nb (a power of two or 3 / 5 times
         # one), so 2^(c-1) <= B <= 2^(c+1): the windows must cover 254 bits without a spare one
         assert 2 <= c <= 24 and nw.value * (c + 1) >= 254 and (nw.value - 1) * (c - 1) < 254 + c
+
+
+def test_table_geometry_is_sane_and_table_entries_reject_bad_arguments():
+    """mi355zk_msm_table_geometry is host arithmetic: power-of-two windows that cover the 254 bits of an exponent, a table index
+    (n_windows * n_bases) that fits the 31 bits of an index-list entry up to 2^27 points; the table entry points refuse null
+    pointers and unknown flags before they touch a device."""
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    for group in (1, 2):
+        prev_w = 64
+        for lg in (0, 4, 10, 16, 18, 19, 20, 22, 23, 24, 26, 27):
+            c, w = C.c_uint32(), C.c_uint32()
+            assert lib.mi355zk_msm_table_geometry(1 << lg, group, C.byref(c), C.byref(w)) == 0
+            assert 4 <= c.value <= 24
+            assert (w.value - 1) * c.value + (c.value - 1) >= 254 > (w.value - 2) * c.value + (c.value - 1)   # the smallest window count that covers 254 bits
+            assert w.value <= prev_w   # longer vectors never take more windows
+            prev_w = w.value
+            assert (w.value << lg) < (1 << 31)
+    assert lib.mi355zk_msm_table_geometry(16, 3, None, None) == zk.lib.ERR_BAD_ARGS
+    out = np.zeros(12, np.uint64)
+    assert lib.mi355zk_bn254_g1_msm_table_dev(None, 4, 0, None, 4, None, 0, 0, None, out.ctypes.data_as(C.c_void_p)) == zk.lib.ERR_BAD_ARGS
+    assert lib.mi355zk_bn254_g1_msm_table_dev(None, 0, 0, None, 0, None, 0, 2, None, out.ctypes.data_as(C.c_void_p)) == zk.lib.ERR_BAD_ARGS   # unknown flag
+    assert lib.mi355zk_bn254_g2_msm_table_build_dev(None, 4, None, 0, None) == zk.lib.ERR_BAD_ARGS
+    assert lib.mi355zk_bases_cache_pin_tables(None, 4, 1) == zk.lib.ERR_BAD_ARGS
+    d, t = C.c_size_t(1), C.c_size_t(1)
+    assert lib.mi355zk_bases_cache_info(out.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 0 and d.value == 0 and t.value == 0
