@@ -1329,7 +1329,8 @@ struct TreeJobs {
 template <class F>
 __global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  using U = typename BucketAcc<F>::type;   // sums travel between the rounds in REGISTER form (U-form limbs): no re-packing per round
+  U* sh = reinterpret_cast<U*>(smem);
   const uint32_t per_w = J.first_block[J.n_jobs];
   const uint32_t w = blockIdx.x / per_w, r = blockIdx.x % per_w;
   uint32_t job = 0;
@@ -1343,21 +1344,22 @@ __global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J) {
   const uint32_t rbase = rp * J.rep_stride[job], limit = J.limit[job];
   const XYZZ<F>* P = J.in[job] + (uint64_t)w * J.stride[job] + rbase;
   const uint32_t x0 = slice * MSM_TREE_SLICE + threadIdx.x, x1 = x0 + 256;
-  XYZZ<F> acc = XYZZ<F>::zero(), other = XYZZ<F>::zero();
-  if (x0 < count && (uint64_t)rbase + (uint64_t)x0 * es < limit && (bit < 0 || (((x0 + off) >> bit) & 1))) acc = load_vec(P + (uint64_t)x0 * es);
-  if (x1 < count && (uint64_t)rbase + (uint64_t)x1 * es < limit && (bit < 0 || (((x1 + off) >> bit) & 1))) other = load_vec(P + (uint64_t)x1 * es);
+  XYZZ<F> r0 = XYZZ<F>::zero(), r1 = XYZZ<F>::zero();
+  if (x0 < count && (uint64_t)rbase + (uint64_t)x0 * es < limit && (bit < 0 || (((x0 + off) >> bit) & 1))) r0 = load_vec(P + (uint64_t)x0 * es);
+  if (x1 < count && (uint64_t)rbase + (uint64_t)x1 * es < limit && (bit < 0 || (((x1 + off) >> bit) & 1))) r1 = load_vec(P + (uint64_t)x1 * es);
+  U acc = xyzzr_load(r0), other = xyzzr_load(r1);   // (the zero record loads as the zero accumulator: ZZ == 0 limbs)
   // ONE inlined xyzz_add for the pair and for every tree level (code size).  Lanes [s, 2s) publish, lanes [0, s)
   // consume; the regions written in consecutive rounds are disjoint from the ones still being read, so one
   // barrier per round.
   for (uint32_t s = 256;;) {
-    rec_add(acc, other);
+    xyzzr_add(acc, other);   // (its results keep the invariants its operands need: the running-sum levels chain it the same way)
     s >>= 1;
     if (s == 0) break;
     if (threadIdx.x >= s && threadIdx.x < 2 * s) sh[threadIdx.x] = acc;
     __syncthreads();
-    other = threadIdx.x < s ? sh[threadIdx.x + s] : XYZZ<F>::zero();
+    other = threadIdx.x < s ? sh[threadIdx.x + s] : U::zero();
   }
-  if (threadIdx.x == 0) store_vec(J.out[job] + ((uint64_t)w * J.out_w[job] + rp) * slices + slice, acc);
+  if (threadIdx.x == 0) store_vec(J.out[job] + ((uint64_t)w * J.out_w[job] + rp) * slices + slice, xyzzr_store(acc));
 }
 
 // Table mode, error path only: the accumulation reports the lowest TABLE index that held the identity, which orders by window
@@ -2116,7 +2118,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
         J.reps[n_jobs] = t_cols; J.rep_stride[n_jobs] = 1; J.elem_stride[n_jobs] = t_cols; J.limit[n_jobs] = final_cnt;
         ++n_jobs;
       }
-      const size_t lds = 256 * sizeof(XYZZ<F>);
+      const size_t lds = 256 * sizeof(typename BucketAcc<F>::type);
       XYZZ<F>* dst = sumtmp;
       for (uint32_t launch = 0;; ++launch) {
         const bool families = tail2d && launch == 0;  // (this launch leaves R and C behind: another one must follow)
