@@ -1174,7 +1174,8 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
                                                                   uint32_t hb, uint32_t seg, XYZZ<F>* __restrict__ seg_sums, int skip_zero,
                                                                   unsigned long long* __restrict__ err_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  using U = typename BucketAcc<F>::type;   // the tree runs on register-form sums (R domain): no re-packing per round
+  U* sh = reinterpret_cast<U*>(smem);
   hb = item_off[hb + 1];  // the leading entries that can be heavy (msm_heavy_plan_kernel)
   const uint32_t total = item_off[hb];
   // a fixed-size grid strides over the segments: dispatching one (mostly empty) workgroup per POSSIBLE segment
@@ -1190,21 +1191,16 @@ __global__ void __launch_bounds__(MSM_HEAVY_LANES) msm_accumulate_heavy_kernel(c
     const uint32_t b = order[lo];
     const uint32_t j0 = first[b] + (item - item_off[lo]) * seg;
     const uint32_t e = j0 + seg < last[b] ? j0 + seg : last[b];
-    if (j0 + threadIdx.x < e) {
-      sh[threadIdx.x] = xyzzu_to_r(accumulate_run<F>(BucketAcc<F>::type::zero(), bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0, err_base));  // an R-domain record (curveu.hpp): what every consumer of bucket sums below works on
-    } else {
-      sh[threadIdx.x] = XYZZ<F>::zero();
-    }
-    __syncthreads();
+    U a = U::zero();
+    if (j0 + threadIdx.x < e)   // an R-domain record (curveu.hpp) is what every consumer of bucket sums works on: its register form here
+      a = xyzzr_load(xyzzu_to_r(accumulate_run<F>(U::zero(), bases, vals, j0 + threadIdx.x, e, blockDim.x, skip_zero != 0, err_base)));
+    // lanes [s, 2s) publish, lanes [0, s) consume: the regions of consecutive rounds are disjoint, one barrier per round
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        XYZZ<F> a = sh[threadIdx.x];
-        rec_add(a, sh[threadIdx.x + s]);
-        sh[threadIdx.x] = a;
-      }
+      if (threadIdx.x >= s && threadIdx.x < 2 * s) sh[threadIdx.x] = a;
       __syncthreads();
+      if (threadIdx.x < s) xyzzr_add(a, sh[threadIdx.x + s]);
     }
-    if (threadIdx.x == 0) store_vec(seg_sums + item, sh[0]);
+    if (threadIdx.x == 0) store_vec(seg_sums + item, xyzzr_store(a));
     __syncthreads();
   }
 }
@@ -1215,27 +1211,22 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const XYZZ<F>* __
                                                               const uint32_t* __restrict__ item_off, uint32_t hb, XYZZ<F>* __restrict__ buckets,
                                                               int carry) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  using U = typename BucketAcc<F>::type;
+  U* sh = reinterpret_cast<U*>(smem);
   hb = item_off[hb + 1];  // the leading entries that can be heavy (msm_heavy_plan_kernel)
   for (uint32_t i = blockIdx.x; i < hb; i += gridDim.x) {
     const uint32_t lo = item_off[i], hi = item_off[i + 1];
     if (hi == lo) continue;  // not heavy (uniform per workgroup)
-    XYZZ<F> acc = XYZZ<F>::zero();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) rec_add(acc, load_vec(seg_sums + k));
-    sh[threadIdx.x] = acc;
-    __syncthreads();
+    U a = U::zero();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) xyzzr_add(a, xyzzr_load(load_vec(seg_sums + k)));
     for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        XYZZ<F> a = sh[threadIdx.x];
-        rec_add(a, sh[threadIdx.x + s]);
-        sh[threadIdx.x] = a;
-      }
+      if (threadIdx.x >= s && threadIdx.x < 2 * s) sh[threadIdx.x] = a;
       __syncthreads();
+      if (threadIdx.x < s) xyzzr_add(a, sh[threadIdx.x + s]);
     }
     if (threadIdx.x == 0) {
-      XYZZ<F> sum = sh[0];
-      if (carry) rec_add(sum, load_vec(buckets + order[i]));  // the bucket's sum over the earlier chunks
-      store_vec(buckets + order[i], sum);
+      if (carry) xyzzr_add(a, xyzzr_load(load_vec(buckets + order[i])));  // the bucket's sum over the earlier chunks
+      store_vec(buckets + order[i], xyzzr_store(a));
     }
     __syncthreads();
   }
@@ -2042,10 +2033,10 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     // (grid-stride over the segments that exist; a short call must not pay for thousands of empty workgroups)
     uint32_t heavy_grid = (uint32_t)((C.m >> 12) < 1024 ? 1024 : (C.m >> 12) > 16384 ? 16384 : (C.m >> 12));
     if (heavy_grid > C.max_items) heavy_grid = C.max_items;
-    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st,
+    hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(typename BucketAcc<F>::type), st,
                        bases_set, vals_b, first, last, order, item_off, C.hb, C.heavy_seg, seg_sums, dense ? 1 : 0, d_err);
     ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(C.hb < 2048 ? C.hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off,
+    hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(C.hb < 2048 ? C.hb : 2048), dim3(64), 64 * sizeof(typename BucketAcc<F>::type), st, seg_sums, order, item_off,
                        C.hb, buckets, carry ? 1 : 0);
     ZK_HIP(hipGetLastError());
     prof_end(slot_heavy, st);
@@ -2383,9 +2374,9 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   ZK_HIP(hipGetLastError());
   hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1024), 0, st, sizes_b, hb, heavy, MSM_HEAVY_SEG, item_off);
   const uint32_t heavy_grid = max_items < 16384 ? max_items : 16384;
-  hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(XYZZ<F>), st, d_points,
+  hipLaunchKernelGGL(msm_accumulate_heavy_kernel<F>, dim3(heavy_grid), dim3(MSM_HEAVY_LANES), MSM_HEAVY_LANES * sizeof(typename BucketAcc<F>::type), st, d_points,
                      vals, first, last, order, item_off, hb, MSM_HEAVY_SEG, seg_sums, 1, (unsigned long long*)nullptr);
-  hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(XYZZ<F>), st, seg_sums, order, item_off, hb,
+  hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(hb < 2048 ? hb : 2048), dim3(64), 64 * sizeof(typename BucketAcc<F>::type), st, seg_sums, order, item_off, hb,
                      buckets, 0);
   hipLaunchKernelGGL((msm_accumulate_kernel<F, false, false>), dim3((n_rows + 255) / 256), dim3(256), 0, st, d_points, vals, first, last, order, heavy, hb,
                      n_rows, buckets, 1, (unsigned long long*)nullptr);
