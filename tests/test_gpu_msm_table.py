@@ -243,3 +243,46 @@ def test_host_entry_runs_pinned_vectors_in_table_mode(zk, worker, group):
     finally:
         zk.unpin_bases(bases)
     assert info()[0] == 0
+
+
+def _to_int(a):
+    return [int(x[0]) | int(x[1]) << 64 | int(x[2]) << 128 | int(x[3]) << 192 for x in a]
+
+
+@pytest.mark.parametrize("group,log_n", [(1, 23), (2, 20)])
+def test_table_mode_closed_form_and_additivity_at_size(zk, worker, group, log_n):
+    """Size-independent properties at the sizes table mode is for (the c = 22 layout of 2^23 G1 points; 2^20 G2 points): bases
+    k_i * G, so the multiexp has the closed form (sum s_i k_i) * G; additivity over point ranges through the source offset (the
+    second range reads the SAME table at an offset); a density map selecting half of the exponents against the plain call."""
+    import torch
+
+    import bench
+    import bn254_model as M
+
+    dev = torch.device("cuda", 0)
+    n = 1 << log_n
+    G = O.G1 if group == 1 else O.G2
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW)
+    lib = zk.lib.load()
+    s = bench.gen_scalars(n, 4101, dev)
+    k = bench.gen_scalars(n, 4102, dev)
+    b = torch.empty((n, 8 * group), dtype=torch.int64, device=dev)
+    fn = lib.mi355zk_bn254_g1_batch_mul_dev if group == 1 else lib.mi355zk_bn254_g2_batch_mul_dev
+    assert fn(C.c_void_p(b.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+    t = zk.MsmTable(b)
+    total = zk.multiexp(worker, (t, 0), zk.FullDensity(), s).wait()
+    hs, hk = s.cpu().numpy().view(np.uint64), k.cpu().numpy().view(np.uint64)
+    dot = sum(x * y for x, y in zip(_to_int(hs), _to_int(hk))) % M.R_ORDER
+    want = G.mul(G.from_affine(gen), M.to_limbs(dot))
+    assert np.array_equal(G.to_affine(total), G.to_affine(want))
+    h = n // 2 + 4321
+    lo = zk.multiexp(worker, (t, 0), zk.FullDensity(), s[:h].contiguous()).wait()
+    hi = zk.multiexp(worker, (t, h), zk.FullDensity(), s[h:].contiguous()).wait()
+    assert np.array_equal(G.to_affine(zk.shard.join_partials(np.stack([lo, hi]))), G.to_affine(total))
+    rng = np.random.default_rng(4103)
+    m = 1 << 18
+    bits = rng.random(m) < 0.5
+    dm = zk.DensityTracker.from_bools(bits)
+    got = zk.multiexp(worker, (t, 7), dm, s[:m].contiguous()).wait()
+    ref = zk.multiexp(worker, (b, 7), dm, s[:m].contiguous()).wait()
+    assert np.array_equal(G.to_affine(got), G.to_affine(ref))
