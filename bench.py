@@ -272,12 +272,28 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus N>1 must be launched through torch.distributed.run", file=sys.stderr)
-            return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: launch the N ranks ourselves, exactly the way the driver's torchrun form does (one
+        # process per GPU, RCCL), on a free port; the ranks' output is ours (rank 0 prints the one JSON line)
+        import socket
+        import subprocess
+
+        ndev = torch.cuda.device_count()
+        if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" and ndev < args.gpus:
+            print("bench.py: --gpus %d but %d GPU(s) visible (BENCH_BACKEND=gloo lets ranks share devices: control flow only, not a "
+                  "scaling number)" % (args.gpus, ndev), file=sys.stderr)
+            return 2
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd)
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         return 2
     # one process per GPU.  BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer
     # GPUs than ranks (ranks then share devices); the driver's multi-GPU run uses nccl (= RCCL over xGMI).
@@ -503,6 +519,8 @@ def main() -> int:
             "value": round(value, 3),
             "unit": "Mscalar-mul/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,   # the world size torch.distributed sees
+            "backend": backend if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),

@@ -62,10 +62,27 @@ extern "C" {
 #define MI355ZK_OP_COSET_FFT 2
 #define MI355ZK_OP_ICOSET_FFT 3
 
-/* ---- lifecycle.  device_ids == NULL / n_devices == 0: use the process's current HIP device.
- * One process drives one GPU (one rank per GPU under torch.distributed / RCCL); device_ids[0] is
- * selected with hipSetDevice.  Replaces nothing in the reference (it has no device). */
+/* ---- lifecycle.  device_ids == NULL / n_devices == 0: use the process's current HIP device.  The LAST call defines the
+ * library's device set.
+ *   n_devices == 1: one GPU (device_ids[0] is selected with hipSetDevice) -- one rank per GPU under torch.distributed / RCCL
+ *                   (shard.py), or a single-GPU process.
+ *   n_devices  > 1: SINGLE-PROCESS MULTI-GPU MODE, for the consumer this library is a drop-in for: one Rust process
+ *                   (phase2/src/bin/prove.rs -> bellman/src/groth16/prover.rs:250-298 -> multiexp.rs:330-355) driving the 8 GPUs of a
+ *                   node.  mi355zk_bn254_g{1,2}_msm (host buffers) with >= 2^20 exponents (env MI355ZK_MULTI_MIN_LOG) is then cut
+ *                   into one cell per device -- contiguous point ranges, each evaluated by the single-GPU pipeline on its
+ *                   own device from its own host thread, its exponents streamed over that device's PCIe link, its copy of a PINNED
+ *                   base vector kept resident there -- and the n_devices Jacobian partials are joined on the host ("D2H of 8
+ *                   records": no collective inside one process).  Result, return code and mi355zk_last_error_index are those of
+ *                   the single-device call (the error at the lowest exponent index wins).  Shorter calls run whole, on the devices
+ *                   of the set in turn, so a prover's eight concurrent multiexps spread over the node.  The calling thread's
+ *                   current device is device_ids[0] on return and is left alone by the multiexps.  Device-pointer (`_dev`) entry
+ *                   points are unaffected: their buffers live on one device, the caller's current one.  An id may be repeated
+ *                   (logical devices sharing a GPU): that is how the mode is tested on a one-GPU box.
+ * Returns 3 for an id that is not a visible device, < 0 if a device is not gfx950.  Replaces nothing in the reference (it has no
+ * device). */
 int mi355zk_init(const int *device_ids, int n_devices);
+/* number of (logical) devices host-buffer multiexps are spread over: 1 unless mi355zk_init was given more */
+int mi355zk_device_count(void);
 void mi355zk_shutdown(void);
 const char *mi355zk_version(void);
 
@@ -153,7 +170,8 @@ int mi355zk_bn254_g2_msm_ex_dev(const void *d_bases, size_t n_bases, size_t base
  *                     n_windows * n_bases affine records (64 B / 128 B each).
  *   table_build_dev:  fills d_table (table_bytes >= n_windows * n_bases * record) from d_bases; d_table may start with the
  *                     bases themselves (d_table == d_bases: window 0 is the vector).  Synchronises `stream`.  One-time work.
- *                     G2: the multiplications by 2^k run through the psi split -- the subgroup precondition of batch_exp_dev.
+ *                     Window w + 1 is window w doubled width[w] times (plain doublings, one batched normalisation): exact for
+ *                     every point the decoders admit, in the order-r subgroup or not.
  *   msm_table_dev:    the multiexp; `n_bases` is the length of the ORIGINAL vector (the table's window stride). */
 int mi355zk_msm_table_geometry(size_t n_bases, int group, uint32_t *window_bits, uint32_t *n_windows);
 int mi355zk_bn254_g1_msm_table_build_dev(const void *d_bases, size_t n_bases, void *d_table, size_t table_bytes, void *stream);

@@ -41,13 +41,21 @@ class DeviceError(RuntimeError):
 
 
 class Worker:
-    """bellman/src/multicore.rs:17-35.  The reference's Worker is a CPU thread pool; here it names
-    the GPU the calling process drives (one process per GPU) and the stream work is issued on."""
+    """bellman/src/multicore.rs:17-35.  The reference's Worker is a CPU thread pool; here it names the GPU(s) the calling process
+    drives.  Worker(3): one GPU (one process per GPU, shard.py).  Worker(devices=[0, 1, .., 7]): the single-process multi-GPU mode
+    of mi355zk_init -- host-buffer multiexps of >= 2^20 exponents are cut into one point range per device and joined on the host,
+    shorter ones go to the devices in turn (include/mi355zk.h).  The last Worker constructed defines the library's device set."""
 
-    def __init__(self, device: int | None = None):
-        self.device = device
-        ids = (C.c_int * 1)(device) if device is not None else None
-        rc = _lib.load().mi355zk_init(ids, 1 if device is not None else 0)
+    def __init__(self, device: int | None = None, devices=None):
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            assert devices and device is None
+            ids = (C.c_int * len(devices))(*devices)
+            self.device, self.devices, n = devices[0], devices, len(devices)
+        else:
+            ids = (C.c_int * 1)(device) if device is not None else None
+            self.device, self.devices, n = device, [device] if device is not None else [], 1 if device is not None else 0
+        rc = _lib.load().mi355zk_init(ids, n)
         if rc != 0:
             raise DeviceError(f"mi355zk_init failed (rc={rc})")
 

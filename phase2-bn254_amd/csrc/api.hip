@@ -3,6 +3,7 @@
 // bellman/src/domain.rs:52-99, and the kernel-timing hooks used by bench.py.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -699,8 +700,43 @@ int batch_mul(void* d_out, const uint64_t* base_raw, const void* d_scalars, size
 
 // Window table of a base vector for table-mode multiexps (msm_impl.hpp: msm_device with table_stride != 0):
 //   table[w * n + i] = 2^(width[0] + .. + width[w-1]) * bases[i],  w < W,  affine records (the identity stays the identity).
-// Window w + 1 is window w multiplied by 2^width[w] -- the shared-scalar batch_exp (one inversion per 16 / 8 points); one-time work
-// per pinned parameter vector, W - 1 passes of n scalar multiplications.
+// Window w + 1 is window w doubled width[w] times: PLAIN doublings on the U-form Jacobian accumulator (X, Y parked in the output
+// plane, Z in scratch), then one batched normalisation (one inversion per 16 / 8 points).  Exact for EVERY point the decoders admit:
+// a doubling is the group law itself, whereas the shared-scalar batch_exp this used to call splits 2^k over psi, which is a
+// multiplication by mu on the order-r subgroup of the twist only -- a G2 record with a cofactor component (nothing in the reference
+// or here tests membership) got a table that disagreed with the plain bucket call and the reference.  It is also cheaper: width[w]
+// ~ 20 doublings against the ~128 doublings + additions of a split multiplication.  One-time work per pinned parameter vector.
+template <class F>
+__global__ void __launch_bounds__(256) table_double_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ in, uint64_t n, uint32_t doublings,
+                                                          F* __restrict__ zbuf) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine<F> p = in[i];
+  if constexpr (std::is_same<F, Fq>::value) {
+    JacU<FqParams> acc = JacU<FqParams>::zero();
+    if (!p.is_zero()) {
+      const FqU C = UPow2<FqParams, 266>::get();            // x*2^256 * 2^266 / 2^261 = x * 2^261
+      acc = JacU<FqParams>{u_mul(u_from_std(p.x), C), u_mul(u_from_std(p.y), C), UPow2<FqParams, 261>::get()};
+#pragma unroll 1
+      for (uint32_t k = 0; k < doublings; ++k) acc = jacu_double(acc);   // (a point of order 2 does not exist on y^2 = x^3 + b over Fq: r is odd)
+    }
+    const Jacobian<F> r = jacu_to_std(acc);
+    out[i] = Affine<F>{r.x, r.y};
+    zbuf[i] = r.z;
+  } else {
+    JacU2 acc = JacU2::zero();
+    if (!p.is_zero()) {
+      const JacTabU2 e = jacu2_tab_from_affine(p.x, p.y);
+      acc = JacU2{e.x, e.y, e.z};
+#pragma unroll 1
+      for (uint32_t k = 0; k < doublings; ++k) acc = jacu2_double(acc);  // (no 2-torsion on the twist either: #E'(Fq2) = r (2q - r) is odd)
+    }
+    const Jacobian<F> r = jacu2_to_std(acc);
+    out[i] = Affine<F>{r.x, r.y};
+    zbuf[i] = r.z;
+  }
+}
+
 template <int GROUP>
 int msm_table_build(const void* d_bases, size_t n, void* d_table, size_t table_bytes, void* stream) {
   using F = typename std::conditional<GROUP == 1, Fq, Fq2>::type;
@@ -714,18 +750,19 @@ int msm_table_build(const void* d_bases, size_t n, void* d_table, size_t table_b
   char* t = (char*)d_table;
   const size_t plane = n * sizeof(Affine<F>);
   if ((const void*)t != d_bases) ZK_HIP(hipMemcpyAsync(t, d_bases, plane, hipMemcpyDeviceToDevice, st));
-  // the W - 1 multipliers 2^width[w], as canonical FrRepr, in ONE device buffer (freed after the closing synchronisation)
-  std::vector<uint64_t> ks((size_t)W * 4, 0);
-  for (uint32_t w = 0; w + 1 < W; ++w) ks[(size_t)w * 4 + (width[w] >> 6)] = 1ull << (width[w] & 63);
-  void* d_ks = nullptr;
-  ZK_HIP(hipMalloc(&d_ks, ks.size() * 8));
-  int rc = ZK_OK;
-  if (hipMemcpyAsync(d_ks, ks.data(), ks.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = ZK_ERR_DEVICE;
-  for (uint32_t w = 0; rc == ZK_OK && w + 1 < W; ++w)
-    rc = batch_exp<F>(t + (size_t)(w + 1) * plane, t + (size_t)w * plane, 0, (const char*)d_ks + (size_t)w * 32, 1, n, stream);
-  if (hipStreamSynchronize(st) != hipSuccess && rc == ZK_OK) rc = ZK_ERR_DEVICE;
-  (void)hipFree(d_ks);
-  return rc;
+  std::lock_guard<std::mutex> launch_lk(g_exp_launch_mu);  // (the Z scratch is per (device, stream): see batch_exp)
+  void* zbuf = nullptr;
+  int rc = exp_scratch((n * sizeof(F) + 255) & ~(size_t)255, stream, &zbuf);
+  if (rc) return rc;
+  for (uint32_t w = 0; w + 1 < W; ++w) {
+    hipLaunchKernelGGL(table_double_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)(t + (size_t)(w + 1) * plane),
+                       (const Affine<F>*)(t + (size_t)w * plane), (uint64_t)n, (uint32_t)width[w], (F*)zbuf);
+    ZK_HIP(hipGetLastError());
+    rc = GROUP == 1 ? batch_normalize_g1(t + (size_t)(w + 1) * plane, zbuf, n, st) : batch_normalize_g2(t + (size_t)(w + 1) * plane, zbuf, n, st);
+    if (rc) return rc;
+  }
+  ZK_HIP(hipStreamSynchronize(st));
+  return ZK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -967,6 +1004,7 @@ struct BasesEntry {
   bool want_table = false, table_failed = false;
   void* table = nullptr;
   size_t table_bytes = 0;
+  size_t table_reserved = 0;  // bytes set aside under g_bc_mu while the table is being built (concurrent builds cannot overbook the cache)
   std::mutex table_mu;
 };
 std::mutex g_bc_mu;
@@ -1048,17 +1086,20 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
   e->host = host; e->n = n; e->group = group; e->dev = dev; e->fp = fp; e->bytes = bytes; e->want_table = want_table;
   {
     std::lock_guard<std::mutex> lk(g_bc_mu);
+    // the capacity is PER DEVICE (a process may drive several: mi355zk_init with n_devices > 1 keeps a copy of a pinned vector on
+    // every device that evaluates cells over it)
     size_t used = 0;
-    for (auto& x : g_bc) used += x->bytes + x->table_bytes;
+    for (auto& x : g_bc)
+      if (x->dev == dev) used += x->bytes + x->table_bytes + x->table_reserved;
     while (used + bytes > cap && !g_bc.empty()) {           // evict least recently used entries nobody is filling
       size_t victim = g_bc.size();
       for (size_t i = 0; i < g_bc.size(); ++i)
-        if (g_bc[i]->ready && g_bc[i].use_count() == 1 && (victim == g_bc.size() || g_bc[i]->tick < g_bc[victim]->tick)) victim = i;
+        if (g_bc[i]->dev == dev && g_bc[i]->ready && g_bc[i].use_count() == 1 && g_bc[i]->table_reserved == 0 &&
+            (victim == g_bc.size() || g_bc[i]->tick < g_bc[victim]->tick))
+          victim = i;
       if (victim == g_bc.size()) break;
-      (void)hipSetDevice(g_bc[victim]->dev);  // the victim may live on another GPU of this process
       (void)hipFree(g_bc[victim]->d);
       (void)hipFree(g_bc[victim]->table);
-      (void)hipSetDevice(dev);
       used -= g_bc[victim]->bytes + g_bc[victim]->table_bytes;
       g_bc.erase(g_bc.begin() + (long)victim);
     }
@@ -1195,30 +1236,37 @@ const void* bases_table(const std::shared_ptr<BasesEntry>& e, hipStream_t st) {
   uint32_t c = 0, W = 0;
   msm_table_geometry(e->n, GROUP, &c, &W, nullptr);
   const size_t bytes = (size_t)W * e->bytes;
-  e->table_failed = true;  // (until it has worked)
-  if ((uint64_t)W * e->n > 0x7fffffffull) return nullptr;
+  if ((uint64_t)W * e->n > 0x7fffffffull) { e->table_failed = true; return nullptr; }
   {
+    // reserve the room before the build: the prover's eight threads build the tables of different vectors at the same time.  A
+    // cache that is full NOW is not a failure of this vector -- the next call asks again, after evictions may have made room.
     std::lock_guard<std::mutex> g(g_bc_mu);
     size_t used = 0;
-    for (auto& x : g_bc) used += x->bytes + x->table_bytes;
+    for (auto& x : g_bc)
+      if (x->dev == e->dev) used += x->bytes + x->table_bytes + x->table_reserved;
     if (used + bytes > bases_cache_cap()) return nullptr;
+    e->table_reserved = bytes;
   }
   void* t = nullptr;
-  if (hipMalloc(&t, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (msm_table_build<GROUP>(e->d, e->n, t, bytes, (void*)st) != ZK_OK) { (void)hipFree(t); return nullptr; }
+  bool ok = hipMalloc(&t, bytes) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  if (ok && msm_table_build<GROUP>(e->d, e->n, t, bytes, (void*)st) != ZK_OK) { (void)hipFree(t); ok = false; }
   std::lock_guard<std::mutex> g(g_bc_mu);
+  e->table_reserved = 0;
+  if (!ok) { e->table_failed = true; return nullptr; }  // allocation or build failed: not tried again for this entry
   e->table = t;
   e->table_bytes = bytes;
-  e->table_failed = false;
   return t;
 }
 
 constexpr uint64_t HOST_CHUNK_UPLOAD = 1ull << 23;  // exponents per chunk of a streamed call whose bases travel too (link-bound)
 constexpr uint64_t HOST_CHUNK_MIN = 1ull << 21;     // smallest first chunk of a call whose bases are on the device; below 4 of these the call is not cut
 
+// One host-buffer multiexp on the calling thread's CURRENT device.  (wgroups, wgroup): only that group of scalar windows (a cell of
+// the single-process multi-GPU mode below; (1, 0) is the whole multiexp).
 template <int GROUP>
-int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
-                   const uint32_t* density, size_t density_bits, uint64_t* out_xyz) {
+int msm_host_run(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
+                 const uint32_t* density, size_t density_bits, uint64_t* out_xyz, uint32_t wgroups = 1, uint32_t wgroup = 0) {
   t_last_err_index = -1;
   if (!out_xyz || (n_scalars && !scalars) || (n_bases && !bases)) return ZK_ERR_BAD_ARGS;
   if (n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
@@ -1408,16 +1456,26 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   };
 
   uint64_t result_xyz[jac_words];
-  std::memset(result_xyz, 0, sizeof result_xyz);
+  {
+    // a call that evaluates no exponent returns the reference's Projective::zero() = (0, 1, 0) (ec.rs:229-235), as msm_device does
+    using J = typename std::conditional<GROUP == 1, G1Jacobian, G2Jacobian>::type;
+    static_assert(sizeof(J) == sizeof result_xyz, "Jacobian layout");
+    const J zero = J::zero();
+    std::memcpy(result_xyz, &zero, sizeof result_xyz);
+  }
   int result = ZK_OK;
   long long err_idx = -1;
   bool aborted = false;
   if (n_chunks > 0) {
     std::thread copier(copy_fn);
     // a vector pinned WITH TABLES, already on the device, in a call that is not cut: table mode
-    const void* d_table = (n_chunks == 1 && entry && !fill) ? bases_table<GROUP>(entry, S->compute) : nullptr;
+    // (not for a handful of exponents over a long vector -- the prover's input multiexps over its 2^20-point a / b queries: the
+    // table's window width comes from the VECTOR's length, and zeroing + reducing 2^19 buckets for a few points costs more than the
+    // plain call, which picks its window from n)
+    const bool table_pays = n * 8 >= n_bases;
+    const void* d_table = (n_chunks == 1 && entry && !fill && wgroups == 1 && table_pays) ? bases_table<GROUP>(entry, S->compute) : nullptr;
     result = msm_dev_entry<GROUP>(d_table ? d_table : d_bases, n_bases, base_offset, nullptr, n_scalars, density, density_bits, (void*)S->compute, result_xyz,
-                                  1, 0, 0, &feed, d_table != nullptr);
+                                  wgroups, wgroup, 0, &feed, d_table != nullptr);
     err_idx = t_last_err_index;
     if (trace) std::fprintf(stderr, "[mi355zk] host entry: result at %.2f ms (%llu chunks)\n", ms_now(), (unsigned long long)n_chunks);
     {
@@ -1444,6 +1502,159 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   if (result != ZK_OK && result != ZK_ERR_UNEXPECTED_EOF) return result;
   std::memcpy(out_xyz, result_xyz, sizeof result_xyz);
   return result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SINGLE-PROCESS MULTI-GPU MODE.  The consumer this library is a drop-in for is ONE Rust process (phase2/src/bin/prove.rs ->
+// bellman/src/groth16/prover.rs:250-298 -> multiexp.rs:330-355), so the 8 GPUs of a node must be reachable through the C ABI, not
+// only through one rank per GPU (shard.py).  mi355zk_init(ids, n > 1) records a DEVICE SET; a host-buffer multiexp of at least
+// 2^MI355ZK_MULTI_MIN_LOG exponents (default 20) is then cut into cells -- contiguous POINT RANGES (cut at multiples of 32
+// exponents so that density words are not shared), optionally x groups of scalar windows -- and every cell is one msm_host_run on
+// its own device from its own host thread: its exponents cross ITS PCIe link while its kernels run (the streamed upload above), its
+// base vector is cached on that device when the caller pinned it.  The N Jacobian partials (96 / 192 B) come back to the host --
+// SURVEY 8e's "or D2H of 8 records": inside one process there is nothing for RCCL to do -- and are joined there with the rule
+// shard.exchange defines: a failing cell's error carries its GLOBAL exponent index, the lowest index wins, Eof (planned for the whole
+// call) before identity at one index.  Smaller calls run whole, on the devices of the set in turn (the prover's eight concurrent
+// multiexps spread over the node).
+// Why point ranges and not shard.py's window groups: a rank of shard.py holds its exponents in HBM; here every cell uploads its own,
+// and a window-group cell would upload ALL exponents of its range over its link (2^26 on 8 devices: 1 GiB per device against 256 MiB).
+// MI355ZK_MULTI_PLAN="PxW" forces P point ranges x W window groups (P * W <= devices) for experiments and for the tests.
+std::mutex g_devset_mu;
+std::vector<int> g_devset;                 // HIP device ids of the set (a test may repeat one id: logical devices sharing a GPU)
+std::atomic<unsigned> g_devset_turn{0};
+
+std::vector<int> devset_snapshot() {
+  std::lock_guard<std::mutex> lk(g_devset_mu);
+  return g_devset;
+}
+
+struct DeviceGuard {  // the calling thread's current device is its own business: restore it
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// bases consumed by exponents [0, i) of a planned call (prefix popcount of the density map; i itself under FullDensity)
+uint64_t density_rank(const DensityPlan& P, const uint32_t* density, uint64_t i) {
+  if (density == nullptr || i == 0) return density == nullptr ? i : 0;
+  const uint64_t w = i >> 5;
+  if (w >= P.prefix.size()) {  // i == n on a word boundary past the last planned word
+    const uint64_t lw = P.prefix.size() - 1;
+    uint32_t v = density[lw];
+    if ((lw + 1) * 32 > P.n) v &= (P.n & 31) ? ((1u << (P.n & 31)) - 1u) : 0xffffffffu;
+    return P.prefix[lw] + (uint32_t)__builtin_popcount(v);
+  }
+  uint64_t r = P.prefix[w];
+  if (i & 31) r += (uint32_t)__builtin_popcount(density[w] & ((1u << (i & 31)) - 1u));
+  return r;
+}
+
+template <int GROUP>
+int msm_host_multi(const std::vector<int>& devs, const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars,
+                   size_t n_scalars, const uint32_t* density, size_t density_bits, uint64_t* out_xyz) {
+  using J = typename std::conditional<GROUP == 1, G1Jacobian, G2Jacobian>::type;
+  t_last_err_index = -1;
+  DensityPlan P;
+  int rc = plan_density(n_bases, base_offset, n_scalars, density, density_bits, &P);
+  if (rc) return rc;
+  const uint64_t n = P.eof_index >= 0 ? (uint64_t)P.eof_index : P.n;  // exponents before the first Eof
+  // ---- the plan: point ranges x window groups
+  uint32_t pg = (uint32_t)devs.size(), wg = 1;
+  if (const char* env = std::getenv("MI355ZK_MULTI_PLAN")) {
+    unsigned a = 0, b = 0;
+    if (std::sscanf(env, "%ux%u", &a, &b) == 2 && a >= 1 && b >= 1 && (size_t)a * b <= devs.size()) { pg = a; wg = b; }
+  }
+  if (wg > 1) {  // the window count of the range's geometry must divide (choose_geom takes care of that; W == 0: no such layout)
+    uint32_t c = 0, W = 0;
+    msm_geometry((n + pg - 1) / pg, wg, &c, &W);
+    if (W == 0 || W % wg) wg = 1;
+  }
+  while (pg > 1 && n / pg < 32) --pg;
+  std::vector<uint64_t> cut(pg + 1, 0);
+  for (uint32_t r = 1; r < pg; ++r) cut[r] = ((n * r / pg) + 31) & ~31ull;
+  cut[pg] = n;
+  struct Cell {
+    int dev = 0;
+    uint64_t lo = 0, hi = 0;
+    uint32_t wgi = 0;
+    int rc = ZK_OK;
+    long long err = -1;
+    J part;
+  };
+  std::vector<Cell> cells;
+  for (uint32_t r = 0; r < pg; ++r)
+    for (uint32_t g = 0; g < wg; ++g) {
+      if (cut[r + 1] <= cut[r]) continue;
+      Cell c;
+      c.dev = devs[cells.size() % devs.size()];
+      c.lo = cut[r];
+      c.hi = cut[r + 1];
+      c.wgi = g;
+      c.part = J::zero();
+      cells.push_back(c);
+    }
+  static const bool trace = std::getenv("MI355ZK_TRACE_HOST") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto run_cell = [&](Cell& c) {
+    if (hipSetDevice(c.dev) != hipSuccess) { c.rc = ZK_ERR_DEVICE; return; }
+    const uint64_t boff = base_offset + density_rank(P, density, c.lo);
+    c.rc = msm_host_run<GROUP>(bases, n_bases, boff, scalars + c.lo * 4, c.hi - c.lo, density ? density + (c.lo >> 5) : nullptr,
+                               density ? c.hi - c.lo : 0, reinterpret_cast<uint64_t*>(&c.part), wg, c.wgi);
+    c.err = t_last_err_index;
+    if (trace)
+      std::fprintf(stderr, "[mi355zk] multi: cell [%llu, %llu) window group %u/%u on device %d: rc %d at %.2f ms\n", (unsigned long long)c.lo,
+                   (unsigned long long)c.hi, c.wgi, wg, c.dev, c.rc,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
+  {
+    DeviceGuard guard;
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < cells.size(); ++i) th.emplace_back([&, i] { run_cell(cells[i]); });
+    if (!cells.empty()) run_cell(cells[0]);
+    for (auto& t : th) t.join();
+  }
+  // ---- the join.  Device failures first, then a non-canonical exponent (bad arguments: the single-device call reports it before
+  // anything else too), then the Source errors by global exponent index.
+  J total = J::zero();
+  long long bad_idx = -1, ident_idx = -1;
+  for (Cell& c : cells) {
+    if (c.rc < 0) return c.rc;
+    if (c.rc == ZK_ERR_BAD_ARGS) {
+      const long long g = c.err >= 0 ? c.err + (long long)c.lo : -1;
+      if (bad_idx < 0 || (g >= 0 && g < bad_idx)) bad_idx = g >= 0 ? g : bad_idx;
+      if (g < 0) { t_last_err_index = -1; return ZK_ERR_BAD_ARGS; }
+    } else if (c.rc == ZK_ERR_UNEXPECTED_IDENTITY) {
+      const long long g = c.err + (long long)c.lo;
+      if (ident_idx < 0 || g < ident_idx) ident_idx = g;
+    } else if (c.rc != ZK_OK) {
+      return ZK_ERR_DEVICE;  // (a cell never reports Eof: the ranges end before the first exponent without a base)
+    }
+  }
+  if (bad_idx >= 0) { t_last_err_index = bad_idx; return ZK_ERR_BAD_ARGS; }
+  if (ident_idx >= 0) { t_last_err_index = ident_idx; return ZK_ERR_UNEXPECTED_IDENTITY; }  // (every exponent before the Eof has a lower index)
+  for (Cell& c : cells) jac_add(total, c.part);
+  std::memcpy(out_xyz, &total, sizeof total);
+  if (P.eof_index >= 0) { t_last_err_index = P.eof_index; return ZK_ERR_UNEXPECTED_EOF; }
+  return ZK_OK;
+}
+
+// the host-buffer entry points: whole on one device, or cut into cells over the device set
+template <int GROUP>
+int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
+                   const uint32_t* density, size_t density_bits, uint64_t* out_xyz) {
+  const std::vector<int> devs = devset_snapshot();
+  if (devs.size() <= 1) return msm_host_run<GROUP>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  if (!out_xyz || (n_scalars && !scalars) || (n_bases && !bases) || n_bases >= (1ull << 31) || n_scalars >= (1ull << 31)) {
+    t_last_err_index = -1;
+    return ZK_ERR_BAD_ARGS;
+  }
+  const char* env = std::getenv("MI355ZK_MULTI_MIN_LOG");  // (read per call: the tests lower it)
+  const int min_log = env ? std::atoi(env) : 20;
+  if (n_scalars >= (1ull << (min_log < 0 ? 0 : min_log > 30 ? 30 : min_log)) && n_scalars >= 64)
+    return msm_host_multi<GROUP>(devs, bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  DeviceGuard guard;
+  ZK_HIP(hipSetDevice(devs[g_devset_turn.fetch_add(1) % devs.size()]));
+  return msm_host_run<GROUP>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
 }
 
 // best_fft / the domain operations on a HOST array (what a bellman shim calls with `&mut [Scalar<E>]`): upload, transform in place
@@ -1535,16 +1746,50 @@ static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const
 extern "C" {
 
 int mi355zk_init(const int* device_ids, int n_devices) {
-  if (device_ids != nullptr && n_devices > 0) ZK_HIP(hipSetDevice(device_ids[0]));
+  if (n_devices < 0 || (n_devices > 0 && device_ids == nullptr)) return ZK_ERR_BAD_ARGS;
+  int count = 0;
+  ZK_HIP(hipGetDeviceCount(&count));
+  auto check = [](int dev) -> int {
+    hipDeviceProp_t prop;
+    ZK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      std::fprintf(stderr, "[mi355zk] device %d is %s; this library contains gfx950 code only\n", dev, prop.gcnArchName);
+      return ZK_ERR_DEVICE;
+    }
+    return ZK_OK;
+  };
+  for (int i = 0; i < n_devices; ++i)
+    if (device_ids[i] < 0 || device_ids[i] >= count) return ZK_ERR_BAD_ARGS;
+  if (n_devices > 0) ZK_HIP(hipSetDevice(device_ids[0]));
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
-  hipDeviceProp_t prop;
-  ZK_HIP(hipGetDeviceProperties(&prop, dev));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    std::fprintf(stderr, "[mi355zk] device %d is %s; this library contains gfx950 code only\n", dev, prop.gcnArchName);
-    return ZK_ERR_DEVICE;
+  // the LAST call defines the device set: more than one id = the single-process multi-GPU mode of the host-buffer multiexps
+  // (msm_host_multi), one id or none = one device, as before
+  std::vector<int> set;
+  if (n_devices > 1) set.assign(device_ids, device_ids + n_devices);
+  int rc = ZK_OK;
+  if (set.empty()) {
+    rc = check(dev);
+    if (rc == ZK_OK) rc = ntt_configure();
+  } else {
+    for (size_t i = 0; i < set.size() && rc == ZK_OK; ++i) {
+      bool seen = false;
+      for (size_t k = 0; k < i; ++k) seen = seen || set[k] == set[i];
+      if (seen) continue;
+      rc = check(set[i]);
+      if (rc == ZK_OK && hipSetDevice(set[i]) != hipSuccess) rc = ZK_ERR_DEVICE;
+      if (rc == ZK_OK) rc = ntt_configure();
+    }
+    (void)hipSetDevice(dev);
   }
-  return ntt_configure();
+  if (rc != ZK_OK) return rc;
+  std::lock_guard<std::mutex> lk(g_devset_mu);
+  g_devset = set;
+  return ZK_OK;
+}
+int mi355zk_device_count(void) {
+  std::lock_guard<std::mutex> lk(g_devset_mu);
+  return g_devset.empty() ? 1 : (int)g_devset.size();
 }
 
 void mi355zk_shutdown(void) {

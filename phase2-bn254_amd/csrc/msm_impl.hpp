@@ -1380,12 +1380,20 @@ __global__ void __launch_bounds__(256) msm_identity_scan_kernel(const Affine<F>*
 struct Workspace {
   void* p = nullptr;
   size_t bytes = 0;
+  std::mutex mu;                    // serialises the MSM calls that share this device's workspace
 };
-std::mutex g_ws_mu;                 // serialises MSM calls sharing a device workspace
-std::map<int, Workspace> g_ws;      // per device
+// per device: a process may drive several GPUs (mi355zk_init with n_devices > 1 runs one cell of a multiexp per device, each from
+// its own host thread), and calls on different devices must not wait for each other
+std::mutex g_ws_reg_mu;             // guards the map only
+std::map<int, Workspace*> g_ws;
+Workspace& ws_of(int dev) {
+  std::lock_guard<std::mutex> lk(g_ws_reg_mu);
+  Workspace*& w = g_ws[dev];
+  if (w == nullptr) w = new Workspace();
+  return *w;
+}
 
-int ws_reserve(int dev, size_t bytes, void** out) {
-  Workspace& w = g_ws[dev];
+int ws_reserve(Workspace& w, size_t bytes, void** out) {  // under w.mu
   if (w.bytes < bytes) {
     if (w.p) ZK_HIP(hipFree(w.p));
     w.p = nullptr;
@@ -1534,12 +1542,14 @@ void ws_release_all() {
       t->bytes = 0;
     }
   }
-  std::lock_guard<std::mutex> lk(g_ws_mu);
+  std::lock_guard<std::mutex> lk(g_ws_reg_mu);
   for (auto& kv : g_ws) {
+    std::lock_guard<std::mutex> wl(kv.second->mu);
     (void)hipSetDevice(kv.first);
-    (void)hipFree(kv.second.p);
+    (void)hipFree(kv.second->p);
+    kv.second->p = nullptr;
+    kv.second->bytes = 0;
   }
-  g_ws.clear();
 }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -1685,14 +1695,17 @@ uint32_t table_window_bits(uint64_t n_bases, int group) {
 
 // the partition kernels use up to the whole 160 KiB of LDS (dynamic): raise the limit once per device
 std::mutex g_part_cfg_mu;
-std::map<int, int> g_part_cfg;
+std::map<std::pair<int, int>, int> g_part_cfg;
+template <class F>
 int part_configure(int dev) {
   std::lock_guard<std::mutex> lk(g_part_cfg_mu);
-  auto it = g_part_cfg.find(dev);
+  const std::pair<int, int> key(dev, (int)sizeof(F));
+  auto it = g_part_cfg.find(key);
   if (it != g_part_cfg.end()) return it->second;
   int rc = ZK_OK;
+  // (the tree kernel keeps 256 register-form sums in LDS: 72 KiB for G2, above the 64 KiB a kernel gets without asking)
   std::vector<const void*> fns = {reinterpret_cast<const void*>(msm_scatter_kernel), reinterpret_cast<const void*>(msm_bucket_kernel),
-                                  reinterpret_cast<const void*>(msm_bigbin_place_kernel)};
+                                  reinterpret_cast<const void*>(msm_bigbin_place_kernel), reinterpret_cast<const void*>(msm_tree_kernel<F>)};
   for (uint32_t rmul : {1u, 3u, 5u, 7u, 9u, 11u, 13u, 15u}) ZK_DISPATCH_RMUL(rmul, fns.push_back(reinterpret_cast<const void*>(msm_digits_hist_kernel<RM>)));
   for (const void* fn : fns) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1701,7 +1714,7 @@ int part_configure(int dev) {
       rc = ZK_ERR_DEVICE;
     }
   }
-  g_part_cfg[dev] = rc;
+  g_part_cfg[key] = rc;
   return rc;
 }
 
@@ -1872,17 +1885,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   const uint64_t tree_tmp = (uint64_t)n_out * ((tree_cnt + MSM_TREE_SLICE - 1) / MSM_TREE_SLICE);
   size_t o_sumtmp = take((size_t)WL * tree_tmp * 2 * sizeof(XYZZ<F>));
 
-  int rc = part_configure(dev);
+  int rc = part_configure<F>(dev);
   if (rc) return rc;
   const bool small_ws = off <= WS_SMALL;
-  std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
+  Workspace& dev_ws = ws_of(dev);
+  std::unique_lock<std::mutex> lk(dev_ws.mu, std::defer_lock);
   void* base = nullptr;
   SmallWsLease lease;
   if (small_ws) {
     rc = tws_acquire(dev, off, st, &lease, &base);
   } else {
     lk.lock();
-    rc = ws_reserve(dev, off, &base);
+    rc = ws_reserve(dev_ws, off, &base);
   }
   if (rc) return rc;
   char* ws = (char*)base;
@@ -2356,9 +2370,10 @@ int segsum_device(const Affine<F>* d_points, uint64_t nnz, const uint32_t* d_row
   size_t o_item_off = take((size_t)(hb + 2) * 4);
   size_t o_seg = take((size_t)max_items * sizeof(XYZZ<F>));
   size_t o_buckets = take((size_t)n_rows * sizeof(XYZZ<F>));
-  std::lock_guard<std::mutex> lk(g_ws_mu);
+  Workspace& dev_ws = ws_of(dev);
+  std::lock_guard<std::mutex> lk(dev_ws.mu);
   void* base = nullptr;
-  int rc = ws_reserve(dev, off, &base);
+  int rc = ws_reserve(dev_ws, off, &base);
   if (rc) return rc;
   char* ws = (char*)base;
   uint32_t* vals = (uint32_t*)(ws + o_vals);

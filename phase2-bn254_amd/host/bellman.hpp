@@ -49,12 +49,18 @@ struct G2Affine {  // x.c0 || x.c1 || y.c0 || y.c1
 };
 static_assert(sizeof(G1Affine) == 64 && sizeof(G2Affine) == 128 && sizeof(G1Projective) == 96 && sizeof(G2Projective) == 192, "ABI layouts");
 
-// ---- multicore.rs:17-72.  The reference's Worker is a CPU pool; here it names the GPU this process drives.
+// ---- multicore.rs:17-72.  The reference's Worker is a CPU pool; here it names the GPU(s) this process drives: Worker(3) one
+// device; Worker({0, 1, .., 7}) the single-process multi-GPU mode of mi355zk_init -- host-buffer multiexps of >= 2^20 exponents are
+// cut into one point range per device and joined on the host, shorter calls take the devices in turn (include/mi355zk.h).  The
+// last Worker constructed defines the library's device set.
 class Worker {
  public:
   explicit Worker(int device = -1) {
     int rc = device >= 0 ? mi355zk_init(&device, 1) : mi355zk_init(nullptr, 0);
     if (rc != 0) throw SynthesisError(SynthesisError::Device);
+  }
+  explicit Worker(const std::vector<int>& devices) {
+    if (mi355zk_init(devices.data(), (int)devices.size()) != 0) throw SynthesisError(SynthesisError::Device);
   }
   uint32_t log_num_cpus() const { return 0; }  // multicore.rs:37-39; the serial/parallel FFT split is moot on the GPU
 };

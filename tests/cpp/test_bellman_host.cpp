@@ -5,6 +5,7 @@
 //   bellman/src/source.rs:44-70       Source errors through the future
 // Run by tests/test_gpu_cpp_host.py on the GPU box; prints "ok <name>" lines and exits 0 on success.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 
@@ -84,6 +85,34 @@ int main() {
     try { multiexp<G1Affine>(worker, {short_bases, 0}, FullDensity{}, exps).get(); CHECK(false); }
     catch (const SynthesisError& e) { CHECK(e.kind == SynthesisError::UnexpectedIdentity && e.index == 4); }
     std::puts("ok density_and_source_errors");
+
+    // the single-process multi-GPU mode: the same calls cut into cells over a device set (here four logical devices on GPU 0);
+    // same affine point, same SynthesisError and exponent index as the one-device call
+    setenv("MI355ZK_MULTI_MIN_LOG", "6", 1);
+    {
+      Worker four(std::vector<int>{0, 0, 0, 0});
+      CHECK(mi355zk_device_count() == 4);
+      G1Projective cut = multiexp<G1Affine>(four, {bases, 0}, FullDensity{}, exps).get();
+      oracle_g1_to_affine(a, reinterpret_cast<const uint64_t*>(&cut));
+      CHECK(std::memcmp(a, b, 64) == 0);
+      G1Projective sparse4 = multiexp<G1Affine>(four, {bases, 0}, d, exps).get();
+      uint64_t s1[8], s4[8];
+      oracle_g1_to_affine(s1, reinterpret_cast<const uint64_t*>(&sparse));
+      oracle_g1_to_affine(s4, reinterpret_cast<const uint64_t*>(&sparse4));
+      CHECK(std::memcmp(s1, s4, 64) == 0);
+      auto holed = std::make_shared<std::vector<G1Affine>>(*bases);
+      (*holed)[1300] = G1Affine{};
+      (*holed)[700] = G1Affine{};
+      try { multiexp<G1Affine>(four, {holed, 0}, FullDensity{}, exps).get(); CHECK(false); }
+      catch (const SynthesisError& e) { CHECK(e.kind == SynthesisError::UnexpectedIdentity && e.index == 700); }
+      auto fewer = std::make_shared<std::vector<G1Affine>>(bases->begin(), bases->begin() + 1000);
+      try { multiexp<G1Affine>(four, {fewer, 0}, FullDensity{}, exps).get(); CHECK(false); }
+      catch (const SynthesisError& e) { CHECK(e.kind == SynthesisError::IoErrorUnexpectedEof && e.index == 1000); }
+    }
+    unsetenv("MI355ZK_MULTI_MIN_LOG");
+    Worker back(0);
+    CHECK(mi355zk_device_count() == 1);
+    std::puts("ok multi_device_cells");
   }
 
   for (uint32_t log_n : {1u, 7u, 13u}) {  // fft_consistency + oracle parity of all four ops

@@ -57,3 +57,26 @@ def test_eight_ranks_at_the_baseline_size():
     assert got["n_gpus"] == 8 and got["full_size_linearity_check"] and got["sharded_result_matches_unsharded"]
     assert got["result_affine_x_limb0"] == "0x5c2b6af288baf266"
     assert got["config"]["points_per_gpu"] == 1 << 25 and "2 point range(s) x 4 window group(s)" in got["config"]["parallelism"]
+
+
+def test_plain_command_launches_its_own_ranks():
+    """`python3 bench.py --gpus 4 ...` exactly as typed (no torchrun, WORLD_SIZE unset): bench.py starts the ranks itself and rank 0
+    prints the one JSON line -- so the first multi-GPU lease produces a scaling curve instead of an argument error."""
+    args = [sys.executable, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--log-n", "21", "--no-cpu-baseline", "--no-h2d-leg", "--no-secondary"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 4 and got["rccl_ranks"] == 4 and got["backend"] == "gloo" and got["sharded_result_matches_unsharded"]
+    ref = _run(1, "random")
+    assert got["result_affine_x_limb0"] == ref["result_affine_x_limb0"]
+    # without the gloo escape hatch a box with fewer GPUs than ranks is refused with a message, not a crash inside RCCL
+    import torch
+
+    if torch.cuda.device_count() < 4:
+        env.pop("BENCH_BACKEND")
+        out = subprocess.run(args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 2 and "GPU(s) visible" in out.stderr

@@ -30,5 +30,5 @@ def test_cpp_host_mirror_against_oracle():
     _build()
     out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    for name in ("multiexp_equals_naive", "density_and_source_errors", "evaluation_domain", "ceremony_mirror", "groth16_create_proof"):
+    for name in ("multiexp_equals_naive", "density_and_source_errors", "multi_device_cells", "evaluation_domain", "ceremony_mirror", "groth16_create_proof"):
         assert "ok " + name in out.stdout

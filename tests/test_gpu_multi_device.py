@@ -1,0 +1,204 @@
+"""The single-process multi-GPU mode of the C ABI (mi355zk_init with n_devices > 1, include/mi355zk.h): a host-buffer multiexp is cut
+into one point range per device, every cell runs the single-GPU pipeline from its own host thread, and the Jacobian partials are
+joined on the host.  The consumer it exists for is ONE Rust process (phase2/src/bin/prove.rs -> bellman/src/groth16/prover.rs:250-298
+-> multiexp.rs:330-355).  On a one-GPU box the device set repeats id 0 ({0,0}, {0,0,0,0}, {0} x 8): logical devices sharing a GPU,
+the same trick the gloo tests use for ranks.  Everything is compared with the CPU oracle: affine result, SynthesisError and index."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as GU
+import inputs
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def multi(zk, worker, monkeypatch):
+    """factory: a Worker over `k` logical devices (all physical device 0), cutting calls from 64 exponents on"""
+    monkeypatch.setenv("MI355ZK_MULTI_MIN_LOG", "6")
+
+    def make(k):
+        w = zk.Worker(devices=[0] * k)
+        assert zk.lib.load().mi355zk_device_count() == k
+        return w
+
+    yield make
+    zk.unpin_bases(None)
+    zk.Worker(0)  # back to one device for the tests that follow
+    assert zk.lib.load().mi355zk_device_count() == 1
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_cells_over_repeated_device_ids_match_the_oracle(zk, multi, group, k):
+    G = O.G1 if group == 1 else O.G2
+    n, off = 3000, 5
+    rng = np.random.default_rng(4100 + k + group)
+    bits = rng.random(n) < 0.6
+    sel = np.nonzero(bits)[0]
+    bases = inputs.bases_progression_cpu(group, len(sel) + off, seed=4101 + group)
+    scalars = inputs.random_scalars(n, seed=4102 + k)
+    scalars[::17] = 0
+    scalars[5::23] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    dens = GU.density_words(bits)
+    w = multi(k)
+    # density map + source offset: every cell starts at the prefix popcount of its first exponent
+    rc, want = G.multiexp(bases, scalars, density=dens, density_bits=n, base_offset=off, threads=4)
+    assert rc == 0
+    dm = zk.DensityTracker.from_bools(bits)
+    got = zk.multiexp(w, (bases, off), dm, scalars).wait()                      # unpinned: every cell uploads its slice of the bases
+    assert np.array_equal(G.to_affine(got), G.to_affine(want))
+    zk.pin_bases(bases)
+    for _ in range(2):                                                          # pinned: kept on the device(s) after the first call
+        assert np.array_equal(G.to_affine(zk.multiexp(w, (bases, off), dm, scalars).wait()), G.to_affine(want))
+    zk.unpin_bases(bases)
+    # FullDensity over a prefix
+    m = len(sel)
+    rc, want = G.multiexp(bases, scalars[:m], threads=4)
+    assert rc == 0
+    assert np.array_equal(G.to_affine(zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars[:m]).wait()), G.to_affine(want))
+
+
+@pytest.mark.parametrize("k", [2, 8])
+def test_errors_carry_the_global_exponent_index(zk, multi, k):
+    """UnexpectedIdentity in a later cell, two identities (the lower exponent wins whatever cell finishes first), Eof planned for
+    the whole call, identity before Eof, a non-canonical exponent: code and index of the single-device call (and of the oracle)."""
+    n, off = 2500, 3
+    rng = np.random.default_rng(4200 + k)
+    bits = rng.random(n) < 0.7
+    sel = np.nonzero(bits)[0]
+    bases = inputs.bases_progression_cpu(1, len(sel) + off, seed=4201)
+    scalars = inputs.random_scalars(n, seed=4202)
+    dens = GU.density_words(bits)
+    dm = zk.DensityTracker.from_bools(bits)
+    w = multi(k)
+    bad = bases.copy()
+    r_hi, r_lo = len(sel) * 7 // 8, len(sel) * 5 // 8
+    bad[off + r_hi] = 0
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(w, (bad, off), dm, scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == int(sel[r_hi])
+    bad[off + r_lo] = 0
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(w, (bad, off), dm, scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == int(sel[r_lo])
+    assert O.G1.multiexp(bad, scalars, density=dens, density_bits=n, base_offset=off)[0] == 1
+    # a zero exponent skips its identity base without looking at it (multiexp.rs:95-96)
+    sc = scalars.copy()
+    sc[sel[r_lo]] = 0
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(w, (bad, off), dm, sc).wait()
+    assert e.value.index == int(sel[r_hi])
+    # FullDensity with more exponents than bases: Eof at the first exponent without a base
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(w, (bases, off), zk.FullDensity(), scalars).wait()
+    assert e.value.kind == zk.SynthesisError.IO_UNEXPECTED_EOF and e.value.index == len(sel)
+    # ... and an identity among the exponents before it wins
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(w, (bad, off), zk.FullDensity(), scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == r_lo
+    # a non-canonical exponent in the last cell
+    sc = scalars.copy()
+    sc[n - 7, 3] |= np.uint64(1 << 62)
+    with pytest.raises(ValueError):
+        zk.multiexp(w, (bases, off), dm, sc).wait()
+    assert zk.lib.load().mi355zk_last_error_index() == n - 7
+
+
+@pytest.mark.parametrize("plan", ["2x2", "1x4", "2x4"])
+def test_window_group_cells(zk, multi, monkeypatch, plan):
+    """MI355ZK_MULTI_PLAN: point ranges x groups of scalar windows (shard.py's cells) inside one process."""
+    monkeypatch.setenv("MI355ZK_MULTI_PLAN", plan)
+    n = 5000
+    bases = inputs.bases_progression_cpu(1, n, seed=4301)
+    scalars = inputs.random_scalars(n, seed=4302)
+    rc, want = O.G1.multiexp(bases, scalars, threads=8)
+    assert rc == 0
+    w = multi(8)
+    assert np.array_equal(O.G1.to_affine(zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars).wait()), O.G1.to_affine(want))
+    bad = bases.copy()
+    bad[4000] = 0
+    with pytest.raises(zk.SynthesisError) as e:
+        zk.multiexp(w, (bad, 0), zk.FullDensity(), scalars).wait()
+    assert e.value.kind == zk.SynthesisError.UNEXPECTED_IDENTITY and e.value.index == 4000
+
+
+def test_short_calls_take_the_devices_in_turn_and_concurrent_callers_work(zk, worker, monkeypatch):
+    """Below the cutting threshold a call runs whole on the next device of the set; eight host threads at once (the prover's eight
+    multiexps, prover.rs:250-298), some cut into cells and some not."""
+    import threading
+
+    monkeypatch.setenv("MI355ZK_MULTI_MIN_LOG", "11")
+    w = zk.Worker(devices=[0, 0, 0, 0])
+    try:
+        cases = []
+        for t in range(8):
+            n = 700 if t % 2 else 4096
+            bases = inputs.bases_progression_cpu(1, n, seed=4400 + t)
+            scalars = inputs.random_scalars(n, seed=4410 + t)
+            rc, want = O.G1.multiexp(bases, scalars, threads=4)
+            assert rc == 0
+            cases.append((bases, scalars, O.G1.to_affine(want)))
+        got = [None] * 8
+
+        def run(t):
+            got[t] = O.G1.to_affine(zk.multiexp(w, (cases[t][0], 0), zk.FullDensity(), cases[t][1]).wait())
+
+        th = [threading.Thread(target=run, args=(t,)) for t in range(8)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for t in range(8):
+            assert np.array_equal(got[t], cases[t][2]), t
+    finally:
+        zk.Worker(0)
+
+
+def test_init_rejects_devices_that_do_not_exist(zk, worker):
+    lib = zk.lib.load()
+    ids = (C.c_int * 2)(0, 1 << 20)
+    assert lib.mi355zk_init(ids, 2) == zk.lib.ERR_BAD_ARGS
+    assert lib.mi355zk_init(None, 2) == zk.lib.ERR_BAD_ARGS
+    assert lib.mi355zk_device_count() == 1   # a rejected set changes nothing
+
+
+def test_eight_cells_at_2e22_same_point_as_one_device(zk, worker, monkeypatch):
+    """At a size where the cells are real work (2^19 exponents each, streamed upload, pinned bases): the same affine point as the
+    device-resident single-GPU call, with and without a density map."""
+    import torch
+
+    import bench
+
+    log_n = 22
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    k = bench.gen_scalars(n, 4501, dev)
+    d_bases = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    assert zk.lib.load().mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(d_bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+    d_scalars = bench.gen_scalars(n, 4502, dev)
+    want = O.G1.to_affine(zk.multiexp(worker, (d_bases, 0), zk.FullDensity(), d_scalars).wait())
+    rng = np.random.default_rng(4503)
+    bits = rng.random(n + 1000) < 0.9
+    m = int(np.searchsorted(np.cumsum(bits), n))  # exponents that consume (almost) all bases
+    bits = bits[:m]
+    dm = zk.DensityTracker.from_bools(bits)
+    d_sc2 = bench.gen_scalars(m, 4504, dev)
+    want_d = O.G1.to_affine(zk.multiexp(worker, (d_bases, 0), dm, d_sc2).wait())
+    h_bases = d_bases.cpu().numpy().view(np.uint64)
+    h_scalars = d_scalars.cpu().numpy().view(np.uint64)
+    h_sc2 = d_sc2.cpu().numpy().view(np.uint64)
+    del d_bases, d_scalars, d_sc2, k
+    w = zk.Worker(devices=[0] * 8)
+    try:
+        zk.pin_bases(h_bases)
+        for _ in range(2):
+            assert np.array_equal(O.G1.to_affine(zk.multiexp(w, (h_bases, 0), zk.FullDensity(), h_scalars).wait()), want)
+        assert np.array_equal(O.G1.to_affine(zk.multiexp(w, (h_bases, 0), dm, h_sc2).wait()), want_d)
+    finally:
+        zk.unpin_bases(None)
+        zk.Worker(0)
