@@ -42,7 +42,7 @@ def test_g1_matches_oracle(zk, worker, n):
     assert np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
 
 
-@pytest.mark.parametrize("n", [1, 33, 500, 4096])
+@pytest.mark.parametrize("n", [1, 33, 500, 4096, 1 << 16])
 def test_g2_matches_oracle(zk, worker, n):
     bases = inputs.bases_progression_cpu(2, n, seed=n)
     scalars = inputs.random_scalars(n, seed=11 * n + 1)

@@ -15,6 +15,22 @@ published test vectors of the EVM precompiles therefore pin this curve from the 
   (out of scope); the points anchor the twist equation, the wire format and -- r * P = infinity on a non-generator r-torsion
   point -- the G2 group law.
 
+Provenance, one row per vector, so that a reader WITH network access can diff them in a minute (repository ethereum/go-ethereum,
+directory core/vm/testdata/precompiles/; every file is a JSON list of {"Input", "Expected", "Name", ...} objects):
+
+  | constant below        | upstream file        | case "Name" | what is compared                                   |
+  |-----------------------|----------------------|-------------|----------------------------------------------------|
+  | ADD["chfast1"]        | bn256Add.json        | chfast1     | "Input" (128 B = P || Q), "Expected" (64 B = P + Q) |
+  | ADD["chfast2"]        | bn256Add.json        | chfast2     | same; its input is chfast1's sum || chfast1's first operand |
+  | MUL["chfast1"]        | bn256ScalarMul.json  | chfast1     | "Input" (96 B = P || k), "Expected" (64 B = k P)   |
+  | MUL["chfast2"]        | bn256ScalarMul.json  | chfast2     | same; k = q - 1 is NOT reduced mod r               |
+  | MUL["chfast3"]        | bn256ScalarMul.json  | chfast3     | same                                               |
+  | DOUBLE_OF_GENERATOR   | EIP-196 text (and bn256Add.json "cdetrio11": (1,2) + (1,2)) | -- | the 64-byte sum 2 * (1, 2)  |
+  | PAIRING_JEFF1         | bn256Pairing.json    | jeff1       | "Input" (384 B = two (G1, G2) pairs); "Expected" = 1 (the pairing itself is out of scope here) |
+
+(EIP-196: https://eips.ethereum.org/EIPS/eip-196, EIP-197: https://eips.ethereum.org/EIPS/eip-197.  The same vectors travel with
+every EVM implementation's precompile tests -- e.g. aleth's test/unittests/libdevcrypto, where the "chfast" cases originate.)
+
 The vectors were typed in from memory of those files (no network in this image) and are self-checking: every input and output
 below must lie on the curve, which a single wrong hex digit breaks with overwhelming probability, before it is compared with
 anything this repository computes.  TEST INFRASTRUCTURE: the oracle is the thing under test here, not the product.
