@@ -80,15 +80,35 @@ __device__ __forceinline__ FrU tab_load(const UTab* p) {
   return r;
 }
 
+// LDS layout of a tile (round 4): ELEMENT-major, nine consecutive words per element.  The stride of 9 words is odd, so lanes with
+// consecutive (or swz-permuted) element indices still sit on different banks -- bank = (9 idx + l) mod 32 is idx mod 32 up to a
+// bijection -- and the nine limbs of an element are at FIXED offsets from ONE address: ds_read / ds_write take them as immediates
+// (hipcc pairs them into ds_read2_b32), where the limb-PLANE layout of rounds 1-3 (lds[l * plane + idx], plane a run-time value)
+// cost one VALU add and one address register per limb: 36 address registers per radix-4 group, ~85 VALU instructions per
+// element and pass.  -DZK_NTT_LDS_PLANES restores the planes for the comparison.
 __device__ __forceinline__ FrU lds_load(const uint32_t* lds, uint32_t plane, uint32_t idx) {
   FrU r;
+#ifdef ZK_NTT_LDS_PLANES
 #pragma unroll
   for (int l = 0; l < 9; ++l) r.l[l] = lds[l * plane + idx];
+#else
+  (void)plane;
+  const uint32_t* e = lds + idx * 9u;
+#pragma unroll
+  for (int l = 0; l < 9; ++l) r.l[l] = e[l];
+#endif
   return r;
 }
 __device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t plane, uint32_t idx, const FrU& v) {
+#ifdef ZK_NTT_LDS_PLANES
 #pragma unroll
   for (int l = 0; l < 9; ++l) lds[l * plane + idx] = v.l[l];
+#else
+  (void)plane;
+  uint32_t* e = lds + idx * 9u;
+#pragma unroll
+  for (int l = 0; l < 9; ++l) e[l] = v.l[l];
+#endif
 }
 __device__ __forceinline__ Fr gload(const Fr* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmi355zk.so")
+# (MI355ZK_SO: another build of the same library, for same-box A/B measurements of a kernel variant -- tools/, never the tests)
+SO_PATH = os.environ.get("MI355ZK_SO") or os.path.join(_HERE, "libmi355zk.so")
 
 OK, ERR_UNEXPECTED_IDENTITY, ERR_UNEXPECTED_EOF, ERR_BAD_ARGS, ERR_DEVICE = 0, 1, 2, 3, -1
 OP_FFT, OP_IFFT, OP_COSET_FFT, OP_ICOSET_FFT = 0, 1, 2, 3
