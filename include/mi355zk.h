@@ -83,6 +83,9 @@ extern "C" {
 int mi355zk_init(const int *device_ids, int n_devices);
 /* number of (logical) devices host-buffer multiexps are spread over: 1 unless mi355zk_init was given more */
 int mi355zk_device_count(void);
+/* GPUs visible to the process (hipGetDeviceCount; 0 when there is none or no driver): the ids 0 .. count-1 are what a caller
+ * without HIP bindings of its own passes to mi355zk_init */
+int mi355zk_visible_devices(void);
 void mi355zk_shutdown(void);
 const char *mi355zk_version(void);
 

@@ -1787,6 +1787,11 @@ int mi355zk_init(const int* device_ids, int n_devices) {
   g_devset = set;
   return ZK_OK;
 }
+int mi355zk_visible_devices(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return count;
+}
 int mi355zk_device_count(void) {
   std::lock_guard<std::mutex> lk(g_devset_mu);
   return g_devset.empty() ? 1 : (int)g_devset.size();

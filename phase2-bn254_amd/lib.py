@@ -23,6 +23,7 @@ _u64p, _u32p, _u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c
 SIGNATURES = {
     "mi355zk_init": (_i, [C.POINTER(C.c_int), _i]),
     "mi355zk_device_count": (_i, []),
+    "mi355zk_visible_devices": (_i, []),
     "mi355zk_shutdown": (None, []),
     "mi355zk_version": (C.c_char_p, []),
     "mi355zk_bases_cache_pin": (_i, [_vp, _sz, _i]),

@@ -130,3 +130,19 @@ def test_table_geometry_is_sane_and_table_entries_reject_bad_arguments():
     assert lib.mi355zk_bases_cache_pin_tables(None, 4, 1) == zk.lib.ERR_BAD_ARGS
     d, t = C.c_size_t(1), C.c_size_t(1)
     assert lib.mi355zk_bases_cache_info(out.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 0 and d.value == 0 and t.value == 0
+
+
+def test_device_set_queries_work_without_a_gpu():
+    """mi355zk_visible_devices / mi355zk_device_count are plain queries (no device needed); a device set naming a GPU that is not
+    there is refused (bad arguments or a device error, never accepted)."""
+    import ctypes as C
+
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    n = lib.mi355zk_visible_devices()
+    assert n >= 0
+    assert lib.mi355zk_device_count() >= 1
+    ids = (C.c_int * 2)(0, 1 << 20)
+    assert lib.mi355zk_init(ids, 2) != 0
+    assert lib.mi355zk_init(None, -1) != 0
