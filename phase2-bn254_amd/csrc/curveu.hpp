@@ -247,6 +247,89 @@ ZK_HD void xyzzr_add(XYZZU<PR>& acc, const XYZZU<PR>& o) {
   acc.zzz = zzz3;
 }
 
+#if defined(__HIPCC__)
+// ---- the same addition by FOUR cooperating lanes (a "quad": lanes 4q .. 4q+3 of a wave), for the parallelism-starved tails of the
+// bucket reduction (msm_impl.hpp: the later running-sum levels, the last rounds of the tree kernels).  There a few thousand lanes
+// each walk a chain of dependent additions, and a lane's addition is 14 field products one after the other (~3300 VALU instructions,
+// ~7 us) however idle the device is.  The products of an addition are mostly independent:
+//     round 1:  U1 = X1 ZZ2   U2 = X2 ZZ1   S1 = Y1 ZZZ2   S2 = Y2 ZZZ1
+//     round 2:  ZZ1 ZZ2       ZZZ1 ZZZ2     PP = P^2       RR = R^2             (P = U2 - U1, R = S2 - S1)
+//     round 3:  PPP = P PP    Q = U1 PP     ZZ3 = ZZ1 ZZ2 PP
+//     round 4:  Y3 = R (Q - X3) - S1 PPP  (two products, one reduction)         ZZZ3 = ZZZ1 ZZZ2 PPP
+// Every lane of the quad holds BOTH operands (replicated), picks its own pair of factors by its role (v_cndmask), runs the one
+// product routine of the round, and the four results travel to all four lanes with DPP quad permutes (v_mov_b32 quad_perm, full
+// rate, no LDS): three u_mul + one u_mul2 in sequence instead of 14 products, ~1400 instructions per lane.  The result is again
+// replicated.  Same values, same bounds as xyzzr_add (u_sqr(a) and u_mul(a, a) form the same column sums), so the canonical records
+// written downstream are bit-identical.  The special cases (an operand at infinity, equal or opposite points) are uniform over the
+// quad -- its lanes hold the same data -- and take the one-lane code, executed redundantly.
+// ALL FOUR lanes of a quad must be active when this is called (DPP reads its source lanes).
+template <int K>
+__device__ __forceinline__ uint32_t quad_get(uint32_t v) {   // v of lane K of the caller's quad
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, true);
+#else
+  return v;   // (host pass of hipcc: never executed)
+#endif
+}
+template <int K, class PR>
+__device__ __forceinline__ FpU<PR> quad_get(const FpU<PR>& a) {
+  FpU<PR> r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = quad_get<K>(a.l[i]);
+  return r;
+}
+template <class PR>
+__device__ __forceinline__ FpU<PR> quad_pick(uint32_t role, const FpU<PR>& a0, const FpU<PR>& a1, const FpU<PR>& a2, const FpU<PR>& a3) {
+  // two levels of two-way selects on VALUES (a four-way `?:` chain over the limb arrays became a table in scratch memory indexed by
+  // the role: hipcc selects the pointer, not the value)
+  FpU<PR> r;
+  const bool odd = (role & 1u) != 0, high = (role & 2u) != 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint32_t v0 = a0.l[i], v1 = a1.l[i], v2 = a2.l[i], v3 = a3.l[i];
+    const uint32_t lo = odd ? v1 : v0, hi = odd ? v3 : v2;
+    r.l[i] = high ? hi : lo;
+  }
+  return r;
+}
+template <class PR>
+__device__ __forceinline__ XYZZU<PR> xyzzr_add_quad(const XYZZU<PR> acc, const XYZZU<PR> o, uint32_t role) {   // by value in, by value out, ONE exit (hipcc keeps by-reference / multiply-returned sums in scratch)
+  XYZZU<PR> res = acc;
+  if (!o.is_zero()) {
+    res = o;
+    if (!acc.is_zero()) {
+      FpU<PR> t = u_mul(quad_pick(role, acc.x, o.x, acc.y, o.y), quad_pick(role, o.zz, acc.zz, o.zzz, acc.zzz));
+      const FpU<PR> u1 = quad_get<0>(t), u2 = quad_get<1>(t), s1 = quad_get<2>(t), s2 = quad_get<3>(t);   // < 1.08p, < 1.08p, < 1.03p, < 1.03p
+      const FpU<PR> p = u_sub<2, 1>(u2, u1);                     // U1 < 2p;  P < 4p, N
+      const FpU<PR> r = u_sub<2, 1>(s2, s1);                     // S1 < 2p;  R < 4p, N
+      t = u_mul(quad_pick(role, acc.zz, acc.zzz, p, r), quad_pick(role, o.zz, o.zzz, p, r));
+      const FpU<PR> zz12 = quad_get<0>(t), zzz12 = quad_get<1>(t), pp = quad_get<2>(t), rr = quad_get<3>(t);   // < 1.03p, < 1.03p, < 1.1p, < 1.1p
+      t = u_mul(quad_pick(role, p, u1, zz12, zz12), pp);
+      const FpU<PR> ppp = quad_get<0>(t), q = quad_get<1>(t), zz3 = quad_get<2>(t);   // < 1.03p, < 1.01p, < 2p
+      const FpU<PR> x3 = u_sub<4, 3>(rr, u_add(ppp, u_dbl(q)));  // < 5.1p  (invariant X < 6p)
+      const FpU<PR> d = u_sub<8, 1>(q, x3);                      // < 9.1p
+      const FpU<PR> ns1 = u_sub<2, 1>(FpU<PR>::zero(), s1);      // 2p - S1 in (0, 2p], N
+      const bool lead = role == 0;
+      FpU<PR> fa, fb, fc;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        fa.l[i] = lead ? r.l[i] : zzz12.l[i];
+        fb.l[i] = lead ? d.l[i] : ppp.l[i];
+        fc.l[i] = lead ? ns1.l[i] : 0u;
+      }
+      t = u_mul2(fa, fb, fc, ppp);                               // lane 0: R*D - S1*PPP < 1.24p;  lanes 1..3: ZZZ1 ZZZ2 PPP < 2p
+      res = XYZZU<PR>{x3, quad_get<0>(t), zz3, quad_get<1>(t)};
+      if (u_is_zero_lt2p(zz3)) {
+        // P == 0 (ZZ1, ZZ2 != 0): the points have the same x.  Same point -> double; opposite -> infinity.  (uniform over the quad)
+        res = XYZZU<PR>::zero();
+        if (u_is_zero_lt8p(r)) res = xyzzu_double(acc);
+      }
+    }
+  }
+  return res;
+}
+#endif  // __HIPCC__
+
 // =================================================================================================
 // Jacobian accumulator on U-form elements, for SCALAR MULTIPLICATION (batch_exp): a doubling is cheaper in
 // Jacobian coordinates (dbl-2009-l: 4 squarings + 3 products here, 1071 mads) than in XYZZ (1467), and a scalar

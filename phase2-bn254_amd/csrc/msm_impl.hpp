@@ -1289,6 +1289,29 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __
   store_vec(outS + t, xyzzr_store(run));
 }
 
+// The same level with a QUAD of lanes per chunk (curveu.hpp: xyzzr_add_quad -- four lanes share the products of every addition):
+// for the levels that are left with too few chunks to fill the device, where a lane's 2L dependent additions are what the launch
+// lasts.  G1 only (the Fq2 addition has its own, different product graph).  Lanes 4t .. 4t+3 hold the same running sums.
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_reduce_level_quad_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t L, uint32_t off,
+                                                                   uint32_t W, XYZZ<F>* __restrict__ outA, XYZZ<F>* __restrict__ outS) {
+  const uint32_t chunks = (count + L - 1) / L;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, t = gt >> 2, role = gt & 3u;
+  if (t >= chunks * W) return;   // (whole quads leave: t is the same for the four lanes)
+  const uint32_t w = t / chunks, ch = t % chunks;
+  const uint32_t lo = ch * L, hi = lo + L < count ? lo + L : count;
+  const XYZZ<F>* B = in + (uint64_t)w * count;
+  // run_x = B[x] + .. + B[hi-1];  acc = sum of run_x over x (off == 1: weights y + 1) or over x > lo (off == 0: weights y).
+  // (two call sites and no selected operands: with the lane kernel's `a = do_acc ? acc : run` hipcc kept the sums in scratch here)
+  auto run = xyzzr_load(XYZZ<F>::zero()), acc = run;
+  for (uint32_t x = hi; x-- > lo;) {
+    run = xyzzr_add_quad(run, xyzzr_load(load_vec(B + x)), role);
+    if (off != 0 || x > lo) acc = xyzzr_add_quad(acc, run, role);
+  }
+  if (role == 0) store_vec(outA + t, xyzzr_store(acc));
+  if (role == 1) store_vec(outS + t, xyzzr_store(run));
+}
+
 // 5b/5c. the tail of the reduction, by trees.  A running-sum level costs 2L dependent additions however few
 //     elements are left, so once at most MSM_FINAL_MAX elements per window remain the weighted sum of the last S[]
 //     is finished by BIT DECOMPOSITION:  sum_x (x+off) S[x] = sum_j 2^j * (sum over x with bit j of (x+off) set of S[x]),
@@ -1316,9 +1339,10 @@ struct TreeJobs {
   int32_t bit[MSM_MAX_JOBS];
   uint32_t first_block[MSM_MAX_JOBS + 1];  // prefix sums of reps * slices: blocks per window = first_block[n_jobs]
   uint32_t n_jobs;
+  uint32_t quad;                           // 1: the last rounds of a slice's tree run four lanes per addition (G1)
 };
 template <class F>
-__global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_tree_kernel(const TreeJobs<F> J) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using U = typename BucketAcc<F>::type;   // sums travel between the rounds in REGISTER form (U-form limbs): no re-packing per round
   U* sh = reinterpret_cast<U*>(smem);
@@ -1342,13 +1366,33 @@ __global__ void __launch_bounds__(256) msm_tree_kernel(const TreeJobs<F> J) {
   // ONE inlined xyzz_add for the pair and for every tree level (code size).  Lanes [s, 2s) publish, lanes [0, s)
   // consume; the regions written in consecutive rounds are disjoint from the ones still being read, so one
   // barrier per round.
+  // Round 4: once at most 64 additions are left in a round (G1), FOUR lanes share each of them (curveu.hpp: xyzzr_add_quad): the
+  // last seven rounds are a chain of seven additions on an otherwise idle workgroup, and a quad's addition is three products +
+  // one double product deep instead of fourteen.  J.quad == 0 keeps the one-lane rounds (the comparison; Fq2 always).
+  const uint32_t quad_from = (sizeof(F) == sizeof(Fq) && J.quad) ? 128u : 0u;   // the value of s after which the quads take over
   for (uint32_t s = 256;;) {
     xyzzr_add(acc, other);   // (its results keep the invariants its operands need: the running-sum levels chain it the same way)
     s >>= 1;
-    if (s == 0) break;
+    if (s == 0 || s < quad_from) break;
     if (threadIdx.x >= s && threadIdx.x < 2 * s) sh[threadIdx.x] = acc;
     __syncthreads();
     other = threadIdx.x < s ? sh[threadIdx.x + s] : U::zero();
+  }
+  if constexpr (sizeof(F) == sizeof(Fq)) {
+    if (quad_from) {
+      // lanes 0 .. 127 hold the sums of the round s = 128; quad q = lane / 4 continues element q
+      if (threadIdx.x < 128) sh[threadIdx.x] = acc;
+      __syncthreads();
+      const uint32_t q = threadIdx.x >> 2, role = threadIdx.x & 3u;
+      acc = sh[q];
+      for (uint32_t s = 64; s > 0; s >>= 1) {
+        if (q < s) {                       // (uniform over a quad)
+          acc = xyzzr_add_quad(acc, sh[q + s], role);
+          if (role == 0) sh[q] = acc;      // read by quad q - s/2 in the next round (when q >= s/2)
+        }
+        __syncthreads();
+      }
+    }
   }
   if (threadIdx.x == 0) store_vec(J.out[job] + ((uint64_t)w * J.out_w[job] + rp) * slices + slice, xyzzr_store(acc));
 }
@@ -2079,20 +2123,38 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   };
 
   const uint32_t* d_sc_first = d_scalars;
+  // quad additions in the parallelism-starved parts of the reduction (G1; env MI355ZK_MSM_QUAD=0 for the comparison,
+  // MI355ZK_MSM_QUAD_MAX = the largest chunk count x windows a level may have to run four lanes per chunk)
+  static const char* env_quad = std::getenv("MI355ZK_MSM_QUAD");
+  static const char* env_quad_max = std::getenv("MI355ZK_MSM_QUAD_MAX");
+  const bool quad_tail = sizeof(F) == sizeof(Fq) && !(env_quad && env_quad[0] == '0');
+  const uint32_t quad_max_chunks = env_quad_max ? (uint32_t)std::atoi(env_quad_max) : 65536u;
   // ---- bucket reduction, the copy back and the host join: once per base vector
   auto finish_set = [&](Jacobian<F>* result, bool last_set) -> int {
     prof_begin(slot_red, st);
     {
       // wsums[w * n_out + k]:  k < n_levels: sum of A of level k;  k >= n_levels: bit sum j = k - n_levels of the last array
       TreeJobs<F> J{};
+      J.quad = quad_tail ? 1u : 0u;
       const XYZZ<F>* in = buckets;
       uint64_t o = 0;
       for (uint32_t lv = 0; lv < n_levels; ++lv) {
         uint32_t threads = lvl_chunks[lv] * WL;
         XYZZ<F>* A = partA + o * WL;
         XYZZ<F>* S = partS + o * WL;
-        hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], 1u << lvl_logl[lv],
-                           lv == 0 ? 1u : 0u, WL, A, S);
+        // a level with few chunks is a chain of 2L dependent additions per lane on a mostly idle device: four lanes per chunk
+        // then (msm_reduce_level_quad_kernel, G1); a level that fills the device keeps the lane per chunk (less work in total)
+        bool quad_level = false;
+        if constexpr (sizeof(F) == sizeof(Fq)) {
+          if (quad_tail && threads <= quad_max_chunks) {
+            quad_level = true;
+            hipLaunchKernelGGL(msm_reduce_level_quad_kernel<F>, dim3((4 * threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], 1u << lvl_logl[lv],
+                               lv == 0 ? 1u : 0u, WL, A, S);
+          }
+        }
+        if (!quad_level)
+          hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], 1u << lvl_logl[lv],
+                             lv == 0 ? 1u : 0u, WL, A, S);
         ZK_HIP(hipGetLastError());
         J.in[lv] = A;
         J.cnt[lv] = J.stride[lv] = lvl_chunks[lv];
