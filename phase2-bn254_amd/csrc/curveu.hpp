@@ -678,6 +678,89 @@ ZK_HD void xyzzr_add(XYZZU2& acc, const XYZZU2& o) {
   acc.zzz = zzz3;
 }
 
+#if defined(__HIPCC__)
+// ---- the G2 addition by a QUAD of lanes (see xyzzr_add_quad above).  An Fq2 product is two independent u_mul2 (its components), and
+// the products of an addition come in independent pairs, so a round is FOUR u_mul2 side by side: role bit 0 = the component, role bit 1
+// = which of the round's two Fq2 products.
+//     round 1: U1 = X1 ZZ2, U2 = X2 ZZ1      round 2: S1 = Y1 ZZZ2, S2 = Y2 ZZZ1     round 3: ZZ1 ZZ2, ZZZ1 ZZZ2
+//     round 4: PP = P^2, RR = R^2 (four single / double products)                    round 5: PPP = P PP, Q = U1 PP
+//     round 6: ZZ3 = (ZZ1 ZZ2) PP, ZZZ3 = (ZZZ1 ZZZ2) PPP                            round 7: Y3 (one u_mul4 per component: two lanes)
+// six u_mul2 and one u_mul4 in sequence instead of 28 + 2 of them.  Operands, bounds and results are those of xyzzr_add(XYZZU2&, ..).
+template <int K>
+__device__ __forceinline__ Fq2U quad_get2(const FqU& t) { return Fq2U{quad_get<K>(t), quad_get<K + 1>(t)}; }
+__device__ __forceinline__ FqU pick2(bool second, const FqU& a, const FqU& b) {
+  FqU r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint32_t va = a.l[i], vb = b.l[i];
+    r.l[i] = second ? vb : va;
+  }
+  return r;
+}
+// lanes 0, 1: the components of a1 * b1;  lanes 2, 3: those of a2 * b2   (nb1 / nb2: K p - b.c1, what f2u_mul<K> multiplies a.c1 by)
+__device__ __forceinline__ FqU quad_f2u_mul_pair(uint32_t role, const Fq2U& a1, const Fq2U& b1, const FqU& nb1, const Fq2U& a2, const Fq2U& b2,
+                                                  const FqU& nb2) {
+  const bool odd = (role & 1u) != 0, high = (role & 2u) != 0;
+  const FqU a0 = pick2(high, a1.c0, a2.c0), a1c = pick2(high, a1.c1, a2.c1);
+  const FqU b0 = pick2(high, b1.c0, b2.c0), b1c = pick2(high, b1.c1, b2.c1), nb = pick2(high, nb1, nb2);
+  return u_mul2(a0, pick2(odd, b0, b1c), a1c, pick2(odd, nb, b0));   // c0 = a0 b0 + a1 (-b1);  c1 = a0 b1 + a1 b0
+}
+__device__ __forceinline__ XYZZU2 xyzzr_add_quad(const XYZZU2 acc, const XYZZU2 o, uint32_t role) {
+  XYZZU2 res = acc;
+  if (!o.is_zero()) {
+    res = o;
+    if (!acc.is_zero()) {
+      const bool odd = (role & 1u) != 0, high = (role & 2u) != 0;
+      const FqU zero = FqU::zero();
+      FqU t = quad_f2u_mul_pair(role, acc.x, o.zz, u_sub<2, 1>(zero, o.zz.c1), o.x, acc.zz, u_sub<2, 1>(zero, acc.zz.c1));
+      const Fq2U u1 = quad_get2<0>(t), u2 = quad_get2<2>(t);   // < 1.15p
+      t = quad_f2u_mul_pair(role, acc.y, o.zzz, u_sub<2, 1>(zero, o.zzz.c1), o.y, acc.zzz, u_sub<2, 1>(zero, acc.zzz.c1));
+      const Fq2U s1 = quad_get2<0>(t), s2 = quad_get2<2>(t);   // < 1.05p
+      const Fq2U p = f2u_sub<2>(u2, u1);                        // U1 < 2p;  P < 3.15p <= 4p, N
+      const Fq2U r = f2u_sub<2>(s2, s1);                        // S1 < 2p;  R < 3.05p <= 4p, N
+      t = quad_f2u_mul_pair(role, acc.zz, o.zz, u_sub<2, 1>(zero, o.zz.c1), acc.zzz, o.zzz, u_sub<2, 1>(zero, o.zzz.c1));
+      const Fq2U zz12 = quad_get2<0>(t), zzz12 = quad_get2<2>(t);   // < 1.05p
+      // round 4: lane 0: P0 P0 + P1 (4p - P1);  lane 1: (2 P0) P1;  lane 2: (R0 + R1)(R0 - R1 + 4p);  lane 3: (2 R0) R1
+      {
+        const FqU f1 = quad_pick(role, p.c0, u_dbl(p.c0), u_carry(u_add(r.c0, r.c1)), u_dbl(r.c0));
+        const FqU f2 = quad_pick(role, p.c0, p.c1, u_sub<4, 1>(r.c0, r.c1), r.c1);
+        const FqU np1 = u_sub<4, 1>(zero, p.c1);
+        FqU f3, f4;
+        const bool first = role == 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          f3.l[i] = first ? p.c1.l[i] : 0u;
+          f4.l[i] = first ? np1.l[i] : 0u;
+        }
+        t = u_mul2(f1, f2, f3, f4);   // (the doubled operands have limbs < 2^30 and a zero second pair: u_mul's column bound)
+      }
+      const Fq2U pp = quad_get2<0>(t), rr = quad_get2<2>(t);       // PP < 1.2p, RR.c0 < 1.39p, RR.c1 < 1.2p
+      const FqU npp1 = u_sub<2, 1>(zero, pp.c1);
+      t = quad_f2u_mul_pair(role, p, pp, npp1, u1, pp, npp1);
+      const Fq2U ppp = quad_get2<0>(t), q = quad_get2<2>(t);       // PPP < 1.08p / 1.06p, Q < 1.03p
+      t = quad_f2u_mul_pair(role, zz12, pp, npp1, zzz12, ppp, u_sub<2, 1>(zero, ppp.c1));
+      const Fq2U zz3 = quad_get2<0>(t), zzz3 = quad_get2<2>(t);    // < 1.03p
+      Fq2U x3;
+      x3.c0 = u_sub<4, 3>(rr.c0, u_add(ppp.c0, u_dbl(q.c0)));      // PPP + 2Q < 3.2p <= 4p, limbs < 3 * 2^29;  X3 < 5.4p
+      x3.c1 = u_sub<4, 3>(rr.c1, u_add(ppp.c1, u_dbl(q.c1)));
+      const Fq2U d = f2u_sub<8>(q, x3);                            // < 9.1p
+      const FqU ns0 = u_sub<2, 1>(zero, s1.c0), ns1 = u_sub<2, 1>(zero, s1.c1), nd1 = u_sub<16, 1>(zero, d.c1);
+      // round 7: even lanes  R0 D0 + R1 (16p - D1) + (2p - S1_0) PPP0 + S1_1 PPP1;  odd lanes  R0 D1 + R1 D0 + (2p - S1_0) PPP1 + (2p - S1_1) PPP0
+      t = u_mul4(r.c0, pick2(odd, d.c0, d.c1), r.c1, pick2(odd, nd1, d.c0), ns0, pick2(odd, ppp.c0, ppp.c1), pick2(odd, s1.c1, ns1),
+                 pick2(odd, ppp.c1, ppp.c0));
+      (void)high;
+      res = XYZZU2{x3, quad_get2<0>(t), zz3, zzz3};
+      if (u_is_zero_lt2p(zz3.c0) && u_is_zero_lt2p(zz3.c1)) {
+        // P == 0: same x.  Same point -> double; opposite -> infinity (uniform over the quad; the doubling as in xyzzr_add)
+        res = XYZZU2::zero();
+        if (u_is_zero_lt8p(r.c0) && u_is_zero_lt8p(r.c1)) res = xyzzr2_from_std(xyzz_double(xyzzr_to_std(xyzzr_store(acc))));
+      }
+    }
+  }
+  return res;
+}
+#endif  // __HIPCC__
+
 // =================================================================================================
 // G2 Jacobian accumulator on U-form Fq2, for SCALAR MULTIPLICATION (batch_exp, the terms of the QAP sums): the G1 design above,
 // componentwise.  Fq2 squaring is (a0 + a1)(a0 - a1) + 2 a0 a1 u (two products), an Fq2 product two fused pairs (f2u_mul), and

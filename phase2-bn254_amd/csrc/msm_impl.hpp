@@ -1291,7 +1291,7 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XYZZ<F>* __
 
 // The same level with a QUAD of lanes per chunk (curveu.hpp: xyzzr_add_quad -- four lanes share the products of every addition):
 // for the levels that are left with too few chunks to fill the device, where a lane's 2L dependent additions are what the launch
-// lasts.  G1 only (the Fq2 addition has its own, different product graph).  Lanes 4t .. 4t+3 hold the same running sums.
+// lasts.  Lanes 4t .. 4t+3 hold the same running sums.
 template <class F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_reduce_level_quad_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, uint32_t L, uint32_t off,
                                                                    uint32_t W, XYZZ<F>* __restrict__ outA, XYZZ<F>* __restrict__ outS) {
@@ -1366,10 +1366,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   // ONE inlined xyzz_add for the pair and for every tree level (code size).  Lanes [s, 2s) publish, lanes [0, s)
   // consume; the regions written in consecutive rounds are disjoint from the ones still being read, so one
   // barrier per round.
-  // Round 4: once at most 64 additions are left in a round (G1), FOUR lanes share each of them (curveu.hpp: xyzzr_add_quad): the
+  // Round 4: once at most 64 additions are left in a round, FOUR lanes share each of them (curveu.hpp: xyzzr_add_quad): the
   // last seven rounds are a chain of seven additions on an otherwise idle workgroup, and a quad's addition is three products +
-  // one double product deep instead of fourteen.  J.quad == 0 keeps the one-lane rounds (the comparison; Fq2 always).
-  const uint32_t quad_from = (sizeof(F) == sizeof(Fq) && J.quad) ? 128u : 0u;   // the value of s after which the quads take over
+  // one double product deep instead of fourteen.  J.quad == 0 keeps the one-lane rounds (the comparison).
+  const uint32_t quad_from = J.quad ? 128u : 0u;   // the value of s after which the quads take over
   for (uint32_t s = 256;;) {
     xyzzr_add(acc, other);   // (its results keep the invariants its operands need: the running-sum levels chain it the same way)
     s >>= 1;
@@ -1378,7 +1378,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     __syncthreads();
     other = threadIdx.x < s ? sh[threadIdx.x + s] : U::zero();
   }
-  if constexpr (sizeof(F) == sizeof(Fq)) {
+  {
     if (quad_from) {
       // lanes 0 .. 127 hold the sums of the round s = 128; quad q = lane / 4 continues element q
       if (threadIdx.x < 128) sh[threadIdx.x] = acc;
@@ -2127,7 +2127,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   // MI355ZK_MSM_QUAD_MAX = the largest chunk count x windows a level may have to run four lanes per chunk)
   static const char* env_quad = std::getenv("MI355ZK_MSM_QUAD");
   static const char* env_quad_max = std::getenv("MI355ZK_MSM_QUAD_MAX");
-  const bool quad_tail = sizeof(F) == sizeof(Fq) && !(env_quad && env_quad[0] == '0');
+  const bool quad_tail = !(env_quad && env_quad[0] == '0');
   const uint32_t quad_max_chunks = env_quad_max ? (uint32_t)std::atoi(env_quad_max) : 65536u;
   // ---- bucket reduction, the copy back and the host join: once per base vector
   auto finish_set = [&](Jacobian<F>* result, bool last_set) -> int {
@@ -2145,7 +2145,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
         // a level with few chunks is a chain of 2L dependent additions per lane on a mostly idle device: four lanes per chunk
         // then (msm_reduce_level_quad_kernel, G1); a level that fills the device keeps the lane per chunk (less work in total)
         bool quad_level = false;
-        if constexpr (sizeof(F) == sizeof(Fq)) {
+        {
           if (quad_tail && threads <= quad_max_chunks) {
             quad_level = true;
             hipLaunchKernelGGL(msm_reduce_level_quad_kernel<F>, dim3((4 * threads + 255) / 256), dim3(256), 0, st, in, lvl_cnt[lv], 1u << lvl_logl[lv],

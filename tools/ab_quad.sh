@@ -6,3 +6,8 @@ for ln in 12 14 16 18 20 22; do
 done
 echo -n "quad_max 262144 2^20 "; MI355ZK_MSM_QUAD_MAX=262144 run 20
 echo -n "quad_max 16384 2^20 "; MI355ZK_MSM_QUAD_MAX=16384 run 20
+g2() { python tools/bench_g2.py --log-n $1 --iters 20 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('G2 2^%d' % d['g2_log_n'], d['ms'], 'ms', d['kernel_ms'], d['matches_closed_form'])"; }
+for ln in 12 16 18 20; do
+  echo -n "quad  "; g2 $ln
+  echo -n "lane  "; MI355ZK_MSM_QUAD=0 g2 $ln
+done
