@@ -1476,6 +1476,7 @@ std::vector<SmallWs*> g_tws;  // the pool: as many entries as there have been co
 // Pinned host buffers for the one copy that ends a multiexp (the window sums and the error words): into pageable memory the runtime
 // stages each copy (~20 us apiece at this size, twice per call); leased per call from a pool like the workspaces, grow-only.
 struct PinBuf {
+  int dev = -1;              // the device that was current when the buffer was allocated (a process may drive several)
   void* p = nullptr;
   size_t bytes = 0;
   bool busy = false;
@@ -1490,14 +1491,15 @@ struct PinLease {
     b->busy = false;
   }
 };
-int pin_acquire(size_t bytes, PinLease* lease) {
+int pin_acquire(int dev, size_t bytes, PinLease* lease) {
   PinBuf* pick = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (PinBuf* b : g_pin)
-      if (!b->busy && (pick == nullptr || b->bytes > pick->bytes)) pick = b;
+      if (!b->busy && b->dev == dev && (pick == nullptr || b->bytes > pick->bytes)) pick = b;
     if (pick == nullptr) {
       pick = new PinBuf();
+      pick->dev = dev;
       g_pin.push_back(pick);
     }
     pick->busy = true;
@@ -1580,6 +1582,7 @@ void ws_release_all() {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (PinBuf* b : g_pin) {
       if (b->busy) continue;
+      (void)hipSetDevice(b->dev);
       if (b->p) (void)hipHostFree(b->p);
       b->p = nullptr;
       b->bytes = 0;
@@ -2007,7 +2010,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     // chunk owns base base_offset + lo + i
     const uint32_t* dens = d_density ? d_density + (C.lo >> 5) : nullptr;
     ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
-    ZK_HIP(hipMemsetAsync(gcnt, 0, o_big_col - o_gcnt, st));  // gcnt and gcur
+    if (C.np > BIG_SEG) ZK_HIP(hipMemsetAsync(gcnt, 0, o_big_col - o_gcnt, st));  // gcnt and gcur (big bins only: see the bucket pass)
     // "msm_sort" spans the whole partition after the digits (scan + scatter + bucket + size order), as it did for the library sort
     prof_begin(slot_digits, st);
     static const bool fused_a = std::getenv("MI355ZK_PART_FUSED_A") != nullptr;  // (the one-kernel pass A, kept for the comparison in DESIGN.md)
@@ -2067,7 +2070,10 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       const uint32_t stage_cap = (uint32_t)want & ~3u;
       hipLaunchKernelGGL(msm_bucket_kernel, dim3(ncell), dim3(PART_THREADS), fixed + (size_t)stage_cap * 4, st, pairs, bin_start, out_start, G.nb, P,
                          stage_cap, first, last, vals_b);
-      // the big bins (none for uniform exponents up to 2^26 points: the surplus workgroups of these launches exit at once)
+      // the big bins (none for uniform exponents up to 2^26 points: the surplus workgroups of these launches exit at once).  A
+      // chunk with at most BIG_SEG elements per window cannot have one at all -- the bucket kernel took every bin -- so a short call
+      // does not pay for three idle launches (~5 us each of a 0.4-ms call at 2^10 .. 2^15 points)
+      if (C.np > BIG_SEG) {
       const uint32_t max_seg = (uint32_t)(2 * (C.m / BIG_SEG) + 2);
       hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
       // (small grids: when there is no big bin -- uniform exponents -- the launches only cost their workgroups' start-up, and the
@@ -2082,6 +2088,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       const int staged = place_staged <= PART_LDS_MAX ? 1 : 0;
       hipLaunchKernelGGL(msm_bigbin_place_kernel, dim3(staged ? place_grid : big_grid), dim3(PART_THREADS), staged ? place_staged : place_fixed, st, pairs, bin_start, out_start,
                          big_plan, big_col, big_seg, G.nb, P, staged, gcnt, gcur, first, last, vals_b);
+      }
     }
     ZK_HIP(hipGetLastError());
     prof_end(slot_bucket, st);
@@ -2141,6 +2148,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   const uint32_t quad_max_chunks = env_quad_max ? (uint32_t)std::atoi(env_quad_max) : 65536u;
   // ---- bucket reduction, the copy back and the host join: once per base vector
   auto finish_set = [&](Jacobian<F>* result, bool last_set) -> int {
+    const size_t back_bytes = (o_err - o_wsums) + 16;  // the window sums, their alignment padding, the two error words
+    PinLease pin;
+    if (int prc = pin_acquire(dev, back_bytes, &pin)) return prc;
     prof_begin(slot_red, st);
     {
       // wsums[w * n_out + k]:  k < n_levels: sum of A of level k;  k >= n_levels: bit sum j = k - n_levels of the last array
@@ -2258,10 +2268,9 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     prof_end(slot_red, st);
     if (checkpoint("reduce", plan[0])) return (int)ZK_ERR_DEVICE;
 
-    const size_t back_bytes = (o_err - o_wsums) + 16;  // the window sums, their alignment padding, the two error words
-    PinLease pin;
-    if (int prc = pin_acquire(back_bytes, &pin)) return prc;
     ZK_HIP(hipMemcpyAsync(pin.b->p, wsums, back_bytes, hipMemcpyDeviceToHost, st));
+    // (parking on an event recorded in front of the reduction and polling the stream from there was measured in round 4: 1.790 against
+    // 1.805 ms at 2^20, nothing at 2^12 .. 2^22 or for the prover's eight threads -- the runtime's own wait is not what a short call waits for)
     ZK_HIP(hipStreamSynchronize(st));
     const XYZZ<F>* h_wsums = reinterpret_cast<const XYZZ<F>*>(pin.b->p);
     unsigned long long h_errs[2];
