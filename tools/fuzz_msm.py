@@ -12,9 +12,14 @@ import phase2_bn254_amd as zk, inputs, oracle_lib as O, bn254_model as M
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-n", type=int, default=3000)
 ap.add_argument("--table", action="store_true", help="evaluate through TABLE MODE (MsmTable of the device-resident vector); MI355ZK_MSM_TABLE_C selects the table's window width")
+ap.add_argument("--devices", type=int, default=1, help="k > 1: the single-process multi-GPU mode over k logical devices (all GPU 0), calls cut from 64 exponents on")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-w = zk.Worker(0)
+if a.devices > 1:
+    os.environ["MI355ZK_MULTI_MIN_LOG"] = "6"
+    w = zk.Worker(devices=[0] * a.devices)
+else:
+    w = zk.Worker(0)
 pools = {g: inputs.bases_cpu(g, 24, seed=900 + g) for g in (1, 2)}
 for g in (1, 2):  # negatives of the first pool entries: P and -P collide in buckets
     G = O.G1 if g == 1 else O.G2
@@ -62,5 +67,5 @@ for case in range(a.cases):
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: g={g} n={n} pool={pool} scal={scal_kind} density={use_density} offset={offset} rc_o={rc_o}")
-print(f"fuzz{' (table mode)' if a.table else ''}: {a.cases - bad}/{a.cases} ok  (C={os.environ.get('MI355ZK_MSM_C')}, RADIX={os.environ.get('MI355ZK_MSM_RADIX')}, TABLE_C={os.environ.get('MI355ZK_MSM_TABLE_C')})")
+print(f"fuzz{' (table mode)' if a.table else ''}{' (%d devices)' % a.devices if a.devices > 1 else ''}: {a.cases - bad}/{a.cases} ok  (C={os.environ.get('MI355ZK_MSM_C')}, RADIX={os.environ.get('MI355ZK_MSM_RADIX')}, TABLE_C={os.environ.get('MI355ZK_MSM_TABLE_C')})")
 sys.exit(1 if bad else 0)

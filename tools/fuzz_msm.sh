@@ -18,4 +18,15 @@ for tc in "" 4 7 11 17 20; do
   [ -n "$tc" ] && export MI355ZK_MSM_TABLE_C=$tc
   timeout 600 python tools/fuzz_msm.py --table --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 || rc=1
 done
+# the single-process multi-GPU mode: the same cases cut into cells over 2 / 3 / 8 logical devices (plain and with streamed chunks inside the cells)
+unset MI355ZK_MSM_TABLE_C
+for k in 2 3 8; do
+  unset MI355ZK_HOST_CHUNK_TEST
+  timeout 600 python tools/fuzz_msm.py --devices $k --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 || rc=1
+  export MI355ZK_HOST_CHUNK_TEST=64
+  timeout 600 python tools/fuzz_msm.py --devices $k --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 | sed 's/^fuzz/fuzz (chunks of 64)/' || rc=1
+done
+unset MI355ZK_HOST_CHUNK_TEST
+# the one-lane reduce tails (MI355ZK_MSM_QUAD=0) against the same cases: the quad additions are the default above
+MI355ZK_MSM_QUAD=0 timeout 300 python tools/fuzz_msm.py --cases ${CASES:-30} --seed ${SEED:-7} 2>&1 | tail -3 | sed 's/^fuzz:/fuzz (one-lane tails):/' || rc=1
 exit $rc
