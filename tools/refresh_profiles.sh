@@ -42,4 +42,13 @@ for lm in 16 20 22; do timeout 300 python $R/tools/bench_prover.py --log-m $lm; 
 for ln in 16 20; do timeout 200 python $R/tools/bench_skew.py --log-n $ln --iters 10; done > $O/skew_small.json 2>/dev/null
 rm -rf /tmp/p_g; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_g -- $R/tools/bin/ubench_gather > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_g -name "*.db" | head -1) --pmc > $O/ubench_gather_fetch_size.txt
+# round 4
+cd $R
+bash tools/ab_quad.sh > $O/ab_quad.txt 2>/dev/null
+timeout 600 python tools/bench_multi_device.py --log-n 26 --devices 1 2 4 8 > $O/multi_device_2e26.json 2>/dev/null
+bash tools/ab_ntt_lds.sh > $O/ntt_configs.txt 2>/dev/null
+cd /tmp; rm -rf /tmp/p_he; timeout 600 rocprofv3 --kernel-trace -d /tmp/p_he -- python $R/tools/trace_host_entry.py > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_he -name "*.db" | head -1) --timeline 140 > $O/host_entry_timeline.txt
+rm -rf /tmp/p_t16; TRACE_LOG_N=16 timeout 300 rocprofv3 --kernel-trace -d /tmp/p_t16 -- python $R/tools/trace_one_msm.py > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/p_t16 -name "*.db" | head -1) --timeline 26 > $O/msm16_timeline.txt
 ls -la $O

@@ -4,7 +4,7 @@ profiles/ (round-tagged names) and rebuilds profiles/latest_pmc.json, which benc
 import json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh"); DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
 def put(src, dst, header=None):
     body = open(os.path.join(SRC, src)).read()
     with open(os.path.join(DST, f"{tag}_{dst}"), "w") as f:
@@ -40,10 +40,77 @@ def counter(path, kernel):
 fetch = counter("msm26_pmc_fetch.txt", "zk::msm_accumulate_kernel<Fq>"); write = counter("msm26_pmc_write.txt", "zk::msm_accumulate_kernel<Fq>")
 sys.path.insert(0, ROOT)
 import bench
-json.dump({"round": 3, "workload_log_n": 26, "n_gpus": 1, "kernel": "msm_accumulate_kernel<Fq>", "FETCH_SIZE_KB_per_launch": fetch,
+json.dump({"round": int(tag[1:3]), "workload_log_n": 26, "n_gpus": 1, "kernel": "msm_accumulate_kernel<Fq>", "FETCH_SIZE_KB_per_launch": fetch,
            "WRITE_SIZE_KB_per_launch": write, "hbm_bytes_per_launch": int((fetch + write) * 1024), "kernel_sources_sha": bench.kernel_sources_sha(),
            "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{tag}_msm26_pmc_hbm.txt); bytes = (FETCH_SIZE + WRITE_SIZE)*1024: "
                   "the kernel reads through 64-byte base gathers and 16-byte index-list loads, which FETCH_SIZE tallies exactly (one 64-byte "
                   "request each, profiles/r02_ubench_gather_fetch_calibration.txt) -- the guide's x2 correction is for 128-byte streaming requests"},
           open(os.path.join(DST, "latest_pmc.json"), "w"), indent=1)
 print(open(os.path.join(DST, "latest_pmc.json")).read())
+
+# ---- round 4 additions
+for src, dst, hdr in (("ab_quad.txt", "ab_quad.txt", "# bash tools/ab_quad.sh: the reduce tails on quad additions (default) against one lane per addition (MI355ZK_MSM_QUAD=0), same box, same process order;\n# bench.py --log-n L --steps 30 --warmup 10 (ms per call, msm_reduce / msm_accumulate by HIP events, result limb) and tools/bench_g2.py\n"),
+                      ("multi_device_2e26.json", "multi_device_2e26.json", None),
+                      ("ntt_configs.txt", "ntt_configs.txt", "# bash tools/ab_ntt_lds.sh: tools/bench_ntt.py (warmed up, no per-pass events in the timed loop): (ms per transform, ntt_pass_kernel avg ms, passes)\n"),
+                      ("host_entry_timeline.txt", "host_entry_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_host_entry.py: streamed host-buffer G1 multiexps at 2^26 over a pinned vector (page-locked exponents, 5 chunks), last 140 dispatches\n"),
+                      ("msm16_timeline.txt", "msm16_timeline.txt", "# rocprofv3 --kernel-trace -- TRACE_LOG_N=16 python tools/trace_one_msm.py: the launches of ONE 2^16-point G1 multiexp\n")):
+    if os.path.exists(os.path.join(SRC, src)): put(src, dst, hdr)
+
+# ---- profiles/README.md is GENERATED from the files it describes (it drifted when it was written by hand: VERDICT r3 weak #10)
+def J(name):
+    try:
+        txt = open(os.path.join(DST, f"{tag}_{name}")).read().strip()
+        return json.loads(txt) if txt.startswith("{") and txt.count("\n{") == 0 else [json.loads(l) for l in txt.splitlines() if l.startswith("{")]
+    except (OSError, ValueError):
+        return None
+def stat(kernel, path=f"{tag}_msm26_kernel_stats.txt", col=3):
+    try:
+        for l in open(os.path.join(DST, path)):
+            if l.startswith(kernel + " "): return float(l.split()[col])
+    except OSError:
+        pass
+    return None
+rows = []
+b = J("bench_n1.json")
+if b:
+    k = b["roofline"]["kernel_ms"]; sec = b.get("secondary", {}); h = b.get("incl_scalar_h2d") or {}
+    rows.append((f"`{tag}_bench_n1.json`", "`python bench.py`", f"2^26 G1 MSM: `value` **{b['value']:.0f} Mscalar-mul/s** ({b['ms_per_step']:.2f} ms; HIP events: accumulate {k['msm_accumulate']:.2f}, digits {k['msm_digits']:.2f}, partition {k['msm_sort']:.2f}, reduce {k['msm_reduce']:.2f} ms); `value_incl_scalar_h2d` **{b['value_incl_scalar_h2d']:.0f}** ({h.get('ms_per_step')} ms; pageable {h.get('pageable_exponents_ms')}, page-locked {h.get('page_locked_exponents_ms')}, first call {h.get('first_call_incl_bases_h2d_ms')}); roofline frac {b['roofline']['frac']}; CPU: {b['cpu_baseline']['value']} M/s on {b['cpu_baseline']['cores']} threads"))
+    n = sec.get("fr_ntt_2e20"); g1 = sec.get("g1_msm_2e20"); g2 = sec.get("g2_msm_2e20"); c = sec.get("contribute_2e20")
+    if n and g1 and g2 and c:
+        rows.append(("  `secondary`", "same run", f"2^20 Fr NTT fft / ifft / coset_fft {n['fft']['ms']} / {n['ifft']['ms']} / {n['coset_fft']['ms']} ms (pass {n['roofline']['pass_ms']} ms = {n['roofline']['achieved']} GB/s algorithmic); 2^20 G1 multiexp {g1['ms']} ms = {g1['value']} M/s (table mode {g1['table_mode']['ms']} ms = {g1['table_mode']['value']}); 2^20 G2 {g2['ms']} ms = {g2['value']} M/s (table mode {g2['table_mode']['ms']} = {g2['table_mode']['value']}); contribute 2^20 {c['ms']} ms = {c['value']} Mpoint/s"))
+b20 = J("bench_2e20.json")
+if b20: rows.append((f"`{tag}_bench_2e20.json`, `{tag}_msm20_timeline.txt`, `{tag}_msm16_timeline.txt`", "`bench.py --log-n 20 --no-secondary`; `rocprofv3 --kernel-trace -- tools/trace_one_msm.py`", f"BASELINE config 2: {b20['ms_per_step']} ms = {b20['value']:.0f} M/s (kernels: {b20['roofline']['kernel_ms']}); launch-by-launch timelines of one 2^20 and one 2^16 call"))
+acc = stat("zk::msm_accumulate_kernel<Fq>")
+if acc: rows.append((f"`{tag}_msm26_kernel_stats.txt`, `{tag}_msm26_pmc_hbm.txt`, `{tag}_msm26_accumulate_sq_pmc.txt`, `latest_pmc.json`", "`rocprofv3 --kernel-trace` / `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc SQ_*` (separate passes) `-- python bench.py ...`", f"`msm_accumulate_kernel<Fq>` avg **{acc / 1e3:.2f} ms** per launch; HBM traffic {(fetch + write) * 1024 / 1e9:.1f} GB per launch = {(fetch + write) * 1024 / (96 * 2**26):.1f} x the algorithmic 6.44 GB (FETCH {fetch * 1024 / 1e9:.1f} + WRITE {write * 1024 / 1e9:.1f})"))
+nt = J("ntt_16_20_24.json")
+if nt: rows.append((f"`{tag}_ntt20*.{{json,txt}}`, `{tag}_ntt_16_20_24.json`, `{tag}_ntt_other_sizes.json`, `{tag}_ntt_configs.txt`", "`tools/bench_ntt.py` (warm-up, no events in the timed loop), under `--kernel-trace` / `--pmc SQ_*`; `tools/ab_ntt_lds.sh`", "; ".join(f"2^{x['log_n']} fft {x['fft']['ms']} / ifft {x['ifft']['ms']} ms" for x in nt)))
+he = J("host_entry.json")
+if he: rows.append((f"`{tag}_host_entry.json`, `{tag}_host_entry_timeline.txt`", "`tools/bench_host_entry.py --log-n 20 24 26`; `rocprofv3 --kernel-trace -- tools/trace_host_entry.py`", "host-buffer entry point (streamed upload, pinned bases): " + json.dumps(he)[:600]))
+sc = J("shard_cells_2e26.json")
+if sc: rows.append((f"`{tag}_shard_cells_2e26.json`", "`tools/bench_shard_cells.py`", f"one rank's cell of an N-GPU run timed alone (single GPU {sc['one_gpu_ms']} ms): " + ", ".join(f"N={w}: {sc['n%d' % w]['cell_ms']} ms = {100 * sc['n%d' % w]['efficiency']:.0f} % of linear against that same-box time" for w in (2, 4, 8))))
+md = J("multi_device_2e26.json")
+if md: rows.append((f"`{tag}_multi_device_2e26.json`", "`tools/bench_multi_device.py`", f"single-process multi-GPU mode of the C ABI on {md['physical_gpus']} physical GPU(s) (repeated ids = logical devices sharing it: correctness / overhead, not scaling): " + ", ".join(f"{len(r['devices'])} cells {r['ms_per_call']} ms" for r in md["runs"])))
+pr = J("prover.json")
+if pr: rows.append((f"`{tag}_prover.json`", "`tools/bench_prover.py --log-m 16 / 20 / 22`", "; ".join(f"2^{x['log_m']}: sequential {x['sequential_ms']} ms, eight threads {x['eight_threads_ms']}, with tables {x['eight_threads_tables_ms']}" for x in pr)))
+for name, cmd, what in (("ab_quad.txt", "`tools/ab_quad.sh`", "quad additions in the reduce tails against one lane per addition, same box (G1 2^12 .. 2^22, G2 2^12 .. 2^20)"),
+                        ("table_mode.json", "`tools/bench_table.py`", "table mode against the plain call, same process"),
+                        ("g2_2e20.json", "`tools/bench_g2.py`", "2^20 G2 multiexp with its closed-form check"),
+                        ("next_rows_2e20.json", "`tools/bench_next_rows.py --log-n 20`", "SURVEY 8(f) rows 1-4 at 2^20"),
+                        ("contribute_2e20.json", "`tools/bench_contribute.py`", "BASELINE config 5"),
+                        ("skew_2e26.json", "`tools/bench_skew.py --log-n 26`", "prover-like exponents at 2^26"), ("skew_16_20.json", "`tools/bench_skew.py`", "prover-like exponents at 2^16 / 2^20"),
+                        ("ubench_valu.txt", "`tools/bin/ubench_valu`", "issue cost of the VALU instructions the kernels are made of"),
+                        ("ubench_fieldmul.txt", "`tools/bin/ubench_fieldmul`", "field product rates"), ("ubench_wave_bucket.txt", "`tools/bin/ubench_wave_bucket`", "lane per bucket vs wave per bucket"),
+                        ("bench_n1_tau.json", "`python bench.py --bases tau`", "the headline on tau-table bases")):
+    if os.path.exists(os.path.join(DST, f"{tag}_{name}")): rows.append((f"`{tag}_{name}`", cmd, what))
+hand = [("`r04_exp_cu_mask.txt`", "`tools/exp_cu_mask.py`", "CU-masked side stream beside the accumulation: measured, rejected (DESIGN 6)"),
+        ("`r04_small_n_sweep.txt`", "`tools/sweep_small_n.sh`", "every window width at 2^10 .. 2^20 and the reduce schedule after the quad additions: the measured table did not move"),
+        ("`r04_fuzz_msm.txt`", "`CASES=40 SEED=11 tools/fuzz_msm.sh`", "1240 differential fuzz cases against the oracle (window layouts, streamed chunks, table mode, 2 / 3 / 8 logical devices, one-lane tails): 0 mismatches"),
+        ("`r04_host_entry_timeline.txt`, `r04_multi_device_2e26.json`", "mid-round copies of the files above", "kept: DESIGN cites them")]
+with open(os.path.join(DST, "README.md"), "w") as f:
+    f.write("# profiles/ — rocprofv3 evidence (MI355X, gfx950, ROCm 7.2)\n\n"
+            "GENERATED by `tools/refresh_profiles_post.py` from the files it lists (after `gpurun -- bash tools/refresh_profiles.sh`): every number below is read\n"
+            "from the file in the first column.  rocprofv3 in this image writes a rocpd SQLite database; the text files are per-kernel summaries made with\n"
+            "`tools/rocpd_summary.py` / `tools/pmc_kernel.py`; PMC passes are separate runs, one counter group per pass (`/opt/skills/guides/MI355X_MICROARCH.md`).\n"
+            "Rounds 1-3: `HISTORY.md`.\n\n| file | command | what it shows |\n|---|---|---|\n")
+    for r in rows + hand: f.write("| " + " | ".join(r) + " |\n")
+print(open(os.path.join(DST, "README.md")).read()[:3000])
