@@ -21,7 +21,7 @@ put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
     "# batch_exp_kernel = synthetic-input generation (outside the timed region); every msm_* launch is a full-size step\n"
     "# (1 warm-up + 3 timed + 2 of the linearity check); msm_accumulate_kernel is the dominant kernel of a step\n")
 put("ntt20_pass_sq_pmc.txt", "ntt20_pass_sq_pmc.txt", "# ntt_pass_kernel, 2^20 elements (2 passes of 1024-point rows, 512 tiles of 2 x 1024, two 512-lane workgroups per CU), per dispatch,\n# rocprofv3 --pmc (two passes of 8 / 7 counters), tools/bench_ntt.py --log-n 20; SQ cycle counters tick once per 4 clocks\n")
-put("msm20_timeline.txt", "msm20_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_one_msm.py: the launches of ONE 2^20-point G1 multiexp in order (start offset, duration incl. the\n# profiler's serialisation, gap to the previous kernel); the host join (0.14 ms) follows the last copy\n")
+put("msm20_timeline.txt", "msm20_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_one_msm.py: the launches of ONE 2^20-point G1 multiexp in order (start offset, duration incl. the\n# profiler's serialisation, gap to the previous kernel); the host join (~0.09 ms) follows the last copy\n")
 put("ntt20_kernel_stats.txt", "ntt20_kernel_stats.txt", "# rocprofv3 --kernel-trace -- python tools/bench_ntt.py --check   (MI355X, 2^20 Fr NTT, 20 iterations x 4 ops)\n")
 put("msm26_accumulate_sq_pmc.txt", "msm26_accumulate_sq_pmc.txt", "# rocprofv3 --pmc SQ_* (one pass, 8 counters) on msm_accumulate_kernel<Fq>, 2^26 points, MI355X\n")
 with open(os.path.join(DST, f"{tag}_msm26_pmc_hbm.txt"), "w") as f:
