@@ -126,8 +126,23 @@ def test_non_canonical_exponent_is_bad_arguments(zk, worker):
 
 
 def test_empty_input_is_identity(zk, worker):
+    """No exponent evaluated: the reference's Projective::zero() = (0, 1, 0) in Montgomery form (ec.rs:229-235), from the host-buffer
+    entry, the device-resident entry and -- Eof at index 0 -- a call whose bases ran out before the first exponent."""
+    import torch
+
+    one = np.array(O.G1.from_affine(inputs.G1_GEN_RAW)[8:12], dtype=np.uint64)   # Z of an affine point lifted to Jacobian = Fq::one()
+    zero = np.concatenate([np.zeros(4, np.uint64), one, np.zeros(4, np.uint64)])
     got = zk.multiexp(worker, (np.zeros((0, 8), np.uint64), 0), zk.FullDensity(), np.zeros((0, 4), np.uint64)).wait()
-    assert not got[8:12].any()  # Z == 0
+    assert np.array_equal(got, zero)
+    d = torch.zeros((4, 8), dtype=torch.int64, device="cuda")
+    got = zk.multiexp(worker, (d, 0), zk.FullDensity(), torch.zeros((0, 4), dtype=torch.int64, device="cuda")).wait()
+    assert np.array_equal(got, zero)
+    lib = zk.lib.load()
+    out = np.full(12, 7, dtype=np.uint64)
+    sc = inputs.random_scalars(5, seed=3)
+    bases = inputs.bases_cpu(1, 2, seed=4)
+    rc = lib.mi355zk_bn254_g1_msm(bases.ctypes.data_as(C.c_void_p), 2, 2, sc.ctypes.data_as(C.c_void_p), 5, None, 0, out.ctypes.data_as(C.c_void_p))
+    assert rc == zk.lib.ERR_UNEXPECTED_EOF and lib.mi355zk_last_error_index() == 0 and np.array_equal(out, zero)
 
 
 def test_skewed_scalars_one_heavy_bucket(zk, worker):

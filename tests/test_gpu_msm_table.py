@@ -286,3 +286,32 @@ def test_table_mode_closed_form_and_additivity_at_size(zk, worker, group, log_n)
     got = zk.multiexp(worker, (t, 7), dm, s[:m].contiguous()).wait()
     ref = zk.multiexp(worker, (b, 7), dm, s[:m].contiguous()).wait()
     assert np.array_equal(G.to_affine(got), G.to_affine(ref))
+
+
+def test_a_handful_of_exponents_over_a_long_pinned_vector_stays_plain(zk, worker):
+    """The prover's input multiexps: a few exponents over the 2^k-point a / b queries of its Parameters.  A table's window width comes
+    from the VECTOR's length, so table mode would zero and reduce 2^19 buckets for a handful of points: host-buffer calls with fewer
+    than n_bases / 8 exponents stay on the plain path (which picks its window from n) even when the vector is pinned with tables --
+    and build no table on their account.  Same result either way."""
+    n_bases = 1 << 14
+    bases = inputs.bases_progression_cpu(1, n_bases, seed=8801)
+    lib = zk.lib.load()
+    zk.pin_bases(bases, tables=True)
+    try:
+        few = inputs.random_scalars(40, seed=8802)
+        rc, want = O.G1.multiexp(bases, few, threads=2)
+        assert rc == 0
+        for _ in range(3):
+            assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (bases, 0), zk.FullDensity(), few).wait()), O.G1.to_affine(want))
+        dev_b, tab_b = C.c_size_t(), C.c_size_t()
+        assert lib.mi355zk_bases_cache_info(bases.ctypes.data_as(C.c_void_p), C.byref(dev_b), C.byref(tab_b)) == 1
+        assert dev_b.value == n_bases * 64 and tab_b.value == 0
+        many = inputs.random_scalars(n_bases, seed=8803)
+        rc, want = O.G1.multiexp(bases, many, threads=8)
+        assert rc == 0
+        for _ in range(2):
+            assert np.array_equal(O.G1.to_affine(zk.multiexp(worker, (bases, 0), zk.FullDensity(), many).wait()), O.G1.to_affine(want))
+        assert lib.mi355zk_bases_cache_info(bases.ctypes.data_as(C.c_void_p), C.byref(dev_b), C.byref(tab_b)) == 1
+        assert tab_b.value > dev_b.value    # the full-length call built and used the table
+    finally:
+        zk.unpin_bases(bases)
