@@ -1829,7 +1829,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   uint32_t lvl_cnt[MSM_MAX_LEVELS + 1], lvl_chunks[MSM_MAX_LEVELS + 1], lvl_logl[MSM_MAX_LEVELS + 1], n_levels = 0;
   uint64_t total_chunks = 1;
   uint32_t final_cnt = G.nb;
-  static const char* env_fmax = std::getenv("MI355ZK_MSM_FINAL_MAX");
+  const char* env_fmax = std::getenv("MI355ZK_MSM_FINAL_MAX");
   const uint32_t final_max = env_fmax && std::atoi(env_fmax) >= 64 ? (uint32_t)std::atoi(env_fmax) : MSM_FINAL_MAX;
   // 2-D TAIL (round 3): once at most 2^17 elements are left over all windows (and at most 2^18 per window), the weighted sum of the
   // last array S is finished in TWO tree launches instead of further levels and a bit decomposition of what they leave:
@@ -1844,7 +1844,17 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     // 16 windows x 8192 elements as 64 x 128 made the 2^20 reduce SLOWER, 0.40 -> 0.71 ms; G1 only: a G2 tree round costs three G1
     // rounds and the two launches gained nothing over the levels, 1.36 -> 1.38 ms)
     if (!no_tail2d && sizeof(F) == sizeof(Fq) && (uint64_t)final_cnt * WL <= (1ull << 17) && final_cnt >= (1u << 15) && final_cnt <= (1u << 18)) break;
-    const uint32_t logl = (uint64_t)final_cnt * WL >= (1ull << 20) ? 3 : 2;
+    uint32_t logl = (uint64_t)final_cnt * WL >= (1ull << 20) ? 3 : 2;
+    {
+      // (experiments: MI355ZK_MSM_LOGL = "3,2,2" forces the chunk length 2^k of the first levels -- read per call)
+      const char* env_l = std::getenv("MI355ZK_MSM_LOGL");
+      if (env_l) {
+        uint32_t k = 0;
+        const char* q = env_l;
+        while (k < n_levels && *q) { if (*q == ',') ++k; ++q; }
+        if (k == n_levels && *q >= '1' && *q <= '5') logl = (uint32_t)(*q - '0');
+      }
+    }
     lvl_cnt[n_levels] = final_cnt;
     lvl_logl[n_levels] = logl;
     lvl_chunks[n_levels] = (final_cnt + (1u << logl) - 1) >> logl;
