@@ -292,6 +292,10 @@ __device__ __forceinline__ FpU<PR> quad_pick(uint32_t role, const FpU<PR>& a0, c
   }
   return r;
 }
+template <int K, class PR>
+__device__ __forceinline__ XYZZU<PR> quad_fetch(const XYZZU<PR>& a) {   // the accumulator lane K of the quad holds, in all four lanes
+  return XYZZU<PR>{quad_get<K>(a.x), quad_get<K>(a.y), quad_get<K>(a.zz), quad_get<K>(a.zzz)};
+}
 template <class PR>
 __device__ __forceinline__ XYZZU<PR> xyzzr_add_quad(const XYZZU<PR> acc, const XYZZU<PR> o, uint32_t role) {   // by value in, by value out, ONE exit (hipcc keeps by-reference / multiply-returned sums in scratch)
   XYZZU<PR> res = acc;
@@ -704,6 +708,11 @@ __device__ __forceinline__ FqU quad_f2u_mul_pair(uint32_t role, const Fq2U& a1, 
   const FqU a0 = pick2(high, a1.c0, a2.c0), a1c = pick2(high, a1.c1, a2.c1);
   const FqU b0 = pick2(high, b1.c0, b2.c0), b1c = pick2(high, b1.c1, b2.c1), nb = pick2(high, nb1, nb2);
   return u_mul2(a0, pick2(odd, b0, b1c), a1c, pick2(odd, nb, b0));   // c0 = a0 b0 + a1 (-b1);  c1 = a0 b1 + a1 b0
+}
+template <int K>
+__device__ __forceinline__ XYZZU2 quad_fetch(const XYZZU2& a) {
+  return XYZZU2{Fq2U{quad_get<K>(a.x.c0), quad_get<K>(a.x.c1)}, Fq2U{quad_get<K>(a.y.c0), quad_get<K>(a.y.c1)},
+                Fq2U{quad_get<K>(a.zz.c0), quad_get<K>(a.zz.c1)}, Fq2U{quad_get<K>(a.zzz.c0), quad_get<K>(a.zzz.c1)}};
 }
 __device__ __forceinline__ XYZZU2 xyzzr_add_quad(const XYZZU2 acc, const XYZZU2 o, uint32_t role) {
   XYZZU2 res = acc;

@@ -1265,6 +1265,32 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   store_vec(buckets + b, xyzzu_to_r(accumulate_run<F, A4>(acc, bases, vals, j, e, 1, skip_zero != 0, err_base)));
 }
 
+// 4c. SHORT calls: the launch above lasts as long as its LONGEST bucket -- a lane adds a point every ~8 us however idle the device is,
+//     and among 2^18 buckets of 4 points on average some hold 14 (2^16 points: 139 us of accumulation where the additions themselves
+//     are 80 us of the device's time).  Buckets longer than `split_t` (and not heavy) are therefore taken out of the lane-per-bucket
+//     launch and walked by a QUAD of lanes each: lane r of the quad adds entries r, r + 4, ... (its own accumulator), the four partial
+//     sums are brought to all four lanes by DPP and joined by three quad additions (curveu.hpp: xyzzr_add_quad).  A 14-entry bucket is
+//     then 4 mixed additions + the join instead of 14.  The buckets are order[0 .. hb) (size order): the main kernel skips them with
+//     its `heavy` test set to split_t.  First chunk / unchunked calls only (no carried record).
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_accumulate_split_kernel(
+    const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+    const uint32_t* __restrict__ order, uint32_t split_t, uint32_t heavy, uint32_t hb, XYZZ<F>* __restrict__ buckets, int skip_zero,
+    unsigned long long* __restrict__ err_base) {
+  using U = typename BucketAcc<F>::type;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, i = gt >> 2, role = gt & 3u;
+  if (i >= hb) return;                                 // (whole quads leave: i is the same for the four lanes)
+  const uint32_t b = order[i];
+  const uint32_t j = first[b], e = last[b];
+  if (e - j <= split_t || e - j > heavy) return;       // the lane-per-bucket launch / the segment-parallel path has it
+  U part = xyzzr_load(XYZZ<F>::zero());
+  if (j + role < e) part = xyzzr_load(xyzzu_to_r(accumulate_run<F, false>(U::zero(), bases, vals, j + role, e, 4, skip_zero != 0, err_base)));
+  // (split_t >= 4: every lane has at least one entry; the test above is for safety)
+  const U p0 = quad_fetch<0>(part), p1 = quad_fetch<1>(part), p2 = quad_fetch<2>(part), p3 = quad_fetch<3>(part);
+  const U sum = xyzzr_add_quad(xyzzr_add_quad(p0, p1, role), xyzzr_add_quad(p2, p3, role), role);
+  if (role == 0) store_vec(buckets + b, xyzzr_store(sum));
+}
+
 // 5. bucket reduction  T_w = sum_{k=1..nb} k * B_k  per window, without scalar multiplications:
 //    split the index x = ch*L + y:   sum_x (x+off) B[x] = sum_ch A[ch] + L * sum_ch ch * S[ch]
 //    with A[ch] = sum_y (y+off) B[ch*L+y] (running sums) and S[ch] = sum_y B[ch*L+y]; the second term
@@ -1881,6 +1907,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     uint64_t lo, n, m, np;  // np: length of the array the partition sees (table mode: all key planes as one)
     PartGeom P;
     uint32_t ncell, heavy, heavy_seg, hb, max_items;
+    uint32_t split_t, split_hb;   // short calls: buckets longer than split_t take the quad-per-bucket launch (0: none)
   };
   std::vector<ChunkPlan> plan(n_chunks);
   uint64_t keys_cap = 0, tile_hist_b = 0, tile_off_b = 0, csum_b = 0;
@@ -1924,6 +1951,29 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     C.max_items = (uint32_t)(C.m / C.heavy_seg) + C.hb;  // every heavy bucket adds at most one partial segment
     hb_max = std::max(hb_max, C.hb);
     items_max = std::max(items_max, C.max_items);
+    // Quad-per-bucket launch for the long buckets of a SHORT, unchunked call (msm_accumulate_split_kernel): while the lane-per-bucket
+    // launch fits the device about once (<= 2^18 bucket lanes), its duration is its longest bucket.  Threshold: the mean length plus
+    // one standard deviation of a Poisson count (~10 % of the buckets of uniform exponents), at least 4 (a lane per entry of a quad).
+    // The two launches run one after the other (same stream): what is gained is the difference between the long buckets' chains.
+    // env MI355ZK_MSM_SPLIT=0 disables, =t forces the threshold.
+    C.split_t = 0;
+    C.split_hb = 0;
+    {
+      const char* env_split = std::getenv("MI355ZK_MSM_SPLIT");
+      const bool off = env_split && env_split[0] == '0' && env_split[1] == 0;
+      // (measured, tools/ab_split.sh: G1 2^10 .. 2^14 points -4 .. -9 % per call, nothing at 2^15 .. 2^17, +3 .. 5 % from 2^18 on; G2: -2 % at 2^12, +2 % at 2^16)
+      if (!off && n_chunks == 1 && n_buckets <= (sizeof(F) == sizeof(Fq) ? 1u << 18 : 1u << 16) && !tmode) {
+        const double mean = (double)C.m / n_buckets;
+        uint32_t t = (uint32_t)std::ceil(mean + std::sqrt(mean + 1.0));
+        if (env_split && std::atoi(env_split) > 0) t = (uint32_t)std::atoi(env_split);
+        if (t < 4) t = 4;
+        if (t < C.heavy) {
+          C.split_t = t;
+          const uint64_t cap = C.m / (t + 1) + 1;    // buckets longer than t
+          C.split_hb = (uint32_t)(cap < n_buckets ? cap : n_buckets);
+        }
+      }
+    }
   }
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
@@ -2128,19 +2178,28 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     prof_begin(slot_acc, st);
     static const bool a4 = std::getenv("MI355ZK_ACC_NARROW") == nullptr;  // (the 4-byte index walk, kept for the traffic comparison in profiles/)
     const dim3 grid((n_buckets + 255) / 256), block(256);
+    // the lane-per-bucket launch leaves out what another launch does: the heavy buckets (> C.heavy, among order[0 .. C.hb)), and for a
+    // short call also the long ones (> C.split_t, among order[0 .. C.split_hb)), which a quad each walks
+    const bool split = C.split_t != 0 && !carry;
+    const uint32_t skip_len = split ? C.split_t : C.heavy, skip_hb = split ? std::max(C.split_hb, C.hb) : C.hb;
+    if (split) {
+      hipLaunchKernelGGL(msm_accumulate_split_kernel<F>, dim3((4 * C.split_hb + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order,
+                         C.split_t, C.heavy, C.split_hb, buckets, dense ? 1 : 0, d_err);
+      ZK_HIP(hipGetLastError());
+    }
     if (carry) {
       if (a4)
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, true, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets,
                            buckets, dense ? 1 : 0, d_err);
       else
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets,
                            buckets, dense ? 1 : 0, d_err);
     } else {
       if (a4)
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, true, false>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true, false>), grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets,
                            buckets, dense ? 1 : 0, d_err);
       else
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, false>), grid, block, 0, st, bases_set, vals_b, first, last, order, C.heavy, C.hb, n_buckets,
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, false>), grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets,
                            buckets, dense ? 1 : 0, d_err);
     }
     ZK_HIP(hipGetLastError());
