@@ -7,6 +7,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1609,8 +1610,14 @@ int msm_host_multi(const std::vector<int>& devs, const uint8_t* bases, size_t n_
   {
     DeviceGuard guard;
     std::vector<std::thread> th;
-    for (size_t i = 1; i < cells.size(); ++i) th.emplace_back([&, i] { run_cell(cells[i]); });
+    size_t started = 1;
+    try {
+      for (; started < cells.size(); ++started) th.emplace_back([&, started] { run_cell(cells[started]); });
+    } catch (const std::exception&) {
+      // (no more host threads to be had: the cells that did not get one run here, one after the other -- nothing is thrown across the C ABI)
+    }
     if (!cells.empty()) run_cell(cells[0]);
+    for (size_t i = started; i < cells.size(); ++i) run_cell(cells[i]);
     for (auto& t : th) t.join();
   }
   // ---- the join.  Device failures first, then a non-canonical exponent (bad arguments: the single-device call reports it before
