@@ -303,6 +303,7 @@ __host__ __device__ __forceinline__ void msm_scalar_digits(const uint32_t s[9], 
 //              written out coalesced.  Bins that outgrow registers / LDS (skewed scalars) take a two-read path.
 //    HBM traffic per element: 4 B (keys) written + read, 8 B (pairs) written + read, 4 B (indices) written = 28 B, against
 //    3 x 16 B for a three-pass pair sort.
+constexpr uint32_t MSM_SIZE_BINS = 4096;   // bins of the counting sort that orders the buckets by size (3b)
 constexpr uint32_t PART_THREADS = 1024;
 constexpr uint32_t PART_MAX_ST = 16384;       // super-tile: scalars per pass-A histogram dump = elements per pass-B workgroup
 constexpr uint32_t PART_MAX_EB = PART_MAX_ST / PART_THREADS;
@@ -788,6 +789,55 @@ __global__ void __launch_bounds__(PART_THREADS) msm_bigbin_plan_kernel(const uin
   }
 }
 
+// The four scans above in ONE single-workgroup launch, for SHORT calls (n_st * ncell small: a 2^16-point call has 16 super-tiles x ~2000
+// columns): a call of 0.4 - 0.6 ms pays ~5 us for every launch, however little it does.  Also clears the size histogram of the
+// bucket order (one memset less) and writes the (empty-or-not) big-bin plan.
+__global__ void __launch_bounds__(PART_THREADS) msm_scan_small_kernel(const uint16_t* __restrict__ tile_hist, PartGeom P, uint32_t ncell, uint32_t nb,
+                                                                      uint32_t* __restrict__ col_total, uint32_t* __restrict__ bin_start,
+                                                                      uint32_t* __restrict__ out_start, uint32_t* __restrict__ tile_off,
+                                                                      uint32_t* __restrict__ size_hist, uint32_t* __restrict__ big_col,
+                                                                      uint32_t* __restrict__ big_seg_off, BigPlan* __restrict__ plan) {
+  __shared__ uint32_t scratch[32];
+  const uint32_t stride = (ncell + 1u) & ~1u;
+  for (uint32_t t = threadIdx.x; t < MSM_SIZE_BINS; t += PART_THREADS) size_hist[t] = 0;
+  for (uint32_t col = threadIdx.x; col < ncell; col += PART_THREADS) {
+    uint32_t s = 0;
+    for (uint32_t r = 0; r < P.n_st; ++r) s += tile_hist[(uint64_t)r * stride + col];
+    col_total[col] = s;
+  }
+  __syncthreads();   // (global writes of this workgroup are visible to it after the barrier)
+  auto padded = [&](uint32_t col) {
+    const uint32_t bin = col % P.nbin;
+    const uint32_t nf = ((bin + 1) << P.lo_bits) <= nb ? 1u << P.lo_bits : nb - (bin << P.lo_bits);
+    return (col_total[col] + 3u * nf + 3u) & ~3u;
+  };
+  const uint32_t t0 = block_scan_long(ncell, scratch, [&](uint32_t c) { return col_total[c]; }, [&](uint32_t c, uint32_t ex) { bin_start[c] = ex; });
+  const uint32_t t1 = block_scan_long(ncell, scratch, padded, [&](uint32_t c, uint32_t ex) { out_start[c] = ex; });
+  if (threadIdx.x == 0) {
+    bin_start[ncell] = t0;
+    out_start[ncell] = t1;
+  }
+  __syncthreads();
+  for (uint32_t col = threadIdx.x; col < ncell; col += PART_THREADS) {
+    uint32_t run = bin_start[col];
+    for (uint32_t r = 0; r < P.n_st; ++r) {
+      tile_off[(uint64_t)r * ncell + col] = run;
+      run += tile_hist[(uint64_t)r * stride + col];
+    }
+  }
+  // the big-bin plan (msm_bigbin_plan_kernel)
+  auto cnt_of = [&](uint32_t col) { return bin_start[col + 1] - bin_start[col]; };
+  const uint32_t n_big = block_scan_long(ncell, scratch, [&](uint32_t c) { return cnt_of(c) > BIG_SEG ? 1u : 0u; },
+                                         [&](uint32_t c, uint32_t ex) { if (cnt_of(c) > BIG_SEG) big_col[ex] = c; });
+  __syncthreads();
+  const uint32_t n_seg = block_scan_long(n_big, scratch, [&](uint32_t k) { return (cnt_of(big_col[k]) + BIG_SEG - 1) / (BIG_SEG); },
+                                         [&](uint32_t k, uint32_t ex) { big_seg_off[k] = ex; });
+  if (threadIdx.x == 0) {
+    plan->n_big = n_big;
+    plan->total_seg = n_seg;
+  }
+}
+
 // (big bin, segment) of workgroup b: the last k with big_seg_off[k] <= b
 __device__ __forceinline__ bool bigbin_locate(const BigPlan* plan, const uint32_t* big_col, const uint32_t* big_seg_off, uint32_t b,
                                               uint32_t* col, uint32_t* seg) {
@@ -961,7 +1011,6 @@ inline PartGeom choose_part(uint64_t n, uint32_t WL, uint32_t nb) {
 //     bucket sizes are Poisson distributed and a wave runs as long as its longest lane -- and so that the few very
 //     long buckets of a skewed input come first.  A counting sort on the size (exact below 2048, then in steps of
 //     2048): histogram, suffix scan, scatter; the order inside a bin is irrelevant.
-constexpr uint32_t MSM_SIZE_BINS = 4096;
 __device__ __forceinline__ uint32_t msm_size_bin(uint32_t sz) {
   uint32_t hi = sz >> 11;
   return sz < 2048 ? sz : 2048 + (hi < 2047 ? hi : 2047);
@@ -1907,6 +1956,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     uint64_t lo, n, m, np;  // np: length of the array the partition sees (table mode: all key planes as one)
     PartGeom P;
     uint32_t ncell, heavy, heavy_seg, hb, max_items;
+    bool small_scan;              // short calls: the four column scans + the big-bin plan in one single-workgroup launch
     uint32_t split_t, split_hb;   // short calls: buckets longer than split_t take the quad-per-bucket launch (0: none)
   };
   std::vector<ChunkPlan> plan(n_chunks);
@@ -1921,6 +1971,10 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     C.P = choose_part(C.np, WL, G.nb);
     if (C.P.st == 0) return ZK_ERR_BAD_ARGS;
     C.ncell = WL * C.P.nbin;
+    {
+      static const bool no_small = std::getenv("MI355ZK_MSM_NO_SMALL_SCAN") != nullptr;
+      C.small_scan = !no_small && (uint64_t)C.P.n_st * C.ncell <= (1u << 16);
+    }
     // index lists: every bucket start is padded to a multiple of 4 entries (<= 3 per bucket), every bin region to 4
     const uint64_t vals_cap = C.m + 3ull * n_buckets + 4ull * C.ncell + 4;
     if (vals_cap > 0xfffffff0ull) return ZK_ERR_BAD_ARGS;
@@ -2069,7 +2123,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     // density words and prefix ranks of this chunk's exponents (cuts are multiples of 32); under FullDensity exponent i of the
     // chunk owns base base_offset + lo + i
     const uint32_t* dens = d_density ? d_density + (C.lo >> 5) : nullptr;
-    ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
+    if (!C.small_scan) ZK_HIP(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));   // (msm_scan_small_kernel clears it)
     if (C.np > BIG_SEG) ZK_HIP(hipMemsetAsync(gcnt, 0, o_big_col - o_gcnt, st));  // gcnt and gcur (big bins only: see the bucket pass)
     // "msm_sort" spans the whole partition after the digits (scan + scatter + bucket + size order), as it did for the library sort
     prof_begin(slot_digits, st);
@@ -2102,10 +2156,15 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     const uint64_t boff = base_offset + (d_density ? 0 : C.lo);
     prof_begin(slot_sort, st);
     prof_begin(slot_scan, st);
+    if (C.small_scan) {
+      hipLaunchKernelGGL(msm_scan_small_kernel, dim3(1), dim3(PART_THREADS), 0, st, tile_hist, P, ncell, G.nb, col_total, bin_start, out_start, tile_off,
+                         size_hist, big_col, big_seg, big_plan);
+    } else {
     hipLaunchKernelGGL(msm_colsum_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, P, ncell, csum);
     hipLaunchKernelGGL(msm_colscan_kernel, dim3((ncell + 255) / 256), dim3(256), 0, st, csum, P, ncell, col_total);
     hipLaunchKernelGGL(msm_binscan_kernel, dim3(1), dim3(PART_THREADS), 0, st, col_total, P, ncell, G.nb, bin_start, out_start);
     hipLaunchKernelGGL(msm_tileoff_kernel, dim3((ncell + 255) / 256, P.n_chunk), dim3(256), 0, st, tile_hist, csum, bin_start, P, ncell, tile_off);
+    }
     ZK_HIP(hipGetLastError());
     prof_end(slot_scan, st);
     prof_begin(slot_scatter, st);
@@ -2135,7 +2194,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       // does not pay for three idle launches (~5 us each of a 0.4-ms call at 2^10 .. 2^15 points)
       if (C.np > BIG_SEG) {
       const uint32_t max_seg = (uint32_t)(2 * (C.m / BIG_SEG) + 2);
-      hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
+      if (!C.small_scan) hipLaunchKernelGGL(msm_bigbin_plan_kernel, dim3(1), dim3(PART_THREADS), 0, st, bin_start, ncell, big_col, big_seg, big_plan);
       // (small grids: when there is no big bin -- uniform exponents -- the launches only cost their workgroups' start-up, and the
       // place kernel's LDS allows one workgroup per CU anyway)
       int n_cu = 256;
