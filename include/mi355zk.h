@@ -300,6 +300,13 @@ int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affin
  * `checked = 0` decoding can admit off-curve G1 records, for which no endomorphism identity holds either. */
 int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
 int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
+/* The same on HOST buffers, spread over the device set of mi355zk_init: what MPCParameters::contribute (parameters.rs:423-470) and
+ * powersoftau's batch_exp (batched_accumulator.rs:1130-1181) are to a single-process caller.  The points are independent, so device d takes
+ * the d-th contiguous point range -- upload, kernels, download from its own host thread, no exchange -- and with one device the
+ * vector is one range.  out / bases: n raw affine records (64 / 128 B, all-zero = infinity; out may not alias bases); scalars: n canonical
+ * FrRepr, or ONE when same_scalar != 0.  Synchronous.  G2: the subgroup precondition above. */
+int mi355zk_bn254_g1_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int same_scalar);
+int mi355zk_bn254_g2_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int same_scalar);
 /* The test that establishes the precondition above: *bad_index = the lowest index of a G2 record that is on the twist but NOT in
  * the order-r subgroup (-1: all n records are; the all-zero record is the identity).  psi(P) == mu P, mu P by a plain
  * double-and-add (no split).  The reference has no counterpart -- its bn256 decoders do not test membership either -- so this

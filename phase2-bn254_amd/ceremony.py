@@ -68,6 +68,19 @@ def batch_exp(bases, exps, same_scalar: bool = False):
     return out
 
 
+def batch_exp_host(bases: np.ndarray, exps: np.ndarray, same_scalar: bool = False) -> np.ndarray:
+    """batch_exp on HOST arrays ((n, 8) / (n, 16) u64 records, (n, 4) or (1, 4) u64 scalars): mi355zk_bn254_g{1,2}_batch_exp, which spreads
+    the points over the device set of the last Worker (contiguous point ranges, no exchange) -- phase2 `contribute` in ONE process on N GPUs."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    exps = np.ascontiguousarray(exps, dtype=np.uint64)
+    g = {8: 1, 16: 2}[bases.shape[1]]
+    out = np.empty_like(bases)
+    fn = _lib.load().mi355zk_bn254_g1_batch_exp if g == 1 else _lib.load().mi355zk_bn254_g2_batch_exp
+    _check(fn(out.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), exps.ctypes.data_as(C.c_void_p), bases.shape[0], 1 if same_scalar else 0),
+           "batch_exp (host buffers)")
+    return out
+
+
 def _to_host_point(g: int):
     return np.zeros(12 * g, dtype=np.uint64)
 

@@ -1664,6 +1664,76 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   return msm_host_run<GROUP>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
 }
 
+// ------------------------------------------------------------------------------------------------
+// batch_exp on HOST buffers, over the device set: what `MPCParameters::contribute` (phase2/src/parameters.rs:423-470: every point of L
+// and H times delta^-1) and powersoftau's `batch_exp` (batched_accumulator.rs:1130-1181) are to a single-process caller.  The points are
+// independent, so they shard by CONTIGUOUS POINT RANGE with no exchange at all (shard.batch_exp_sharded is the
+// one-process-per-GPU form): device d of mi355zk_init's set takes range d -- upload, the batch_exp kernels, download -- from its own
+// host thread; with one device the whole vector is one range.  Ranges are worked off in pieces of 2^22 points (a piece's buffers
+// come from the grow-only pool, so a 2^26-point vector does not allocate 10 GiB).  G2: the subgroup precondition of batch_exp_dev.
+template <class F>
+int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, size_t n, int same_scalar) {
+  if ((n && (!out || !bases)) || !scalars) return ZK_ERR_BAD_ARGS;
+  if (n == 0) return ZK_OK;
+  if (n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  constexpr size_t rec = sizeof(Affine<F>);
+  std::vector<int> devs = devset_snapshot();
+  if (devs.empty()) {
+    int cur = 0;
+    ZK_HIP(hipGetDevice(&cur));
+    devs.push_back(cur);
+  }
+  size_t parts = devs.size();
+  while (parts > 1 && n / parts < 1024) --parts;
+  std::vector<int> rcs(parts, ZK_OK);
+  auto run_range = [&](size_t d) {
+    const size_t lo = n * d / parts, hi = n * (d + 1) / parts;
+    if (hipSetDevice(devs[d]) != hipSuccess) { rcs[d] = ZK_ERR_DEVICE; return; }
+    StageLease stage_lease;
+    HostStage* S = host_stage(devs[d], &stage_lease);
+    if (S == nullptr) { rcs[d] = ZK_ERR_DEVICE; return; }
+    const size_t piece = (size_t)1 << 22;
+    const size_t m_max = hi - lo < piece ? hi - lo : piece;
+    const size_t sc_bytes = same_scalar ? 256 : ((m_max * 32 + 255) & ~(size_t)255);
+    DensityPool::Lease buf;   // (the grow-only device buffer pool of the host-buffer entry points)
+    int rc = buf.acquire(devs[d], 2 * m_max * rec + sc_bytes, S->compute);
+    if (rc) { rcs[d] = rc; return; }
+    char* d_in = (char*)buf.b->p;
+    char* d_out = d_in + m_max * rec;
+    char* d_sc = d_out + m_max * rec;
+    auto fail = [&](hipError_t e) {
+      std::fprintf(stderr, "[mi355zk] batch_exp (host buffers): HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+      rcs[d] = ZK_ERR_DEVICE;
+    };
+    hipError_t e = hipSuccess;
+    if (same_scalar && (e = hipMemcpyAsync(d_sc, scalars, 32, hipMemcpyHostToDevice, S->compute)) != hipSuccess) return fail(e);
+    for (size_t p0 = lo; p0 < hi; p0 += piece) {
+      const size_t m = hi - p0 < piece ? hi - p0 : piece;
+      if ((e = hipMemcpyAsync(d_in, bases + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute)) != hipSuccess) return fail(e);
+      if (!same_scalar && (e = hipMemcpyAsync(d_sc, scalars + p0 * 4, m * 32, hipMemcpyHostToDevice, S->compute)) != hipSuccess) return fail(e);
+      rc = batch_exp<F>(d_out, d_in, 0, d_sc, same_scalar, m, (void*)S->compute);
+      if (rc) { rcs[d] = rc; return; }
+      if ((e = hipMemcpyAsync(out + p0 * rec, d_out, m * rec, hipMemcpyDeviceToHost, S->compute)) != hipSuccess) return fail(e);
+      if ((e = hipStreamSynchronize(S->compute)) != hipSuccess) return fail(e);   // (the piece's buffers are reused by the next one)
+    }
+  };
+  {
+    DeviceGuard guard;
+    std::vector<std::thread> th;
+    size_t started = 1;
+    try {
+      for (; started < parts; ++started) th.emplace_back([&, started] { run_range(started); });
+    } catch (const std::exception&) {
+    }
+    run_range(0);
+    for (size_t d = started; d < parts; ++d) run_range(d);
+    for (auto& t : th) t.join();
+  }
+  for (int rc : rcs)
+    if (rc != ZK_OK) return rc;
+  return ZK_OK;
+}
+
 // best_fft / the domain operations on a HOST array (what a bellman shim calls with `&mut [Scalar<E>]`): upload, transform in place
 // on the device, copy back.  Device buffer and stream are leased from the pools of the host-buffer entry points -- round 2
 // hipMalloc'ed and hipFree'd per call (both synchronise the whole device, i.e. every other thread's multiexp) and ran on the null
@@ -2049,6 +2119,12 @@ int mi355zk_bn254_g2_sparse_matvec_dev(void* d_out_affine, const void* d_bases_a
   return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
 }
 
+int mi355zk_bn254_g1_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int same_scalar) {
+  return batch_exp_host<Fq>(out_affine, bases_affine, scalars, n, same_scalar);
+}
+int mi355zk_bn254_g2_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int same_scalar) {
+  return batch_exp_host<Fq2>(out_affine, bases_affine, scalars, n, same_scalar);
+}
 int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
   return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
 }

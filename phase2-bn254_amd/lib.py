@@ -88,6 +88,8 @@ SIGNATURES = {
     "mi355zk_bn254_g2_point_fft_dev": (_i, [_vp, _u32, _i, _vp]),
     "mi355zk_bn254_g1_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "mi355zk_bn254_g2_batch_mul_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_g1_batch_exp": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "mi355zk_bn254_g2_batch_exp": (_i, [_vp, _vp, _vp, _sz, _i]),
     "mi355zk_bn254_g1_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mi355zk_bn254_g2_batch_exp_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mi355zk_bn254_g2_subgroup_check_dev": (_i, [_vp, _sz, _vp, C.POINTER(C.c_longlong)]),

@@ -203,3 +203,33 @@ def test_eight_cells_at_2e22_same_point_as_one_device(zk, worker, monkeypatch):
     finally:
         zk.unpin_bases(None)
         zk.Worker(0)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("k", [1, 3, 8])
+def test_batch_exp_on_host_buffers_over_the_device_set(zk, worker, group, k):
+    """mi355zk_bn254_g{1,2}_batch_exp: phase2 `contribute` / powersoftau `batch_exp` for a single-process caller -- the points shard by
+    contiguous range over the device set, no exchange.  Per-point scalars and one shared scalar, an infinity record among the points,
+    against the oracle's mul_assign + into_affine; identical for 1, 3 and 8 logical devices."""
+    G = O.G1 if group == 1 else O.G2
+    n = 4200 if group == 1 else 3100          # (>= 1024 points per range, or the call is not cut)
+    bases = inputs.bases_progression_cpu(group, n, seed=4600 + group)
+    bases[17] = 0
+    sc = inputs.random_scalars(n, seed=4601)
+    sc[5] = 0
+    sc[6] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    w = zk.Worker(devices=[0] * k) if k > 1 else zk.Worker(0)
+    try:
+        got = zk.ceremony.batch_exp_host(bases, sc)
+        one = zk.ceremony.batch_exp_host(bases, sc[3:4], same_scalar=True)
+    finally:
+        zk.Worker(0)
+    idx = list(range(0, 40)) + list(range(n // 3 - 5, n // 3 + 5)) + list(range(n - 20, n))   # around every range boundary for k = 3
+    for i in idx:
+        assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), sc[i]))), i
+        assert np.array_equal(one[i], G.to_affine(G.mul(G.from_affine(bases[i]), sc[3]))), i
+    # the whole vector against the device-resident entry point
+    import torch
+
+    d = zk.ceremony.batch_exp(torch.from_numpy(bases.view(np.int64)).cuda(), torch.from_numpy(sc.view(np.int64)).cuda())
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), got)
