@@ -1692,30 +1692,63 @@ int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, 
     StageLease stage_lease;
     HostStage* S = host_stage(devs[d], &stage_lease);
     if (S == nullptr) { rcs[d] = ZK_ERR_DEVICE; return; }
-    const size_t piece = (size_t)1 << 22;
+    // pieces of 2^18 points, double-buffered
+    const size_t piece = (size_t)1 << 18;
     const size_t m_max = hi - lo < piece ? hi - lo : piece;
+    const size_t in_bytes = (m_max * rec + 255) & ~(size_t)255;
     const size_t sc_bytes = same_scalar ? 256 : ((m_max * 32 + 255) & ~(size_t)255);
     DensityPool::Lease buf;   // (the grow-only device buffer pool of the host-buffer entry points)
-    int rc = buf.acquire(devs[d], 2 * m_max * rec + sc_bytes, S->compute);
+    int rc = buf.acquire(devs[d], 4 * in_bytes + 2 * sc_bytes, S->compute);
     if (rc) { rcs[d] = rc; return; }
-    char* d_in = (char*)buf.b->p;
-    char* d_out = d_in + m_max * rec;
-    char* d_sc = d_out + m_max * rec;
+    char* base = (char*)buf.b->p;
+    char* d_in[2] = {base, base + in_bytes};
+    char* d_out[2] = {base + 2 * in_bytes, base + 3 * in_bytes};
+    char* d_sc[2] = {base + 4 * in_bytes, base + 4 * in_bytes + sc_bytes};
+    hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    auto cleanup = [&] {
+      (void)hipStreamSynchronize(S->copy);
+      (void)hipStreamSynchronize(S->compute);
+      for (int k = 0; k < 2; ++k) { if (up[k]) (void)hipEventDestroy(up[k]); if (done[k]) (void)hipEventDestroy(done[k]); }
+    };
     auto fail = [&](hipError_t e) {
       std::fprintf(stderr, "[mi355zk] batch_exp (host buffers): HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
       rcs[d] = ZK_ERR_DEVICE;
+      cleanup();
     };
     hipError_t e = hipSuccess;
-    if (same_scalar && (e = hipMemcpyAsync(d_sc, scalars, 32, hipMemcpyHostToDevice, S->compute)) != hipSuccess) return fail(e);
-    for (size_t p0 = lo; p0 < hi; p0 += piece) {
-      const size_t m = hi - p0 < piece ? hi - p0 : piece;
-      if ((e = hipMemcpyAsync(d_in, bases + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute)) != hipSuccess) return fail(e);
-      if (!same_scalar && (e = hipMemcpyAsync(d_sc, scalars + p0 * 4, m * 32, hipMemcpyHostToDevice, S->compute)) != hipSuccess) return fail(e);
-      rc = batch_exp<F>(d_out, d_in, 0, d_sc, same_scalar, m, (void*)S->compute);
-      if (rc) { rcs[d] = rc; return; }
-      if ((e = hipMemcpyAsync(out + p0 * rec, d_out, m * rec, hipMemcpyDeviceToHost, S->compute)) != hipSuccess) return fail(e);
-      if ((e = hipStreamSynchronize(S->compute)) != hipSuccess) return fail(e);   // (the piece's buffers are reused by the next one)
+    for (int k = 0; k < 2; ++k)
+      if ((e = hipEventCreateWithFlags(&up[k], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming)) != hipSuccess) return fail(e);
+    if (same_scalar && (e = hipMemcpyAsync(d_sc[0], scalars, 32, hipMemcpyHostToDevice, S->copy)) != hipSuccess) return fail(e);
+    // ONE host thread keeps the device busy although copies from / to PAGEABLE host memory block it: the kernels of piece i + 1 are
+    // always queued before the thread waits for piece i's download, and piece i + 2 is uploaded (into the buffer piece i's kernels
+    // have finished with: its download has just returned) while piece i + 1 computes.
+    const size_t n_pieces = (hi - lo + piece - 1) / piece;
+    auto upload_and_launch = [&](size_t i) -> bool {
+      const size_t p0 = lo + i * piece, m = hi - p0 < piece ? hi - p0 : piece;
+      const int k = (int)(i & 1);
+      if ((e = hipMemcpyAsync(d_in[k], bases + p0 * rec, m * rec, hipMemcpyHostToDevice, S->copy)) != hipSuccess) return false;
+      if (!same_scalar && (e = hipMemcpyAsync(d_sc[k], scalars + p0 * 4, m * 32, hipMemcpyHostToDevice, S->copy)) != hipSuccess) return false;
+      if ((e = hipEventRecord(up[k], S->copy)) != hipSuccess || (e = hipStreamWaitEvent(S->compute, up[k], 0)) != hipSuccess) return false;
+      rc = batch_exp<F>(d_out[k], d_in[k], 0, same_scalar ? d_sc[0] : d_sc[k], same_scalar, m, (void*)S->compute);
+      if (rc) return false;
+      return (e = hipEventRecord(done[k], S->compute)) == hipSuccess;
+    };
+    auto bail = [&] {
+      if (rc) { rcs[d] = rc; cleanup(); }
+      else fail(e);
+    };
+    for (size_t i = 0; i < 2 && i < n_pieces; ++i)
+      if (!upload_and_launch(i)) return bail();
+    for (size_t i = 0; i < n_pieces; ++i) {
+      const size_t p0 = lo + i * piece, m = hi - p0 < piece ? hi - p0 : piece;
+      const int k = (int)(i & 1);
+      if ((e = hipStreamWaitEvent(S->copy, done[k], 0)) != hipSuccess) return fail(e);
+      if ((e = hipMemcpyAsync(out + p0 * rec, d_out[k], m * rec, hipMemcpyDeviceToHost, S->copy)) != hipSuccess) return fail(e);
+      if ((e = hipStreamSynchronize(S->copy)) != hipSuccess) return fail(e);   // piece i is on the host; its buffers are free
+      if (i + 2 < n_pieces && !upload_and_launch(i + 2)) return bail();
     }
+    if ((e = hipStreamSynchronize(S->compute)) != hipSuccess) return fail(e);
+    cleanup();
   };
   {
     DeviceGuard guard;

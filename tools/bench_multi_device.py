@@ -73,6 +73,23 @@ def main():
                             "first_call_ms": round(t_first * 1e3, 1), "same_point_as_device_resident_call": bool(np.array_equal(aff, ref_aff))})
         del first
     zk.unpin_bases(None)
+    # phase2 contribute through the same door: mi355zk_bn254_g1_batch_exp on host buffers, 2^20 points times one scalar
+    m = 1 << 20
+    pts = hb[:m]
+    dinv = np.array([[0x0123456789ABCDEF, 0x0FEDCBA987654321, 0x1111111111111111, 0x0222222222222222]], dtype=np.uint64)
+    want = None
+    out["batch_exp_2e20"] = []
+    for k in args.devices:
+        ids = [i % phys for i in range(k)]
+        zk.Worker(devices=ids) if k > 1 else zk.Worker(0)
+        zk.ceremony.batch_exp_host(pts, dinv, same_scalar=True)
+        t = time.perf_counter()
+        for _ in range(args.iters):
+            got = zk.ceremony.batch_exp_host(pts, dinv, same_scalar=True)
+        dt = (time.perf_counter() - t) / args.iters
+        want = got if want is None else want
+        out["batch_exp_2e20"].append({"devices": ids, "ms_per_call_incl_pcie": round(dt * 1e3, 3), "Mpoint_per_s": round(m / dt / 1e6, 1),
+                                      "same_records_as_one_device": bool(np.array_equal(got, want))})
     zk.Worker(0)
     print(json.dumps(out))
 
