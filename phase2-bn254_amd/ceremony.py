@@ -102,6 +102,30 @@ def merge_pairs(v1, v2, rho):
     return s, sx
 
 
+def merge_pairs_host(v1: np.ndarray, v2: np.ndarray, rho: np.ndarray):
+    """merge_pairs on HOST arrays: mi355zk_bn254_g{1,2}_merge_pairs -- pieces of 2^21 points over the device set of the last Worker, partials
+    added on the host (powersoftau's verify_transform in ONE process on N GPUs).  v1 / v2 may be overlapping views (power_pairs)."""
+    g = {8: 1, 16: 2}[v1.shape[1]]
+    assert v1.flags["C_CONTIGUOUS"] and v2.flags["C_CONTIGUOUS"] and v1.dtype == np.uint64 and v2.dtype == np.uint64 and v1.shape == v2.shape
+    rho = np.ascontiguousarray(rho, dtype=np.uint64)
+    s, sx = _to_host_point(g), _to_host_point(g)
+    fn = _lib.load().mi355zk_bn254_g1_merge_pairs if g == 1 else _lib.load().mi355zk_bn254_g2_merge_pairs
+    _check(fn(v1.ctypes.data_as(C.c_void_p), v2.ctypes.data_as(C.c_void_p), rho.ctypes.data_as(C.c_void_p), v1.shape[0], s.ctypes.data_as(C.c_void_p),
+              sx.ctypes.data_as(C.c_void_p)), "merge_pairs (host buffers)")
+    return s, sx
+
+
+def dense_multiexp_host(bases: np.ndarray, exponents: np.ndarray) -> np.ndarray:
+    """dense_multiexp on HOST arrays (mi355zk_bn254_g{1,2}_dense_multiexp), over the device set like merge_pairs_host."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    exponents = np.ascontiguousarray(exponents, dtype=np.uint64)
+    g = {8: 1, 16: 2}[bases.shape[1]]
+    out = _to_host_point(g)
+    fn = _lib.load().mi355zk_bn254_g1_dense_multiexp if g == 1 else _lib.load().mi355zk_bn254_g2_dense_multiexp
+    _check(fn(bases.ctypes.data_as(C.c_void_p), exponents.ctypes.data_as(C.c_void_p), bases.shape[0], out.ctypes.data_as(C.c_void_p)), "dense_multiexp (host buffers)")
+    return out
+
+
 def power_pairs(v, rho):
     """merge_pairs(v[:-1], v[1:]) (utils.rs:133-135); rho has len(v) - 1 scalars."""
     return merge_pairs(v[:-1], v[1:], rho)

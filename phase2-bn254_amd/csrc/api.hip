@@ -1767,6 +1767,94 @@ int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, 
   return ZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// dense_multiexp / merge_pairs on HOST buffers, over the device set: the verification multiexps of the ceremony code (SURVEY 8f row 2:
+// powersoftau/src/utils.rs:112-135, 189-292; phase2/src/utils.rs:59-105) for a single-process caller.  sum_i rho_i * v_i is linear in the
+// points, so the vectors are cut into pieces of 2^21 points, every piece is one device call (msm_g*_dense_device: digits and partition
+// shared by the two sums of merge_pairs) and the Jacobian partials are added on the host.  The pieces are dealt to TWO host threads per
+// device of mi355zk_init's set (one piece uploads -- pageable copies block their thread -- while the other computes); v2 == nullptr:
+// dense_multiexp.  No Source errors (infinity bases add nothing: the reference's dense contract).
+template <int GROUP>
+int dense_host(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t n, uint64_t* out_s, uint64_t* out_sx) {
+  using J = typename std::conditional<GROUP == 1, G1Jacobian, G2Jacobian>::type;
+  constexpr size_t rec = GROUP == 1 ? 64 : 128;
+  if (!out_s || (v2 && !out_sx) || (n && (!v1 || !rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  J total = J::zero(), total2 = J::zero();
+  if (n > 0) {
+    std::vector<int> devs = devset_snapshot();
+    if (devs.empty()) {
+      int cur = 0;
+      ZK_HIP(hipGetDevice(&cur));
+      devs.push_back(cur);
+    }
+    size_t piece = (size_t)1 << 21;
+    if (const char* env = std::getenv("MI355ZK_DENSE_PIECE_TEST")) {   // (test hook, read per call: points per piece, so that the cut can be held against the oracle)
+      const size_t v = (size_t)std::strtoull(env, nullptr, 10);
+      if (v >= 16) piece = v;
+    }
+    const size_t n_pieces = (n + piece - 1) / piece;
+    size_t workers = 2 * devs.size();
+    if (workers > n_pieces) workers = n_pieces;
+    struct Part { int rc = ZK_OK; J s, sx; };
+    std::vector<Part> parts(workers);
+    for (auto& pt : parts) { pt.s = J::zero(); pt.sx = J::zero(); }
+    std::atomic<size_t> next{0};
+    auto work = [&](size_t wk) {
+      Part& P = parts[wk];
+      const int dev = devs[wk % devs.size()];
+      if (hipSetDevice(dev) != hipSuccess) { P.rc = ZK_ERR_DEVICE; return; }
+      StageLease stage_lease;
+      HostStage* S = host_stage(dev, &stage_lease);
+      if (S == nullptr) { P.rc = ZK_ERR_DEVICE; return; }
+      const size_t m_max = n < piece ? n : piece;
+      const size_t vb = (m_max * rec + 255) & ~(size_t)255;
+      DensityPool::Lease buf;
+      if (int rc = buf.acquire(dev, (v2 ? 2 : 1) * vb + m_max * 32, S->compute)) { P.rc = rc; return; }
+      char* d_v1 = (char*)buf.b->p;
+      char* d_v2 = v2 ? d_v1 + vb : nullptr;
+      char* d_rho = d_v1 + (v2 ? 2 : 1) * vb;
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n_pieces) break;
+        const size_t p0 = i * piece, m = n - p0 < piece ? n - p0 : piece;
+        hipError_t e = hipMemcpyAsync(d_v1, v1 + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute);
+        if (e == hipSuccess && v2) e = hipMemcpyAsync(d_v2, v2 + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rho, rho + p0 * 4, m * 32, hipMemcpyHostToDevice, S->compute);
+        if (e != hipSuccess) {
+          std::fprintf(stderr, "[mi355zk] dense multiexp (host buffers): HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+          P.rc = ZK_ERR_DEVICE;
+          return;
+        }
+        J a = J::zero(), b = J::zero();
+        const int rc = GROUP == 1 ? msm_g1_dense_device(d_v1, d_v2, d_rho, m, S->compute, reinterpret_cast<uint64_t*>(&a), v2 ? reinterpret_cast<uint64_t*>(&b) : nullptr)
+                                  : msm_g2_dense_device(d_v1, d_v2, d_rho, m, S->compute, reinterpret_cast<uint64_t*>(&a), v2 ? reinterpret_cast<uint64_t*>(&b) : nullptr);
+        if (rc != ZK_OK) { P.rc = rc; return; }
+        jac_add(P.s, a);
+        if (v2) jac_add(P.sx, b);
+      }
+    };
+    {
+      DeviceGuard guard;
+      std::vector<std::thread> th;
+      size_t started = 1;
+      try {
+        for (; started < workers; ++started) th.emplace_back([&, started] { work(started); });
+      } catch (const std::exception&) {
+      }
+      work(0);   // (a worker takes pieces until none is left: the ones that got no thread are covered by the others)
+      for (auto& t : th) t.join();
+    }
+    for (auto& pt : parts) {
+      if (pt.rc != ZK_OK) return pt.rc;
+      jac_add(total, pt.s);
+      if (v2) jac_add(total2, pt.sx);
+    }
+  }
+  std::memcpy(out_s, &total, sizeof total);
+  if (v2) std::memcpy(out_sx, &total2, sizeof total2);
+  return ZK_OK;
+}
+
 // best_fft / the domain operations on a HOST array (what a bellman shim calls with `&mut [Scalar<E>]`): upload, transform in place
 // on the device, copy back.  Device buffer and stream are leased from the pools of the host-buffer entry points -- round 2
 // hipMalloc'ed and hipFree'd per call (both synchronise the whole device, i.e. every other thread's multiexp) and ran on the null
@@ -2004,6 +2092,20 @@ int mi355zk_bn254_g2_msm_table_dev(const void* d_table, size_t n_bases, size_t b
                                    const uint32_t* density, size_t density_bits, uint32_t flags, void* stream, uint64_t out_xyz[24]) {
   if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
   return msm_dev_entry<2>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
+}
+int mi355zk_bn254_g1_dense_multiexp(const uint8_t* bases, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
+  return dense_host<1>(bases, nullptr, scalars, n, out_xyz, nullptr);
+}
+int mi355zk_bn254_g2_dense_multiexp(const uint8_t* bases, const uint64_t* scalars, size_t n, uint64_t out_xyz[24]) {
+  return dense_host<2>(bases, nullptr, scalars, n, out_xyz, nullptr);
+}
+int mi355zk_bn254_g1_merge_pairs(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t n, uint64_t out_s[12], uint64_t out_sx[12]) {
+  if (!v2) return ZK_ERR_BAD_ARGS;
+  return dense_host<1>(v1, v2, rho, n, out_s, out_sx);
+}
+int mi355zk_bn254_g2_merge_pairs(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t n, uint64_t out_s[24], uint64_t out_sx[24]) {
+  if (!v2) return ZK_ERR_BAD_ARGS;
+  return dense_host<2>(v1, v2, rho, n, out_s, out_sx);
 }
 int mi355zk_bn254_g1_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
   if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;

@@ -43,6 +43,10 @@ SIGNATURES = {
     "mi355zk_bn254_g2_msm_table_build_dev": (_i, [_vp, _sz, _vp, _sz, _vp]),
     "mi355zk_bn254_g1_msm_table_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _vp, _vp]),
     "mi355zk_bn254_g2_msm_table_dev": (_i, [_vp, _sz, _sz, _vp, _sz, _vp, _sz, _u32, _vp, _vp]),
+    "mi355zk_bn254_g1_dense_multiexp": (_i, [_vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_g2_dense_multiexp": (_i, [_vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_g1_merge_pairs": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "mi355zk_bn254_g2_merge_pairs": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g1_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g2_dense_multiexp_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "mi355zk_bn254_g1_merge_pairs_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),

@@ -233,3 +233,57 @@ def test_batch_exp_on_host_buffers_over_the_device_set(zk, worker, group, k):
 
     d = zk.ceremony.batch_exp(torch.from_numpy(bases.view(np.int64)).cuda(), torch.from_numpy(sc.view(np.int64)).cuda())
     assert np.array_equal(d.cpu().numpy().view(np.uint64), got)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("k", [1, 3])
+def test_merge_pairs_on_host_buffers_over_the_device_set(zk, worker, group, k, monkeypatch):
+    """mi355zk_bn254_g{1,2}_merge_pairs / _dense_multiexp on host buffers (powersoftau's verification multiexps for a single-process caller):
+    the vectors are cut into pieces (MI355ZK_DENSE_PIECE_TEST: 700 points instead of 2^21), dealt to two host threads per device, and the
+    partials are added on the host.  power_pairs shape (v2 = v1 shifted by one record, overlapping views), an infinity entry, a zero
+    scalar -- against the oracle."""
+    monkeypatch.setenv("MI355ZK_DENSE_PIECE_TEST", "700")
+    G = O.G1 if group == 1 else O.G2
+    n = 5000 if group == 1 else 1500
+    v = inputs.bases_progression_cpu(group, n + 1, seed=4700 + group)
+    v[1234] = 0
+    rho = inputs.random_scalars(n, seed=4701)
+    rho[5] = 0
+
+    def ref(bases):
+        sc = rho.copy()
+        sc[~bases.any(axis=1)] = 0
+        rc, out = G.multiexp(bases, sc, threads=4)
+        assert rc == 0
+        return G.to_affine(out)
+
+    zk.Worker(devices=[0] * k) if k > 1 else zk.Worker(0)
+    try:
+        s, sx = zk.ceremony.merge_pairs_host(v[:n], v[1:], rho)
+        one = zk.ceremony.dense_multiexp_host(v[:n], rho)
+        empty = zk.ceremony.dense_multiexp_host(v[:0], rho[:0])
+    finally:
+        zk.Worker(0)
+    assert np.array_equal(G.to_affine(s), ref(v[:n])) and np.array_equal(G.to_affine(sx), ref(v[1:n + 1]))
+    assert np.array_equal(G.to_affine(one), ref(v[:n]))
+    assert not empty[8 * group:].any()   # Z == 0
+
+
+def test_merge_pairs_host_at_2e22_matches_the_device_resident_call(zk, worker):
+    """Two real pieces of 2^21 points through two host threads: the same affine sums as ONE device-resident merge_pairs call."""
+    import torch
+
+    import bench
+
+    n = (1 << 22) - 1
+    dev = torch.device("cuda", 0)
+    k = bench.gen_scalars(n + 1, 4801, dev)
+    d_v = torch.empty((n + 1, 8), dtype=torch.int64, device=dev)
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+    assert zk.lib.load().mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(d_v.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n + 1, None) == 0
+    d_rho = bench.gen_scalars(n, 4802, dev)
+    want_s, want_sx = zk.ceremony.power_pairs(d_v, d_rho)
+    h_v = d_v.cpu().numpy().view(np.uint64)
+    h_rho = d_rho.cpu().numpy().view(np.uint64)
+    s, sx = zk.ceremony.merge_pairs_host(h_v[:n], h_v[1:], h_rho)
+    assert np.array_equal(O.G1.to_affine(s), O.G1.to_affine(want_s)) and np.array_equal(O.G1.to_affine(sx), O.G1.to_affine(want_sx))
