@@ -141,7 +141,7 @@ int mi355zk_bn254_g2_dense_multiexp_dev(const void *d_bases, const void *d_scala
 int mi355zk_bn254_g1_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[12], uint64_t out_sx[12]);
 int mi355zk_bn254_g2_merge_pairs_dev(const void *d_v1, const void *d_v2, const void *d_rho, size_t n, void *stream, uint64_t out_s[24], uint64_t out_sx[24]);
 /* The same two on HOST buffers, over the device set of mi355zk_init (a single-process caller: powersoftau's verify_transform runs them over
- * 2^21 .. 2^28-point vectors): the sums are linear in the points, so the vectors are cut into pieces of 2^21 points, every piece is one
+ * 2^21 .. 2^28-point vectors): the sums are linear in the points, so the vectors are cut into pieces of 2^22 points, every piece is one
  * device call and the Jacobian partials are added on the host; the pieces are dealt to two host threads per device (one uploads while the
  * other computes).  Records and scalars as in the _dev forms; v1, v2 may overlap (power_pairs: v2 = v1 + one record).  Synchronous. */
 int mi355zk_bn254_g1_dense_multiexp(const uint8_t *bases, const uint64_t *scalars, size_t n, uint64_t out_xyz[12]);

@@ -103,7 +103,7 @@ def merge_pairs(v1, v2, rho):
 
 
 def merge_pairs_host(v1: np.ndarray, v2: np.ndarray, rho: np.ndarray):
-    """merge_pairs on HOST arrays: mi355zk_bn254_g{1,2}_merge_pairs -- pieces of 2^21 points over the device set of the last Worker, partials
+    """merge_pairs on HOST arrays: mi355zk_bn254_g{1,2}_merge_pairs -- pieces of 2^22 points over the device set of the last Worker, partials
     added on the host (powersoftau's verify_transform in ONE process on N GPUs).  v1 / v2 may be overlapping views (power_pairs)."""
     g = {8: 1, 16: 2}[v1.shape[1]]
     assert v1.flags["C_CONTIGUOUS"] and v2.flags["C_CONTIGUOUS"] and v1.dtype == np.uint64 and v2.dtype == np.uint64 and v1.shape == v2.shape

@@ -1770,7 +1770,7 @@ int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, 
 // ------------------------------------------------------------------------------------------------
 // dense_multiexp / merge_pairs on HOST buffers, over the device set: the verification multiexps of the ceremony code (SURVEY 8f row 2:
 // powersoftau/src/utils.rs:112-135, 189-292; phase2/src/utils.rs:59-105) for a single-process caller.  sum_i rho_i * v_i is linear in the
-// points, so the vectors are cut into pieces of 2^21 points, every piece is one device call (msm_g*_dense_device: digits and partition
+// points, so the vectors are cut into pieces of 2^22 points, every piece is one device call (msm_g*_dense_device: digits and partition
 // shared by the two sums of merge_pairs) and the Jacobian partials are added on the host.  The pieces are dealt to TWO host threads per
 // device of mi355zk_init's set (one piece uploads -- pageable copies block their thread -- while the other computes); v2 == nullptr:
 // dense_multiexp.  No Source errors (infinity bases add nothing: the reference's dense contract).
@@ -1787,7 +1787,7 @@ int dense_host(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t
       ZK_HIP(hipGetDevice(&cur));
       devs.push_back(cur);
     }
-    size_t piece = (size_t)1 << 21;
+    size_t piece = (size_t)1 << 22;
     if (const char* env = std::getenv("MI355ZK_DENSE_PIECE_TEST")) {   // (test hook, read per call: points per piece, so that the cut can be held against the oracle)
       const size_t v = (size_t)std::strtoull(env, nullptr, 10);
       if (v >= 16) piece = v;
@@ -1807,18 +1807,23 @@ int dense_host(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t
       HostStage* S = host_stage(dev, &stage_lease);
       if (S == nullptr) { P.rc = ZK_ERR_DEVICE; return; }
       const size_t m_max = n < piece ? n : piece;
-      const size_t vb = (m_max * rec + 255) & ~(size_t)255;
+      const size_t vb = ((m_max + 16) * rec + 255) & ~(size_t)255;
       DensityPool::Lease buf;
       if (int rc = buf.acquire(dev, (v2 ? 2 : 1) * vb + m_max * 32, S->compute)) { P.rc = rc; return; }
       char* d_v1 = (char*)buf.b->p;
-      char* d_v2 = v2 ? d_v1 + vb : nullptr;
+      // power_pairs (utils.rs:133-135) is merge_pairs(v[0 .. n-1], v[1 .. n]): the two vectors are ONE array seen at two offsets, and
+      // uploading it twice would double the PCIe traffic of a call the link already bounds -- a v2 that starts `shift` (<= 16)
+      // records into v1 shares v1's upload
+      const size_t shift = (v2 && v2 >= v1 && (size_t)(v2 - v1) % rec == 0 && (size_t)(v2 - v1) / rec <= 16) ? (size_t)(v2 - v1) / rec : (size_t)-1;
+      const bool shared = shift != (size_t)-1;
+      char* d_v2 = v2 ? (shared ? d_v1 + shift * rec : d_v1 + vb) : nullptr;
       char* d_rho = d_v1 + (v2 ? 2 : 1) * vb;
       for (;;) {
         const size_t i = next.fetch_add(1);
         if (i >= n_pieces) break;
         const size_t p0 = i * piece, m = n - p0 < piece ? n - p0 : piece;
-        hipError_t e = hipMemcpyAsync(d_v1, v1 + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute);
-        if (e == hipSuccess && v2) e = hipMemcpyAsync(d_v2, v2 + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute);
+        hipError_t e = hipMemcpyAsync(d_v1, v1 + p0 * rec, (m + (shared ? shift : 0)) * rec, hipMemcpyHostToDevice, S->compute);
+        if (e == hipSuccess && v2 && !shared) e = hipMemcpyAsync(d_v2, v2 + p0 * rec, m * rec, hipMemcpyHostToDevice, S->compute);
         if (e == hipSuccess) e = hipMemcpyAsync(d_rho, rho + p0 * 4, m * 32, hipMemcpyHostToDevice, S->compute);
         if (e != hipSuccess) {
           std::fprintf(stderr, "[mi355zk] dense multiexp (host buffers): HIP error %d (%s)\n", (int)e, hipGetErrorString(e));

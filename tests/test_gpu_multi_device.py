@@ -239,7 +239,7 @@ def test_batch_exp_on_host_buffers_over_the_device_set(zk, worker, group, k):
 @pytest.mark.parametrize("k", [1, 3])
 def test_merge_pairs_on_host_buffers_over_the_device_set(zk, worker, group, k, monkeypatch):
     """mi355zk_bn254_g{1,2}_merge_pairs / _dense_multiexp on host buffers (powersoftau's verification multiexps for a single-process caller):
-    the vectors are cut into pieces (MI355ZK_DENSE_PIECE_TEST: 700 points instead of 2^21), dealt to two host threads per device, and the
+    the vectors are cut into pieces (MI355ZK_DENSE_PIECE_TEST: 700 points instead of 2^22), dealt to two host threads per device, and the
     partials are added on the host.  power_pairs shape (v2 = v1 shifted by one record, overlapping views), an infinity entry, a zero
     scalar -- against the oracle."""
     monkeypatch.setenv("MI355ZK_DENSE_PIECE_TEST", "700")
@@ -269,13 +269,13 @@ def test_merge_pairs_on_host_buffers_over_the_device_set(zk, worker, group, k, m
     assert not empty[8 * group:].any()   # Z == 0
 
 
-def test_merge_pairs_host_at_2e22_matches_the_device_resident_call(zk, worker):
-    """Two real pieces of 2^21 points through two host threads: the same affine sums as ONE device-resident merge_pairs call."""
+def test_merge_pairs_host_at_2e23_matches_the_device_resident_call(zk, worker):
+    """Two real pieces of 2^22 points through two host threads: the same affine sums as ONE device-resident merge_pairs call."""
     import torch
 
     import bench
 
-    n = (1 << 22) - 1
+    n = (1 << 23) - 1
     dev = torch.device("cuda", 0)
     k = bench.gen_scalars(n + 1, 4801, dev)
     d_v = torch.empty((n + 1, 8), dtype=torch.int64, device=dev)
