@@ -53,6 +53,8 @@ for src, dst, hdr in (("ab_quad.txt", "ab_quad.txt", "# bash tools/ab_quad.sh: t
                       ("multi_device_2e26.json", "multi_device_2e26.json", None),
                       ("ntt_configs.txt", "ntt_configs.txt", "# bash tools/ab_ntt_lds.sh: tools/bench_ntt.py (warmed up, no per-pass events in the timed loop): (ms per transform, ntt_pass_kernel avg ms, passes)\n"),
                       ("host_entry_timeline.txt", "host_entry_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_host_entry.py: streamed host-buffer G1 multiexps at 2^26 over a pinned vector (page-locked exponents, 5 chunks), last 140 dispatches\n"),
+                      ("ab_split.txt", "ab_split.txt", "# bash tools/ab_split.sh (ms per call; msm_accumulate / msm_reduce by HIP events; MI355ZK_MSM_SPLIT=0 = the lane-per-bucket launch alone)\n"),
+                      ("bench_small.json", "bench_small.json", None),
                       ("msm16_timeline.txt", "msm16_timeline.txt", "# rocprofv3 --kernel-trace -- TRACE_LOG_N=16 python tools/trace_one_msm.py: the launches of ONE 2^16-point G1 multiexp\n")):
     if os.path.exists(os.path.join(SRC, src)): put(src, dst, hdr)
 
@@ -93,6 +95,8 @@ if md: rows.append((f"`{tag}_multi_device_2e26.json`", "`tools/bench_multi_devic
 pr = J("prover.json")
 if pr: rows.append((f"`{tag}_prover.json`", "`tools/bench_prover.py --log-m 16 / 20 / 22`", "; ".join(f"2^{x['log_m']}: sequential {x['sequential_ms']} ms, eight threads {x['eight_threads_ms']}, with tables {x['eight_threads_tables_ms']}" for x in pr)))
 for name, cmd, what in (("ab_quad.txt", "`tools/ab_quad.sh`", "quad additions in the reduce tails against one lane per addition, same box (G1 2^12 .. 2^22, G2 2^12 .. 2^20)"),
+                        ("ab_split.txt", "`tools/ab_split.sh`", "short calls: the long buckets on a quad each (msm_accumulate_split_kernel) against the lane-per-bucket launch alone, same box"),
+                        ("bench_small.json", "`bench.py --log-n 12 / 14 / 16 / 20`", "the short calls after all of round 4's changes"),
                         ("table_mode.json", "`tools/bench_table.py`", "table mode against the plain call, same process"),
                         ("g2_2e20.json", "`tools/bench_g2.py`", "2^20 G2 multiexp with its closed-form check"),
                         ("next_rows_2e20.json", "`tools/bench_next_rows.py --log-n 20`", "SURVEY 8(f) rows 1-4 at 2^20"),
@@ -104,6 +108,8 @@ for name, cmd, what in (("ab_quad.txt", "`tools/ab_quad.sh`", "quad additions in
     if os.path.exists(os.path.join(DST, f"{tag}_{name}")): rows.append((f"`{tag}_{name}`", cmd, what))
 hand = [("`r04_exp_cu_mask.txt`", "`tools/exp_cu_mask.py`", "CU-masked side stream beside the accumulation: measured, rejected (DESIGN 6)"),
         ("`r04_small_n_sweep.txt`", "`tools/sweep_small_n.sh`", "every window width at 2^10 .. 2^20 and the reduce schedule after the quad additions: the measured table did not move"),
+        ("`r04_reduce_schedule_sweep.txt`, `r04_partition_sweep.txt`", "`tools/sweep_reduce_schedule.sh`, `tools/sweep_partition.sh`", "forced reduce schedules (chunk lengths per level, hand-over to the trees) and partition geometries (super-tile size, fine bits) against the defaults: the defaults stay"),
+        ("`r04_ntt20_isa_ledger.txt`", "`tools/ntt_isa_ledger.py [-DZK_NTT_LDS_PLANES]`", "static instruction ledger of `ntt_pass_kernel<10, radix-4>` by class, element-major LDS tiles against the limb planes of rounds 1-3 (84 vs 125 VGPRs)"),
         ("`r04_fuzz_msm.txt`", "`CASES=40 SEED=11 tools/fuzz_msm.sh`", "1240 differential fuzz cases against the oracle (window layouts, streamed chunks, table mode, 2 / 3 / 8 logical devices, one-lane tails): 0 mismatches"),
         ("`r04_host_entry_timeline.txt`, `r04_multi_device_2e26.json`", "mid-round copies of the files above", "kept: DESIGN cites them")]
 with open(os.path.join(DST, "README.md"), "w") as f:
