@@ -282,7 +282,8 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
     # ---- the single-process multi-GPU mode of the C ABI (mi355zk_init with n_devices > 1: include/mi355zk.h), only when this
     # process sees more than one GPU (the driver's N = 1 run on a multi-GPU node): ONE host thread calls mi355zk_bn254_g1_msm on host buffers,
     # the library cuts the call into one point range per device.  2^24 points, pinned bases, page-locked exponents, upload inside the call.
-    ndev = torch.cuda.device_count()
+    phys = torch.cuda.device_count()
+    ndev = int(os.environ.get("BENCH_MULTI_LOGICAL", phys))   # (test hook: k logical devices on the GPUs there are -- control flow, not scaling)
     if ndev > 1:
         mlog = 24
         m = 1 << mlog
@@ -304,7 +305,7 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         L.mi355zk_bn254_g1_to_affine(ref_aff.ctypes.data_as(C.c_void_p), np.ascontiguousarray(ref).ctypes.data_as(C.c_void_p))
         k = 1
         while k <= ndev:
-            wk = zk.Worker(devices=list(range(k))) if k > 1 else zk.Worker(0)
+            wk = zk.Worker(devices=[i % phys for i in range(k)]) if k > 1 else zk.Worker(0)
             zk.multiexp(wk, (hb, 0), zk.FullDensity(), hs).wait()           # every device uploads its copy of the pinned vector
             t = time.perf_counter()
             for _ in range(3):
@@ -318,7 +319,7 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         zk.Worker(dev.index)
         sec["single_process_multi_gpu_2e%d" % mlog] = {
             "metric": "2^%d-point G1 multiexp through mi355zk_bn254_g1_msm (host buffers, exponents' H2D inside the call) over 1 .. %d GPUs of ONE process" % (mlog, ndev),
-            "runs": runs}
+            "physical_gpus": phys, "runs": runs}
     return sec
 
 

@@ -80,3 +80,15 @@ def test_plain_command_launches_its_own_ranks():
         env.pop("BENCH_BACKEND")
         out = subprocess.run(args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 2 and "GPU(s) visible" in out.stderr
+
+
+def test_single_process_multi_gpu_leg_of_the_bench():
+    """When bench.py's process sees several GPUs its secondary block also times the single-process multi-GPU mode of the C ABI
+    (mi355zk_init with n > 1); BENCH_MULTI_LOGICAL=4 exercises that leg with four logical devices on the one GPU there is: same point."""
+    args = [sys.executable, "bench.py", "--log-n", "20", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-h2d-leg"]
+    env = dict(os.environ, BENCH_MULTI_LOGICAL="4")
+    out = subprocess.run(args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    leg = got["secondary"]["single_process_multi_gpu_2e24"]
+    assert [r["devices"] for r in leg["runs"]] == [1, 2, 4] and all(r["same_point"] for r in leg["runs"])
