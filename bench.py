@@ -280,46 +280,23 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
     sec["contribute_2e%d" % log_n] = entry
 
     # ---- the single-process multi-GPU mode of the C ABI (mi355zk_init with n_devices > 1: include/mi355zk.h), only when this
-    # process sees more than one GPU (the driver's N = 1 run on a multi-GPU node): ONE host thread calls mi355zk_bn254_g1_msm on host buffers,
-    # the library cuts the call into one point range per device.  2^24 points, pinned bases, page-locked exponents, upload inside the call.
+    # process sees more than one GPU (the driver's N = 1 run on a multi-GPU node): ONE host thread calls mi355zk_bn254_g1_msm on host buffers
+    # and the library cuts the call into one point range per device.  Run as a CHILD process (tools/bench_multi_device.py: 2^24 points,
+    # pinned bases, page-locked exponents, upload inside the call) with a time limit: this mode has never run on real multi-GPU hardware,
+    # and nothing it does may cost the headline line.
     phys = torch.cuda.device_count()
     ndev = int(os.environ.get("BENCH_MULTI_LOGICAL", phys))   # (test hook: k logical devices on the GPUs there are -- control flow, not scaling)
     if ndev > 1:
-        mlog = 24
-        m = 1 << mlog
-        gen_raw = np.ascontiguousarray(inputs.G1_GEN_RAW)
-        bb = torch.empty((m, 8), dtype=torch.int64, device=dev)
-        kk = gen_scalars(m, 31, dev)
-        assert L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bb.data_ptr()), gen_raw.ctypes.data_as(C.c_void_p), C.c_void_p(kk.data_ptr()), m, None) == 0
-        ss = gen_scalars(m, 32, dev)
-        ref = zk.multiexp(worker, (bb, 0), zk.FullDensity(), ss).wait()
-        hb = bb.cpu().numpy().view(np.uint64)
-        hs_t = torch.empty(ss.shape, dtype=torch.int64, pin_memory=True)
-        hs_t.copy_(ss)
-        torch.cuda.synchronize()
-        hs = hs_t.numpy().view(np.uint64)
-        del bb, kk, ss
-        zk.pin_bases(hb)
-        runs = []
-        ref_aff = np.zeros(8, dtype=np.uint64)
-        L.mi355zk_bn254_g1_to_affine(ref_aff.ctypes.data_as(C.c_void_p), np.ascontiguousarray(ref).ctypes.data_as(C.c_void_p))
-        k = 1
-        while k <= ndev:
-            wk = zk.Worker(devices=[i % phys for i in range(k)]) if k > 1 else zk.Worker(0)
-            zk.multiexp(wk, (hb, 0), zk.FullDensity(), hs).wait()           # every device uploads its copy of the pinned vector
-            t = time.perf_counter()
-            for _ in range(3):
-                got = zk.multiexp(wk, (hb, 0), zk.FullDensity(), hs).wait()
-            dt = (time.perf_counter() - t) / 3
-            aff = np.zeros(8, dtype=np.uint64)
-            L.mi355zk_bn254_g1_to_affine(aff.ctypes.data_as(C.c_void_p), np.ascontiguousarray(got).ctypes.data_as(C.c_void_p))
-            runs.append({"devices": k, "ms": round(dt * 1e3, 3), "Mscalar_mul_per_s": round(m / dt / 1e6, 1), "same_point": bool(np.array_equal(aff, ref_aff))})
-            k *= 2
-        zk.unpin_bases(None)
-        zk.Worker(dev.index)
-        sec["single_process_multi_gpu_2e%d" % mlog] = {
-            "metric": "2^%d-point G1 multiexp through mi355zk_bn254_g1_msm (host buffers, exponents' H2D inside the call) over 1 .. %d GPUs of ONE process" % (mlog, ndev),
-            "physical_gpus": phys, "runs": runs}
+        import subprocess
+
+        counts = [str(k) for k in (1, 2, 4, 8, 16) if k <= ndev]
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_multi_device.py"), "--log-n", "24", "--iters", "3", "--no-batch-exp", "--devices"] + counts,
+                                 capture_output=True, text=True, timeout=240, cwd=ROOT)
+            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+            sec["single_process_multi_gpu_2e24"] = json.loads(line[-1]) if out.returncode == 0 and line else {"error": "rc %d: %s" % (out.returncode, out.stderr[-300:])}
+        except Exception as e:  # noqa: BLE001
+            sec["single_process_multi_gpu_2e24"] = {"error": repr(e)[:300]}
     return sec
 
 

@@ -91,4 +91,4 @@ def test_single_process_multi_gpu_leg_of_the_bench():
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     leg = got["secondary"]["single_process_multi_gpu_2e24"]
-    assert [r["devices"] for r in leg["runs"]] == [1, 2, 4] and all(r["same_point"] for r in leg["runs"])
+    assert [len(r["devices"]) for r in leg["runs"]] == [1, 2, 4] and all(r["same_point_as_device_resident_call"] for r in leg["runs"])
