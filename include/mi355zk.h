@@ -262,6 +262,14 @@ int mi355zk_bn254_g1_sparse_matvec_dev(void *d_out_affine, const void *d_bases_a
 int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, size_t n_bases, const uint32_t *d_row_ptr,
                                        const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
 
+/* The same on HOST buffers, over the device set of mi355zk_init (MPCParameters::new in one process on N GPUs): the rows are independent,
+ * so device d evaluates the d-th contiguous row range -- its slice of (col, coeff), the whole base vector -- and writes its rows; no
+ * exchange.  Same validation (3 = bad arguments) and output as the _dev form.  Synchronous. */
+int mi355zk_bn254_g1_sparse_matvec(uint8_t *out_affine, const uint8_t *bases_affine, size_t n_bases, const uint32_t *row_ptr, const uint32_t *col,
+                                   const uint64_t *coeffs, size_t n_rows, size_t nnz);
+int mi355zk_bn254_g2_sparse_matvec(uint8_t *out_affine, const uint8_t *bases_affine, size_t n_bases, const uint32_t *row_ptr, const uint32_t *col,
+                                   const uint64_t *coeffs, size_t n_rows, size_t nnz);
+
 /* ---- point codecs: the reference's wire encodings <-> raw affine records.
  * Replaces EncodedPoint::{into_affine, into_affine_unchecked, from_affine} for G1Uncompressed (64 B), G1Compressed
  * (32 B), G2Uncompressed (128 B), G2Compressed (64 B)  (pairing/src/bn256/ec.rs:763-946, 1136-1344), which

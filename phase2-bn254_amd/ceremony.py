@@ -150,6 +150,25 @@ def eval_qap(bases, row_ptr, col, coeff):
     return out
 
 
+def eval_qap_host(bases: np.ndarray, row_ptr: np.ndarray, col: np.ndarray, coeff: np.ndarray) -> np.ndarray:
+    """eval_qap on HOST arrays (bases (n, 8|16) u64, row_ptr / col uint32, coeff (nnz, 4) u64): mi355zk_bn254_g{1,2}_sparse_matvec, which gives
+    every device of the last Worker's set a contiguous range of rows (MPCParameters::new in ONE process on N GPUs)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    coeff = np.ascontiguousarray(coeff, dtype=np.uint64)
+    g = {8: 1, 16: 2}[bases.shape[1]]
+    n_rows = row_ptr.shape[0] - 1
+    out = np.zeros((n_rows, 8 * g), dtype=np.uint64)
+    fn = _lib.load().mi355zk_bn254_g1_sparse_matvec if g == 1 else _lib.load().mi355zk_bn254_g2_sparse_matvec
+    rc = fn(out.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), bases.shape[0], row_ptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+            coeff.ctypes.data_as(C.c_void_p), n_rows, col.shape[0])
+    if rc == _lib.ERR_BAD_ARGS:
+        raise ValueError("eval_qap: a column index is out of range or row_ptr is not a CSR offset array")
+    _check(rc, "eval_qap (host buffers)")
+    return out
+
+
 def _point_fft(points, inverse: int):
     g = _group(points)
     n = points.shape[0]

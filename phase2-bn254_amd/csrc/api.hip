@@ -1946,6 +1946,90 @@ static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const
   return rc;
 }
 
+// The QAP evaluation on HOST buffers, over the device set (SURVEY 8f row 3 for a single-process caller: MPCParameters::new over a
+// 2^20+-constraint circuit): the rows of the CSR matrix are independent, so device d takes the d-th contiguous ROW range -- its slice of
+// (col, coeff), a row_ptr rebased to zero, and the WHOLE base vector (any row may name any Lagrange coefficient) -- and writes its rows
+// of the output; no exchange.  The index arrays are validated on the device as in the _dev form; row_ptr[0] == 0, row_ptr[n_rows] == nnz
+// and monotonicity across the cuts are checked here.
+template <class F>
+static int sparse_matvec_host(uint8_t* out, const uint8_t* bases, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col, const uint64_t* coeffs,
+                              size_t n_rows, size_t nnz, int group) {
+  constexpr size_t rec = sizeof(Affine<F>);
+  if (!row_ptr || (n_rows && !out) || (nnz && (!bases || !col || !coeffs)) || n_rows >= (1ull << 31) || nnz >= (1ull << 31) || n_bases >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+  if (n_rows == 0) return ZK_OK;
+  if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return ZK_ERR_BAD_ARGS;
+  std::vector<int> devs = devset_snapshot();
+  if (devs.empty()) {
+    int cur = 0;
+    ZK_HIP(hipGetDevice(&cur));
+    devs.push_back(cur);
+  }
+  size_t parts = devs.size();
+  while (parts > 1 && n_rows / parts < 128) --parts;
+  // cuts of equal WEIGHT (rows + terms: a row costs a normalisation, a term an addition chain), found by one walk over row_ptr -- the
+  // variables of a circuit are far from equally used (the constant ONE sits in most constraints)
+  std::vector<size_t> cut(parts + 1, n_rows);
+  cut[0] = 0;
+  {
+    const size_t weight = n_rows + nnz;
+    size_t d = 1;
+    for (size_t r = 0; r < n_rows && d < parts; ++r)
+      while (d < parts && r + (size_t)row_ptr[r] >= weight * d / parts) cut[d++] = r;
+  }
+  std::vector<int> rcs(parts, ZK_OK);
+  auto run_range = [&](size_t d) {
+    const size_t r0 = cut[d], r1 = cut[d + 1];
+    if (r1 == r0) return;
+    const uint32_t t0 = row_ptr[r0], t1 = row_ptr[r1];
+    if (t1 < t0) { rcs[d] = ZK_ERR_BAD_ARGS; return; }
+    const size_t rows = r1 - r0, terms = t1 - t0;
+    if (hipSetDevice(devs[d]) != hipSuccess) { rcs[d] = ZK_ERR_DEVICE; return; }
+    StageLease stage_lease;
+    HostStage* S = host_stage(devs[d], &stage_lease);
+    if (S == nullptr) { rcs[d] = ZK_ERR_DEVICE; return; }
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_bases = 0, o_out = o_bases + al((n_bases ? n_bases : 1) * rec), o_rp = o_out + al(rows * rec), o_col = o_rp + al((rows + 1) * 4),
+                 o_cf = o_col + al((terms ? terms : 1) * 4), total = o_cf + al((terms ? terms : 1) * 32);
+    DensityPool::Lease buf;
+    if (int rc = buf.acquire(devs[d], total, S->compute)) { rcs[d] = rc; return; }
+    char* base = (char*)buf.b->p;
+    std::vector<uint32_t> rp(rows + 1);
+    for (size_t r = 0; r <= rows; ++r) {
+      const uint32_t v = row_ptr[r0 + r];
+      if (v < t0 || v > t1) { rcs[d] = ZK_ERR_BAD_ARGS; return; }   // (monotone inside the range is checked on the device)
+      rp[r] = v - t0;
+    }
+    hipError_t e = hipSuccess;
+    if (n_bases) e = hipMemcpyAsync(base + o_bases, bases, n_bases * rec, hipMemcpyHostToDevice, S->compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + o_rp, rp.data(), (rows + 1) * 4, hipMemcpyHostToDevice, S->compute);
+    if (e == hipSuccess && terms) e = hipMemcpyAsync(base + o_col, col + t0, terms * 4, hipMemcpyHostToDevice, S->compute);
+    if (e == hipSuccess && terms) e = hipMemcpyAsync(base + o_cf, coeffs + (size_t)t0 * 4, terms * 32, hipMemcpyHostToDevice, S->compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(S->compute);   // (rp is a local vector)
+    if (e != hipSuccess) { rcs[d] = ZK_ERR_DEVICE; return; }
+    int rc = sparse_matvec<F>(base + o_out, base + o_bases, n_bases, (const uint32_t*)(base + o_rp), (const uint32_t*)(base + o_col), base + o_cf, rows, terms,
+                              (void*)S->compute, group);
+    if (rc != ZK_OK) { rcs[d] = rc; return; }
+    e = hipMemcpyAsync(out + r0 * rec, base + o_out, rows * rec, hipMemcpyDeviceToHost, S->compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(S->compute);
+    if (e != hipSuccess) rcs[d] = ZK_ERR_DEVICE;
+  };
+  {
+    DeviceGuard guard;
+    std::vector<std::thread> th;
+    size_t started = 1;
+    try {
+      for (; started < parts; ++started) th.emplace_back([&, started] { run_range(started); });
+    } catch (const std::exception&) {
+    }
+    run_range(0);
+    for (size_t d = started; d < parts; ++d) run_range(d);
+    for (auto& t : th) t.join();
+  }
+  for (int rc : rcs)
+    if (rc != ZK_OK) return rc;
+  return ZK_OK;
+}
+
 extern "C" {
 
 int mi355zk_init(const int* device_ids, int n_devices) {
@@ -2249,6 +2333,14 @@ int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affin
 }
 int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[16], const void* d_scalars, size_t n, void* stream) {
   return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
+}
+int mi355zk_bn254_g1_sparse_matvec(uint8_t* out_affine, const uint8_t* bases_affine, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col,
+                                   const uint64_t* coeffs, size_t n_rows, size_t nnz) {
+  return sparse_matvec_host<Fq>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 1);
+}
+int mi355zk_bn254_g2_sparse_matvec(uint8_t* out_affine, const uint8_t* bases_affine, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col,
+                                   const uint64_t* coeffs, size_t n_rows, size_t nnz) {
+  return sparse_matvec_host<Fq2>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 2);
 }
 int mi355zk_bn254_g1_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
                                        const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {

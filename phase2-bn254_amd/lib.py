@@ -82,6 +82,8 @@ SIGNATURES = {
     "mi355zk_selftest_g1_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mi355zk_selftest_g2_scalar_mul_u": (_i, [_vp, _vp, _vp]),
     "mi355zk_selftest_g2_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "mi355zk_bn254_g1_sparse_matvec": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz]),
+    "mi355zk_bn254_g2_sparse_matvec": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz]),
     "mi355zk_bn254_g1_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_bn254_g2_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_bn254_g1_decode_dev": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),

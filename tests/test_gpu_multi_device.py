@@ -287,3 +287,48 @@ def test_merge_pairs_host_at_2e23_matches_the_device_resident_call(zk, worker):
     h_rho = d_rho.cpu().numpy().view(np.uint64)
     s, sx = zk.ceremony.merge_pairs_host(h_v[:n], h_v[1:], h_rho)
     assert np.array_equal(O.G1.to_affine(s), O.G1.to_affine(want_s)) and np.array_equal(O.G1.to_affine(sx), O.G1.to_affine(want_sx))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("k", [1, 3])
+def test_qap_evaluation_on_host_buffers_over_the_device_set(zk, worker, group, k):
+    """mi355zk_bn254_g{1,2}_sparse_matvec: the per-variable sums of MPCParameters::new for a single-process caller -- every device of the set
+    takes a contiguous range of rows.  600 rows of 0 .. 6 terms (and one long row), +-1 / zero coefficients, an infinity base: the same
+    records as the device-resident call, sampled rows against the oracle; a bad column index is bad arguments from whichever range holds it."""
+    import torch
+
+    import bn254_model as M
+
+    G = O.G1 if group == 1 else O.G2
+    nb = 96
+    bases = inputs.bases_progression_cpu(group, nb, seed=4900 + group)
+    bases[7] = 0
+    rng = np.random.default_rng(4901)
+    n_rows = 600
+    row_len = rng.integers(0, 7, size=n_rows)
+    row_len[311] = 200
+    row_ptr = np.concatenate([[0], np.cumsum(row_len)]).astype(np.uint32)
+    nnz = int(row_ptr[-1])
+    col = rng.integers(0, nb, size=nnz).astype(np.uint32)
+    coeff = inputs.random_scalars(nnz, seed=4902)
+    small = rng.integers(0, 4, size=nnz)
+    coeff[small == 0] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    coeff[small == 1] = np.array(M.to_limbs(M.R_ORDER - 1), dtype=np.uint64)
+    coeff[11] = 0
+    zk.Worker(devices=[0] * k) if k > 1 else zk.Worker(0)
+    try:
+        got = zk.ceremony.eval_qap_host(bases, row_ptr, col, coeff)
+        bad_col = col.copy()
+        bad_col[nnz - 3] = nb
+        with pytest.raises(ValueError):
+            zk.ceremony.eval_qap_host(bases, row_ptr, bad_col, coeff)
+    finally:
+        zk.Worker(0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else np.int32)).cuda()  # noqa: E731
+    want = zk.ceremony.eval_qap(d(bases), d(row_ptr), d(col), d(coeff)).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    for r in list(range(0, 12)) + [199, 200, 201, 311, 399, 400, 401, n_rows - 1]:
+        acc = G.from_affine(np.zeros(G.aff, np.uint64))
+        for t in range(row_ptr[r], row_ptr[r + 1]):
+            acc = G.add(acc, G.mul(G.from_affine(bases[col[t]]), coeff[t]))
+        assert np.array_equal(got[r], G.to_affine(acc)), r
