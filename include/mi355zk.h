@@ -236,6 +236,7 @@ int mi355zk_ubench_fp_mul(int which, uint32_t blocks, uint32_t iters, const uint
 /* ---- self-test hooks: the kernels' "U-form" arithmetic (29-bit lazy limbs, csrc/fieldu.hpp, curveu.hpp)
  * compiled for the HOST, so that it can be checked against the oracle / big-int model without a GPU. */
 int mi355zk_selftest_u_mul(int which, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]);
+int mi355zk_selftest_u_mul_shoup(int which, const uint32_t a[9], const uint32_t w_plain[8], uint32_t out[9], uint32_t out_wq[9]);
 int mi355zk_selftest_u_sub(int which, int k, int s, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]);
 int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9], const uint32_t in_u[9], uint64_t out_std[4]);
 int mi355zk_selftest_u_reduce32(int which, const uint32_t in_u[9], uint64_t out_std[4]);

@@ -128,7 +128,28 @@ static int selftest_u_sub(int k, int s, const uint32_t* a, const uint32_t* b, ui
   return ZK_OK;
 }
 
+template <class PR>
+static void selftest_u_mul_shoup(const uint32_t* a, const uint32_t* w_plain, uint32_t* out, uint32_t* out_wq) {
+  zk::FpU<PR> x;
+  std::memcpy(&x, a, 36);
+  zk::Fp<PR> c;
+  std::memcpy(&c, w_plain, 32);
+  const zk::FpU<PR> w = zk::u_from_std(c), wq = zk::u_shoup_quotient<PR>(c.l);
+  const zk::FpU<PR> r = zk::u_mul_shoup(x, w, wq);
+  std::memcpy(out, &r, 36);
+  std::memcpy(out_wq, &wq, 36);
+}
+
 extern "C" {
+
+// the product by a table constant (fieldu.hpp u_mul_shoup): a on 9 u32 limbs, w_plain the canonical integer w < p on 8 x 32-bit words;
+// out = a * w - q * p (N-form, < 2p for a < 160p), out_wq = floor(w * 2^261 / p) on 9 limbs
+int mi355zk_selftest_u_mul_shoup(int which, const uint32_t a[9], const uint32_t w_plain[8], uint32_t out[9], uint32_t out_wq[9]) {
+  if (!a || !w_plain || !out || !out_wq) return ZK_ERR_BAD_ARGS;
+  if (which == 0) selftest_u_mul_shoup<zk::FqParams>(a, w_plain, out, out_wq);
+  else selftest_u_mul_shoup<zk::FrParams>(a, w_plain, out, out_wq);
+  return ZK_OK;
+}
 
 // a, b, out: 9 u32 limbs (radix 2^29).  which: 0 Fq, 1 Fr.  out = a*b*2^-261 mod p (N-form, lazily reduced)
 int mi355zk_selftest_u_mul(int which, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {

@@ -388,6 +388,101 @@ ZK_HD FpU<PR> u_mul4(const FpU<PR>& a, const FpU<PR>& b, const FpU<PR>& c, const
   });
 }
 
+// ---- product by a CONSTANT with a precomputed quotient (Shoup / Barrett with the quotient of the constant) ----
+// For a constant w < p let wq = floor(w * 2^261 / p).  Then q = floor(a * wq / 2^261) is at most 1 + a / 2^261 (+ 1 for the
+// truncation below) short of floor(a * w / p), and  r = a * w - q * p  needs only the LOW nine limbs of the two products
+// (r < 2^261): 45 + 45 mads, plus 53 for the high half of a * wq -- 143 v_mad_u64_u32 against the 171 + 9 v_mul_lo_u32 of the
+// Montgomery product, no serial m_i chain, and no factor 2^-261: the value is a * w itself, so data in the memory format's 2^256
+// domain stays there with PLAIN constants.  The NTT multiplies by table twiddles only (ntt.hip).
+//   PB = 2^261 - p, so that  a * w - q * p == a * w + q * PB  (mod 2^261)  is one accumulation without signs.
+template <class PR>
+struct UShoup {
+  static constexpr uint32_t PB(int i) { return i == 0 ? (1u << U_BITS) - UParams<PR>::P(0) : U_MASK - UParams<PR>::P(i); }   // P(0) is odd: no carry out of limb 0
+};
+
+// a * w mod p (no Montgomery factor) for a table constant (w, wq).
+//   preconditions: w canonical (< p) in N-form, wq = floor(w * 2^261 / p) in N-form with l[8] < 2^29;  limbs of a < 2^31
+//                  (columns: 9 * 2^60 + 9 * 2^58 + carry < 2^64);  value(a) < 160 p (< 0.94 * 2^261).
+//   result: N-form (l[8] < 2^23), value = a * w - q * p with floor(a w / p) - 1 - a / 2^261 - 2^-20 < q <= floor(a w / p):
+//           0 <= value < (2 + a / 2^261) p, and since value and q are integers with value == a w (mod p):  value < 2p whenever a < 160p.
+//   (the columns 0 .. 6 of a * wq are dropped: their sum is < 7 * 2^60 * 2^174 * 1.01 < 2^238, i.e. below 2^-23 of 2^261)
+template <class PR>
+ZK_HD FpU<PR> u_mul_shoup(const FpU<PR>& a, const FpU<PR>& w, const FpU<PR>& wq) {
+  uint32_t q[9];
+  uint64_t acc = 0;
+  for_limbs<10>([&](auto kc) {
+    constexpr int k = 7 + decltype(kc)::value;                              // columns 7 .. 16 of a * wq
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) u_mad(acc, a.l[i], wq.l[j]);
+    });
+    if constexpr (k >= 9) q[k - 9] = (uint32_t)acc & U_MASK;
+    acc >>= U_BITS;
+  });
+  q[8] = (uint32_t)acc;                                                     // column 17: the carry (a * wq < 2^261 * 2^261)
+  FpU<PR> r;
+  acc = 0;
+  for_limbs<9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) u_mad(acc, a.l[i], w.l[j]);
+    });
+    for_limbs<9>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int j = k - i;
+      if constexpr (j >= 0 && j < 9) {
+        constexpr uint32_t pb = UShoup<PR>::PB(j);
+        u_mad(acc, q[i], pb);
+      }
+    });
+    r.l[k] = (uint32_t)acc & U_MASK;                                        // (k == 8: mod 2^261; the value is < 2p < 2^255)
+    acc >>= U_BITS;
+  });
+  return r;
+}
+
+// wq = floor(w * 2^261 / p) for a canonical w given as the plain integer on 8 x 32-bit words (NOT a Montgomery form): restoring
+// division, one quotient bit per round.  Table builders and the host only (~10^4 instructions).
+template <class PR>
+ZK_HD FpU<PR> u_shoup_quotient(const uint32_t w_plain[8]) {
+  uint32_t rem[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rem[i] = w_plain[i];
+  FpU<PR> q;
+  for_limbs<9>([&](auto lc) {                                               // bits 260 .. 0, limb by limb (static limb index)
+    constexpr int limb = 8 - decltype(lc)::value;
+    uint32_t ql = 0;
+    for (int b = 28; b >= 0; --b) {
+      uint32_t carry = 0;                                                   // rem = 2 rem  (rem < p < 2^254: no carry out)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t nc = rem[i] >> 31;
+        rem[i] = (rem[i] << 1) | carry;
+        carry = nc;
+      }
+      uint32_t d[8];
+      uint32_t borrow = 0;
+      for_limbs<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr uint32_t pi = PR::P[i];
+        const uint64_t t = (uint64_t)rem[i] - pi - borrow;
+        d[i] = (uint32_t)t;
+        borrow = (uint32_t)(t >> 32) & 1u;
+      });
+      if (!borrow) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rem[i] = d[i];
+        ql |= 1u << b;
+      }
+    }
+    q.l[limb] = ql;
+  });
+  return q;
+}
+
 // value == 0 mod p for an N-form value < 2p  (i.e. value in {0, p})
 template <class PR>
 ZK_HD bool u_is_zero_lt2p(const FpU<PR>& a) {

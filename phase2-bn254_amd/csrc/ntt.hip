@@ -8,18 +8,20 @@
 //
 // Algorithm (not the reference's): a size-N transform is factored N = N_1 * ... * N_R (R <= 3,
 // N_p <= 4096, normally 1024) Cooley-Tukey style.  Pass p transforms digit p of the index for G adjacent
-// "columns" at once: a workgroup stages a G x N_p tile (<= 4096 elements) in LDS as NINE 29-bit limb
-// planes (U-form, fieldu.hpp; unit-stride lanes -> conflict-free ds_read_b32), runs log2(N_p) DIT stages
+// "columns" at once: a workgroup stages a G x N_p tile (<= 4096 elements) in LDS on nine 29-bit limbs per
+// element (U-form, fieldu.hpp; element-major, see lds_load), runs log2(N_p) DIT stages
 // there, multiplies by the inter-pass twiddle omega^(T_p*k_p*rest) and writes back in the 32-byte
 // memory format.  The last pass writes straight to the natural-order position (fused digit reversal),
 // with the G tile rows chosen so that both its loads and its stores are >= 128-byte contiguous.
 // distribute_powers (coset) is fused into the first pass's load, the 1/m and g^-k scalings into the
 // last pass's store.  HBM traffic: 64 B per element per pass (R passes) -- DESIGN.md "NTT".
 //
-// U-form bookkeeping (fieldu.hpp): data stays in the memory format's 2^256 domain the whole time --
-// u_mul(data, tw) with the twiddle tables kept in the 2^261 domain returns data*tw in the 2^256
-// domain -- so loads and stores only re-pack bits.  DIT butterflies (a + w b, a - w b) grow values
-// linearly: V_s <= V_0 + 2 s p <= 24p after 10 stages, far below u_mul's 2^261-related limits; limbs
+// U-form bookkeeping (fieldu.hpp): data stays in the memory format's 2^256 domain the whole time -- every
+// product is by a table twiddle, kept as the PLAIN integer w with its quotient floor(w 2^261 / p), and
+// u_mul_shoup(data, w, wq) returns data*w itself, below 2p (round 4; rounds 1-3: Montgomery products by
+// twiddles in the 2^261 domain, 180 multiplier instructions against 143) -- so loads and stores only
+// re-pack bits.  DIT butterflies (a + w b, a - w b) grow values linearly: V_s <= V_0 + 2 s p <= 24p after
+// 10 stages (30p with the skipped twiddle-one products), far below the 160p the product admits; limbs
 // are carried every 4th stage (the bound of each call is noted at the call).
 // The mathematical result X[k] = sum_i a[i] w^(ik) is unique and the stored elements are fully
 // reduced, so the output bytes are identical to serial_fft's.
@@ -27,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -66,19 +69,45 @@ struct NttPassParams {
   uint32_t in_u, out_u;     // the source / destination is the inter-pass scratch in U-FORM: nine 29-bit limbs, 36 B per element, value < 2p (experiment, round 4)
 };
 
-// table entry: U-form element in the 2^261 domain, padded to 48 B for three 16-byte loads
-struct alignas(16) UTab {
-  uint32_t l[12];
+// table entry (round 4): a twiddle as the PLAIN canonical integer w on nine 29-bit limbs followed by wq = floor(w * 2^261 / p) --
+// the constant and its quotient of fieldu.hpp's u_mul_shoup -- 72 B, 8-byte aligned (padding the entry to 80 B for aligned 16-byte
+// loads measured 0.5-1 % slower: tools/ab_ntt_shoup.sh).  (Rounds 1-3: w * 2^261 mod p for the Montgomery product, 48 B.)
+struct alignas(8) UTab {
+  uint32_t l[18];
+};
+struct TwU {
+  FrU w, q;
 };
 
-__device__ __forceinline__ FrU tab_load(const UTab* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1], c = q[2];
-  FrU r;
-  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  r.l[8] = c.x;
+__device__ __forceinline__ TwU tab_load(const UTab* p) {
+  const uint2* s = reinterpret_cast<const uint2*>(p);   // (hipcc merges neighbours into 16-byte loads where the address allows)
+  uint32_t v[18];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint2 t = s[i];
+    v[2 * i] = t.x;
+    v[2 * i + 1] = t.y;
+  }
+  TwU r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { r.w.l[i] = v[i]; r.q.l[i] = v[9 + i]; }
   return r;
+}
+// x * (the table constant): the value itself (no Montgomery factor), < 2p for x < 160p with limbs < 2^31
+__device__ __forceinline__ FrU tw_mul(const FrU& x, const TwU& t) { return u_mul_shoup(x, t.w, t.q); }
+
+// entry for the plain canonical integer c (8 x 32-bit words)
+ZK_HD TwU tw_make(const Fr& c_plain) {
+  TwU t;
+  t.w = u_from_std(c_plain);
+  t.q = u_shoup_quotient<FrParams>(c_plain.l);
+  return t;
+}
+__device__ __forceinline__ void tab_store(UTab* p, const TwU& t) {
+  UTab e;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { e.l[i] = t.w.l[i]; e.l[9 + i] = t.q.l[i]; }
+  *p = e;
 }
 
 // LDS layout of a tile (round 4): ELEMENT-major, nine consecutive words per element.  The stride of 9 words is odd, so lanes with
@@ -153,7 +182,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
                                                               const UTab* __restrict__ roots, const UTab* __restrict__ twA,
                                                               const UTab* __restrict__ twB, const UTab* __restrict__ preA,
                                                               const UTab* __restrict__ preB, const UTab* __restrict__ postA,
-                                                              const UTab* __restrict__ postB, FrU post_c, const UTab* __restrict__ twF) {
+                                                              const UTab* __restrict__ postB, TwU post_c, const UTab* __restrict__ twF) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr uint32_t np = 1u << LOG_NP;
   // twiddle-one products are skipped in stages 0 .. SKIP_MAX: rows longer than 2^10 give up stage 2 (a skipped stage doubles the
@@ -180,8 +209,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     const uint64_t gi = in_base + x * P.in_xs + g * P.in_gs;
     FrU v = P.in_u ? uload(in, gi) : u_from_std(gload(in + gi));           // < p (< 2p from a U-form scratch), N
     if (P.pre) {                                                          // distribute_powers (domain.rs:176-189)
-      FrU w = u_mul(tab_load(preA + (gi >> P.pre_h)), tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));  // g^i, < 2p
-      v = u_mul(v, w);                                                    // < 2p, N
+      v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));                    // g^i = A[i >> h] * B[i & mask]: two products by constants
+      v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));     // < 2p, N
     }
     lds_store(lds, plane, g * pitch + swz(bitrev(x, LOG_NP)), v);
   }
@@ -196,10 +225,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   // Bounds with skipping: a skipped product leaves t as large as u, so values DOUBLE on that path: V_1 < 4p, V_2 < 8p, V_3 < 16p, and
   // with + 2p for each of the stages 3..9: < 30p at the end (u_to_std_lt32p / the closing product allow < 32p); the subtraction
   // constant follows (u_sub<4,1> / <8,1>).  Stage 3 is not skipped: it would take the bound past 32p.
-  auto bf = [&](auto stc, FrU& u, FrU& t, const FrU& w, bool skip) {
+  auto bf = [&](auto stc, FrU& u, FrU& t, const TwU& w, bool skip) {
     constexpr uint32_t ST = (uint32_t) decltype(stc)::value;
     // (t < 24p with limbs < 4*2^29 either way: the skipped product only leaves t as large as u may be)
-    if (!skip) t = u_mul(t, w);                                            // limbs < 4*2^29 times N: ok; < 2p, N
+    if (!skip) t = tw_mul(t, w);                                           // limbs < 4*2^29, < 30p: ok; < 2p, N
     else t = u_carry(t);
     FrU sum = u_add(u, t);                                                 // limbs grow by 2^29, value by 2p
     if constexpr ((ST & 3) == 3) sum = u_carry(sum);
@@ -217,7 +246,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       const uint32_t g = b >> (LOG_NP - 1), x0 = (b & ((np >> 1) - 1)) << 1;
       const uint32_t i0 = g * pitch + swz(x0), i1 = g * pitch + swz(x0 + 1);
       FrU u = lds_load(lds, plane, i0), t = lds_load(lds, plane, i1);
-      bf(std::integral_constant<int, 0>{}, u, t, u, true);
+      bf(std::integral_constant<int, 0>{}, u, t, TwU{u, u}, true);
       lds_store(lds, plane, i0, u);
       lds_store(lds, plane, i1, t);
     }
@@ -249,19 +278,19 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       FrU a = lds_load(lds, plane, ia), b = lds_load(lds, plane, ib), c = lds_load(lds, plane, ic), d = lds_load(lds, plane, id);
       const bool one = s <= SKIP_MAX && j == 0;                            // stage s (s == 0: j == 0 always)
       {
-        FrU w1 = a;
+        TwU w1{a, a};
         if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));
         bf(std::integral_constant<int, (int)s>{}, a, b, w1, one);
         bf(std::integral_constant<int, (int)s>{}, c, d, w1, one);
       }
       const bool one2 = s + 1 <= SKIP_MAX && j == 0;                       // stage s + 1, pair (a, c): index j
       {
-        FrU w2 = a;
+        TwU w2{a, a};
         if (!one2) w2 = tab_load(roots + ((uint64_t)j << (LOG_NP - 2 - s)));
         bf(std::integral_constant<int, (int)s + 1>{}, a, c, w2, one2);
       }
       {
-        const FrU w3 = tab_load(roots + ((uint64_t)(j + m) << (LOG_NP - 2 - s)));   // pair (b, d): index j + m, never zero
+        const TwU w3 = tab_load(roots + ((uint64_t)(j + m) << (LOG_NP - 2 - s)));   // pair (b, d): index j + m, never zero
         bf(std::integral_constant<int, (int)s + 1>{}, b, d, w3, false);
       }
       lds_store(lds, plane, ia, a);
@@ -305,7 +334,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       FrU u = lds_load(lds, plane, i0);
       FrU t = lds_load(lds, plane, i1);
       // (t < 24p with limbs < 4*2^29 either way: the skipped product only leaves t as large as u may be)
-      if (s != 0 && !(j_slow && j == 0)) t = u_mul(t, tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s))));  // limbs < 4*2^29 times N: ok; < 2p, N
+      if (s != 0 && !(j_slow && j == 0)) t = tw_mul(t, tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s))));  // limbs < 4*2^29, < 30p: ok; < 2p, N
       else t = u_carry(t);                                                // w = 1 (stage 0; j == 0): no product
       FrU sum = u_add(u, t);                                              // limbs grow by 2^29, value by 2p
       if (carry_now) sum = u_carry(sum);
@@ -324,52 +353,45 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     uint32_t g = e % P.g, k = e / P.g;
     FrU v = lds_load(lds, plane, g * pitch + swz(k));                     // < 30p, limbs < 4*2^29
     const uint64_t go = out_base + k * P.out_xs + g * P.out_gs;
-    FrU w;
+    TwU w;
     if (P.tw_full) {
       w = tab_load(twF + go);                                             // w^(k * col), streamed: one product instead of two
     } else if (P.tw_mul != 0) {
       uint64_t ex = P.tw_mul * k * (lo * P.g + g);
-      w = u_mul(tab_load(twA + (ex >> P.tw_h)), tab_load(twB + (ex & ((1ull << P.tw_h) - 1))));
+      v = tw_mul(v, tab_load(twA + (ex >> P.tw_h)));                      // w^ex = A[ex >> h] * B[ex & mask]
+      w = tab_load(twB + (ex & ((1ull << P.tw_h) - 1)));
     } else if (P.post == 2) {                                             // minv * ginv^k (icoset_fft, domain.rs:197-203)
-      w = u_mul(tab_load(postA + (go >> P.post_h)), tab_load(postB + (go & ((1ull << P.post_h) - 1))));
-      w = u_mul(w, post_c);
+      v = tw_mul(v, tab_load(postA + (go >> P.post_h)));
+      v = tw_mul(v, tab_load(postB + (go & ((1ull << P.post_h) - 1))));
+      w = post_c;
     } else if (P.post == 3) {                                             // plain fft / coset_fft: nothing to multiply by --
       gstore(out + go, u_to_std_lt32p(u_carry(v)));                       // reduce the < 24p value directly
       continue;
     } else {
       w = post_c;                                                         // minv (ifft, domain.rs:163-173)
     }
-    const FrU prod = u_mul(v, w);                                          // 30 * 2 * 0.006 + 1 < 2p
+    const FrU prod = tw_mul(v, w);                                         // v < 30p, limbs < 4*2^29: < 2p
     if (P.out_u) ustore(out, go, prod);                                    // the next pass takes it as it is
     else gstore(out + go, u_to_std_lt2p(prod));
   }
 }
 
-// tab[j] = base^(j * step) in U-form, 2^261 domain:  u_mul(x * 2^256, 2^266) = x * 2^261
+// tab[j] = base^(j * step): the plain integer and its quotient (UTab)
 __global__ void ntt_pow_table_kernel(UTab* tab, Fr base, uint64_t step, uint64_t count) {
   uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
-  FrU u = u_mul(u_from_std(pow_u64(base, j * step)), UPow2<FrParams, 266>::get());
-  UTab t;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) t.l[i] = u.l[i];
-  t.l[9] = t.l[10] = t.l[11] = 0;
-  tab[j] = t;
+  tab_store(tab + j, tw_make(to_canonical(pow_u64(base, j * step))));
 }
 
 // The inter-pass twiddles of a two-pass transform N = N_1 * S, laid out like the first pass's OUTPUT: full[k * S + col] = w^(k * col)
-// (k < N_1, col < S), U-form, 2^261 domain -- from the two-level table w^e = A[e >> h] * B[e & mask].
+// (k < N_1, col < S), entries like every table's (UTab) -- from the two-level table w^e = A[e >> h] * B[e & mask].
 __global__ void ntt_full_twiddle_kernel(UTab* __restrict__ full, const UTab* __restrict__ A, const UTab* __restrict__ B, uint32_t h,
                                         uint32_t log_s, uint64_t count) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const uint64_t k = i >> log_s, col = i & ((1ull << log_s) - 1), ex = k * col;
-  const FrU w = u_mul(tab_load(A + (ex >> h)), tab_load(B + (ex & ((1ull << h) - 1))));  // < 2p, N: what the pass computed per element before
-  UTab t;
-#pragma unroll
-  for (int l = 0; l < 9; ++l) t.l[l] = w.l[l];
-  t.l[9] = t.l[10] = t.l[11] = 0;
-  full[i] = t;
+  const FrU w = tw_mul(tab_load(A + (ex >> h)).w, tab_load(B + (ex & ((1ull << h) - 1))));  // < 2p, N
+  tab_store(full + i, tw_make(u_to_std_lt2p(w)));                                           // canonical, and its quotient
 }
 
 // a[i] *= c * gA[i >> h] * gB[i & mask]   (gA == nullptr: a[i] *= c);  c in the memory format
@@ -377,9 +399,9 @@ __global__ void ntt_scale_kernel(Fr* a, uint64_t n, Fr c, const UTab* __restrict
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   FrU v = u_from_std(gload(a + i));
-  FrU w = u_mul(u_from_std(c), UPow2<FrParams, 266>::get());            // c * 2^261
-  if (gA != nullptr) w = u_mul(w, u_mul(tab_load(gA + (i >> h)), tab_load(gB + (i & ((1ull << h) - 1)))));
-  gstore(a + i, u_to_std_lt2p(u_mul(v, w)));
+  v = u_mul(v, u_mul(u_from_std(c), UPow2<FrParams, 266>::get()));      // (c is a Montgomery form: c * 2^261, then the Montgomery product) < 2p
+  if (gA != nullptr) v = tw_mul(tw_mul(v, tab_load(gA + (i >> h))), tab_load(gB + (i & ((1ull << h) - 1))));
+  gstore(a + i, u_to_std_lt2p(v));
 }
 
 struct Key {
@@ -402,7 +424,7 @@ struct PowTables {
   UTab* A = nullptr;
   UTab* B = nullptr;
   UTab* roots[NTT_MAX_LOG_NP + 1] = {};  // roots[b][x] = (w^(N/2^b))^x, x < 2^(b-1)
-  UTab* full = nullptr;    // two-pass transforms up to NTT_FULL_TW_MAX_LOG: w^(k * col) at the first pass's output position (48 B per element)
+  UTab* full = nullptr;    // two-pass transforms up to NTT_FULL_TW_MAX_LOG: w^(k * col) at the first pass's output position (72 B per element)
   uint32_t full_log_s = 0;
 };
 // Measured (round 3): 2^20 fft 0.1507 -> 0.1456 ms with the table (one product less per element of the first pass, 50 MB more to
@@ -546,7 +568,17 @@ void ntt_release_all() {
 
 int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st);
 
-static FrU to_u261(const Fr& x) { return u_mul(u_from_std(x), UPow2<FrParams, 266>::get()); }  // host: x*2^256 -> x*2^261
+// host: a Montgomery form -> the plain integer and its quotient.  The quotient is a 261-round division (~10 us on the host): the few
+// scale factors a process uses (1/m per domain size) are kept.  Called under g_run_mu.
+static TwU to_tw(const Fr& x) {
+  static std::vector<std::pair<Fr, TwU>> memo;
+  for (const auto& e : memo)
+    if (std::memcmp(&e.first, &x, sizeof(Fr)) == 0) return e.second;
+  const TwU t = tw_make(to_canonical(x));
+  if (memo.size() >= 64) memo.clear();
+  memo.emplace_back(x, t);
+  return t;
+}
 
 // d_a: 2^log_n Fr elements on the current device, in place:
 //   a[i] *= pre_g^i (if pre_g)  ->  X[k] = sum_i a[i] * omega^(i*k)  ->  X[k] *= post_c * post_g^k (if given).
@@ -586,7 +618,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   PowTables* Tpost = nullptr;
   if (pre_g) { rc = build_pow_tables(st, log_n, *pre_g, false, nullptr, 0, &Tpre); if (rc) return rc; }
   if (post_g) { rc = build_pow_tables(st, log_n, *post_g, false, nullptr, 0, &Tpost); if (rc) return rc; }
-  const FrU post_cu = to_u261(post_c ? *post_c : Fr::one());
+  const TwU post_cu = post_c ? to_tw(*post_c) : (post_g ? to_tw(Fr::one()) : TwU{FrU::zero(), FrU::zero()});   // (neither: post == 3 multiplies by nothing)
   static const int slot_pass = prof_slot("ntt_pass");
 
   Fr* scratch = nullptr;

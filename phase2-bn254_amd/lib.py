@@ -76,6 +76,7 @@ SIGNATURES = {
     "mi355zk_selftest_glv2_split": (_i, [_vp, _vp]),
     "mi355zk_selftest_g2_psi": (_i, [_vp, _vp]),
     "mi355zk_selftest_u_mul": (_i, [_i, _vp, _vp, _vp]),
+    "mi355zk_selftest_u_mul_shoup": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mi355zk_selftest_u_sub": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "mi355zk_selftest_u_pack": (_i, [_i, _vp, _vp, _vp, _vp]),
     "mi355zk_selftest_u_reduce32": (_i, [_i, _vp, _vp]),

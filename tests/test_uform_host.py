@@ -69,6 +69,34 @@ def test_u_mul(lib, which, p):
 
 
 @pytest.mark.parametrize("which,p", MODS)
+def test_u_mul_by_a_constant_with_its_quotient(lib, which, p):
+    """u_mul_shoup (the NTT's product by a table twiddle): the plain product a * w reduced with the precomputed quotient floor(w 2^261 / p);
+    operands as loose as the stage code feeds it (values up to 160p, limbs up to 2^31), the result below 2p in N-form."""
+    edge_w = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 1 << 253, (1 << 29) - 1]
+    for trial in range(400):
+        vw = edge_w[trial] if trial < len(edge_w) else rnd.randrange(p)
+        bound = (160 * p, 30 * p, 2 * p, p)[trial % 4]
+        va = rnd.randrange(bound) if trial % 7 else bound - 1
+        a = _u32(redundant(va, 2) if trial % 2 else limbs29(va))
+        w = np.array([(vw >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+        out, wq = np.zeros(9, np.uint32), np.zeros(9, np.uint32)
+        assert lib.mi355zk_selftest_u_mul_shoup(which, a.ctypes.data, w.ctypes.data, out.ctypes.data, wq.ctypes.data) == 0
+        assert val(wq) == (vw << 261) // p and all(int(x) <= MASK for x in wq)
+        r = val(out)
+        assert r % p == va * vw % p
+        assert r < 2 * p and all(int(x) <= MASK for x in out[:8])
+        q = (va * vw - r) // p
+        assert va * vw // p - 2 <= q <= va * vw // p
+    # the widest limbs the columns admit: every limb of a at 2^31 - 1
+    a = _u32([(1 << 31) - 1] * 8 + [(100 * p) >> 232])
+    vw = p - 1
+    w = np.array([(vw >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+    out, wq = np.zeros(9, np.uint32), np.zeros(9, np.uint32)
+    lib.mi355zk_selftest_u_mul_shoup(which, a.ctypes.data, w.ctypes.data, out.ctypes.data, wq.ctypes.data)
+    assert val(out) % p == val(a) * vw % p and val(out) < 2 * p
+
+
+@pytest.mark.parametrize("which,p", MODS)
 @pytest.mark.parametrize("k,s", [(1, 1), (2, 1), (4, 1), (4, 2), (4, 3), (8, 1)])
 def test_u_sub(lib, which, p, k, s):
     for _ in range(200):
