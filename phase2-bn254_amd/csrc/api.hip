@@ -1529,6 +1529,17 @@ std::vector<int> devset_snapshot() {
   return g_devset;
 }
 
+// a cell / range / worker body run so that nothing is thrown out of a host thread or across the C ABI (std::bad_alloc from a
+// staging vector, a std::system_error from a lock): the unit fails as a device error
+template <class Fn>
+void run_guarded(int& rc, Fn&& fn) noexcept {
+  try {
+    fn();
+  } catch (...) {
+    rc = ZK_ERR_DEVICE;
+  }
+}
+
 struct DeviceGuard {  // the calling thread's current device is its own business: restore it
   int prev = -1;
   DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
@@ -1612,12 +1623,12 @@ int msm_host_multi(const std::vector<int>& devs, const uint8_t* bases, size_t n_
     std::vector<std::thread> th;
     size_t started = 1;
     try {
-      for (; started < cells.size(); ++started) th.emplace_back([&, started] { run_cell(cells[started]); });
+      for (; started < cells.size(); ++started) th.emplace_back([&, started] { run_guarded(cells[started].rc, [&] { run_cell(cells[started]); }); });
     } catch (const std::exception&) {
       // (no more host threads to be had: the cells that did not get one run here, one after the other -- nothing is thrown across the C ABI)
     }
-    if (!cells.empty()) run_cell(cells[0]);
-    for (size_t i = started; i < cells.size(); ++i) run_cell(cells[i]);
+    if (!cells.empty()) run_guarded(cells[0].rc, [&] { run_cell(cells[0]); });
+    for (size_t i = started; i < cells.size(); ++i) run_guarded(cells[i].rc, [&] { run_cell(cells[i]); });
     for (auto& t : th) t.join();
   }
   // ---- the join.  Device failures first, then a non-canonical exponent (bad arguments: the single-device call reports it before
@@ -1755,11 +1766,11 @@ int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, 
     std::vector<std::thread> th;
     size_t started = 1;
     try {
-      for (; started < parts; ++started) th.emplace_back([&, started] { run_range(started); });
+      for (; started < parts; ++started) th.emplace_back([&, started] { run_guarded(rcs[started], [&] { run_range(started); }); });
     } catch (const std::exception&) {
     }
-    run_range(0);
-    for (size_t d = started; d < parts; ++d) run_range(d);
+    run_guarded(rcs[0], [&] { run_range(0); });
+    for (size_t d = started; d < parts; ++d) run_guarded(rcs[d], [&] { run_range(d); });
     for (auto& t : th) t.join();
   }
   for (int rc : rcs)
@@ -1843,10 +1854,10 @@ int dense_host(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t
       std::vector<std::thread> th;
       size_t started = 1;
       try {
-        for (; started < workers; ++started) th.emplace_back([&, started] { work(started); });
+        for (; started < workers; ++started) th.emplace_back([&, started] { run_guarded(parts[started].rc, [&] { work(started); }); });
       } catch (const std::exception&) {
       }
-      work(0);   // (a worker takes pieces until none is left: the ones that got no thread are covered by the others)
+      run_guarded(parts[0].rc, [&] { work(0); });   // (a worker takes pieces until none is left: the ones that got no thread are covered by the others)
       for (auto& t : th) t.join();
     }
     for (auto& pt : parts) {
@@ -2018,11 +2029,11 @@ static int sparse_matvec_host(uint8_t* out, const uint8_t* bases, size_t n_bases
     std::vector<std::thread> th;
     size_t started = 1;
     try {
-      for (; started < parts; ++started) th.emplace_back([&, started] { run_range(started); });
+      for (; started < parts; ++started) th.emplace_back([&, started] { run_guarded(rcs[started], [&] { run_range(started); }); });
     } catch (const std::exception&) {
     }
-    run_range(0);
-    for (size_t d = started; d < parts; ++d) run_range(d);
+    run_guarded(rcs[0], [&] { run_range(0); });
+    for (size_t d = started; d < parts; ++d) run_guarded(rcs[d], [&] { run_range(d); });
     for (auto& t : th) t.join();
   }
   for (int rc : rcs)
@@ -2033,294 +2044,382 @@ static int sparse_matvec_host(uint8_t* out, const uint8_t* bases, size_t n_bases
 extern "C" {
 
 int mi355zk_init(const int* device_ids, int n_devices) {
-  if (n_devices < 0 || (n_devices > 0 && device_ids == nullptr)) return ZK_ERR_BAD_ARGS;
-  int count = 0;
-  ZK_HIP(hipGetDeviceCount(&count));
-  auto check = [](int dev) -> int {
-    hipDeviceProp_t prop;
-    ZK_HIP(hipGetDeviceProperties(&prop, dev));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-      std::fprintf(stderr, "[mi355zk] device %d is %s; this library contains gfx950 code only\n", dev, prop.gcnArchName);
-      return ZK_ERR_DEVICE;
-    }
-    return ZK_OK;
-  };
-  for (int i = 0; i < n_devices; ++i)
-    if (device_ids[i] < 0 || device_ids[i] >= count) return ZK_ERR_BAD_ARGS;
-  if (n_devices > 0) ZK_HIP(hipSetDevice(device_ids[0]));
-  int dev = 0;
-  ZK_HIP(hipGetDevice(&dev));
-  // the LAST call defines the device set: more than one id = the single-process multi-GPU mode of the host-buffer multiexps
-  // (msm_host_multi), one id or none = one device, as before
-  std::vector<int> set;
-  if (n_devices > 1) set.assign(device_ids, device_ids + n_devices);
-  int rc = ZK_OK;
-  if (set.empty()) {
-    rc = check(dev);
-    if (rc == ZK_OK) rc = ntt_configure();
-  } else {
-    for (size_t i = 0; i < set.size() && rc == ZK_OK; ++i) {
-      bool seen = false;
-      for (size_t k = 0; k < i; ++k) seen = seen || set[k] == set[i];
-      if (seen) continue;
-      rc = check(set[i]);
-      if (rc == ZK_OK && hipSetDevice(set[i]) != hipSuccess) rc = ZK_ERR_DEVICE;
+  return abi_guard([&]() -> int {
+    if (n_devices < 0 || (n_devices > 0 && device_ids == nullptr)) return ZK_ERR_BAD_ARGS;
+    int count = 0;
+    ZK_HIP(hipGetDeviceCount(&count));
+    auto check = [](int dev) -> int {
+      hipDeviceProp_t prop;
+      ZK_HIP(hipGetDeviceProperties(&prop, dev));
+      if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "[mi355zk] device %d is %s; this library contains gfx950 code only\n", dev, prop.gcnArchName);
+        return ZK_ERR_DEVICE;
+      }
+      return ZK_OK;
+    };
+    for (int i = 0; i < n_devices; ++i)
+      if (device_ids[i] < 0 || device_ids[i] >= count) return ZK_ERR_BAD_ARGS;
+    if (n_devices > 0) ZK_HIP(hipSetDevice(device_ids[0]));
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    // the LAST call defines the device set: more than one id = the single-process multi-GPU mode of the host-buffer multiexps
+    // (msm_host_multi), one id or none = one device, as before
+    std::vector<int> set;
+    if (n_devices > 1) set.assign(device_ids, device_ids + n_devices);
+    int rc = ZK_OK;
+    if (set.empty()) {
+      rc = check(dev);
       if (rc == ZK_OK) rc = ntt_configure();
+    } else {
+      for (size_t i = 0; i < set.size() && rc == ZK_OK; ++i) {
+        bool seen = false;
+        for (size_t k = 0; k < i; ++k) seen = seen || set[k] == set[i];
+        if (seen) continue;
+        rc = check(set[i]);
+        if (rc == ZK_OK && hipSetDevice(set[i]) != hipSuccess) rc = ZK_ERR_DEVICE;
+        if (rc == ZK_OK) rc = ntt_configure();
+      }
+      (void)hipSetDevice(dev);
     }
-    (void)hipSetDevice(dev);
-  }
-  if (rc != ZK_OK) return rc;
-  std::lock_guard<std::mutex> lk(g_devset_mu);
-  g_devset = set;
-  return ZK_OK;
+    if (rc != ZK_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_devset_mu);
+    g_devset = set;
+    return ZK_OK;
+  });
 }
 int mi355zk_visible_devices(void) {
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return count;
+  return abi_guard([&]() -> int {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count;
+  });
 }
 int mi355zk_device_count(void) {
-  std::lock_guard<std::mutex> lk(g_devset_mu);
-  return g_devset.empty() ? 1 : (int)g_devset.size();
+  return abi_guard([&]() -> int {
+    std::lock_guard<std::mutex> lk(g_devset_mu);
+    return g_devset.empty() ? 1 : (int)g_devset.size();
+  });
 }
 
 void mi355zk_shutdown(void) {
-  ntt_release_all();
-  exp_scratch_release_all();
-  mul_slots_release_all();
-  host_entry_release_all();
-  msm_release_g1();
-  msm_release_g2();
+  abi_guard_void([&] {
+    ntt_release_all();
+    exp_scratch_release_all();
+    mul_slots_release_all();
+    host_entry_release_all();
+    msm_release_g1();
+    msm_release_g2();
+  });
 }
 
 const char* mi355zk_version(void) { return "mi355zk 0.3 (gfx950)"; }
 
-int mi355zk_bases_cache_pin(const void* host_bases, size_t n_bases, int group) { return bases_cache_pin(host_bases, n_bases, group); }
-int mi355zk_bases_cache_pin_tables(const void* host_bases, size_t n_bases, int group) { return bases_cache_pin(host_bases, n_bases, group, true); }
+int mi355zk_bases_cache_pin(const void* host_bases, size_t n_bases, int group) { return abi_guard([&]() -> int { return bases_cache_pin(host_bases, n_bases, group); }); }
+int mi355zk_bases_cache_pin_tables(const void* host_bases, size_t n_bases, int group) { return abi_guard([&]() -> int { return bases_cache_pin(host_bases, n_bases, group, true); }); }
 int mi355zk_bases_cache_info(const void* host_bases, size_t* device_bytes, size_t* table_bytes) {
-  size_t d = 0, t = 0;
-  int found = 0;
-  {
-    std::lock_guard<std::mutex> lk(g_bc_mu);
-    for (auto& e : g_bc)
-      if (e->host == host_bases && e->ready) { d += e->bytes; t += e->table_bytes; found = 1; }
-  }
-  if (device_bytes) *device_bytes = d;
-  if (table_bytes) *table_bytes = t;
-  return found;
+  return abi_guard([&]() -> int {
+    size_t d = 0, t = 0;
+    int found = 0;
+    {
+      std::lock_guard<std::mutex> lk(g_bc_mu);
+      for (auto& e : g_bc)
+        if (e->host == host_bases && e->ready) { d += e->bytes; t += e->table_bytes; found = 1; }
+    }
+    if (device_bytes) *device_bytes = d;
+    if (table_bytes) *table_bytes = t;
+    return found;
+  });
 }
 void mi355zk_bases_cache_invalidate(const void* host_bases) {
-  int dev = 0;
-  const bool have = hipGetDevice(&dev) == hipSuccess;
-  bases_cache_invalidate(host_bases);
-  if (have) (void)hipSetDevice(dev);
+  abi_guard_void([&] {
+    int dev = 0;
+    const bool have = hipGetDevice(&dev) == hipSuccess;
+    bases_cache_invalidate(host_bases);
+    if (have) (void)hipSetDevice(dev);
+  });
 }
 
 int mi355zk_bn254_g1_msm(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
                          const uint32_t* density, size_t density_bits, uint64_t out_xyz[12]) {
-  return msm_host_entry<1>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  return abi_guard([&]() -> int {
+    return msm_host_entry<1>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  });
 }
 int mi355zk_bn254_g2_msm(const uint8_t* bases, size_t n_bases, size_t base_offset, const uint64_t* scalars, size_t n_scalars,
                          const uint32_t* density, size_t density_bits, uint64_t out_xyz[24]) {
-  return msm_host_entry<2>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  return abi_guard([&]() -> int {
+    return msm_host_entry<2>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  });
 }
 int mi355zk_bn254_g1_msm_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                              const uint32_t* density, size_t density_bits, void* stream, uint64_t out_xyz[12]) {
-  return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+  return abi_guard([&]() -> int {
+    return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+  });
 }
 int mi355zk_bn254_g2_msm_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                              const uint32_t* density, size_t density_bits, void* stream, uint64_t out_xyz[24]) {
-  return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+  return abi_guard([&]() -> int {
+    return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz);
+  });
 }
 // one window group of a multiexp (multi-GPU sharding by windows; shard.py)
 int mi355zk_bn254_g1_msm_part_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                                   const uint32_t* density, size_t density_bits, uint32_t window_groups, uint32_t window_group, void* stream,
                                   uint64_t out_xyz[12]) {
-  if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
-  return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
+  return abi_guard([&]() -> int {
+    if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
+    return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
+  });
 }
 int mi355zk_bn254_g2_msm_part_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                                   const uint32_t* density, size_t density_bits, uint32_t window_groups, uint32_t window_group, void* stream,
                                   uint64_t out_xyz[24]) {
-  if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
-  return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
+  return abi_guard([&]() -> int {
+    if (window_groups == 0 || window_group >= window_groups) return ZK_ERR_BAD_ARGS;
+    return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group);
+  });
 }
 // flags (MI355ZK_MSM_*) + window groups in one entry point
 int mi355zk_bn254_g1_msm_ex_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                                 const uint32_t* density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
                                 void* stream, uint64_t out_xyz[12]) {
-  if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
-  return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+  return abi_guard([&]() -> int {
+    if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
+    return msm_dev_entry<1>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+  });
 }
 int mi355zk_bn254_g2_msm_ex_dev(const void* d_bases, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                                 const uint32_t* density, size_t density_bits, uint32_t flags, uint32_t window_groups, uint32_t window_group,
                                 void* stream, uint64_t out_xyz[24]) {
-  if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
-  return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+  return abi_guard([&]() -> int {
+    if (window_groups == 0 || window_group >= window_groups || (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY)) return ZK_ERR_BAD_ARGS;
+    return msm_dev_entry<2>(d_bases, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, window_groups, window_group, flags);
+  });
 }
 int mi355zk_msm_table_geometry(size_t n_bases, int group, uint32_t* window_bits, uint32_t* n_windows) {
-  if ((group != 1 && group != 2) || n_bases >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
-  uint32_t c = 0, W = 0;
-  msm_table_geometry(n_bases ? n_bases : 1, group, &c, &W, nullptr);
-  if (window_bits) *window_bits = c;
-  if (n_windows) *n_windows = W;
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if ((group != 1 && group != 2) || n_bases >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+    uint32_t c = 0, W = 0;
+    msm_table_geometry(n_bases ? n_bases : 1, group, &c, &W, nullptr);
+    if (window_bits) *window_bits = c;
+    if (n_windows) *n_windows = W;
+    return ZK_OK;
+  });
 }
 int mi355zk_bn254_g1_msm_table_build_dev(const void* d_bases, size_t n_bases, void* d_table, size_t table_bytes, void* stream) {
-  return msm_table_build<1>(d_bases, n_bases, d_table, table_bytes, stream);
+  return abi_guard([&]() -> int {
+    return msm_table_build<1>(d_bases, n_bases, d_table, table_bytes, stream);
+  });
 }
 int mi355zk_bn254_g2_msm_table_build_dev(const void* d_bases, size_t n_bases, void* d_table, size_t table_bytes, void* stream) {
-  return msm_table_build<2>(d_bases, n_bases, d_table, table_bytes, stream);
+  return abi_guard([&]() -> int {
+    return msm_table_build<2>(d_bases, n_bases, d_table, table_bytes, stream);
+  });
 }
 int mi355zk_bn254_g1_msm_table_dev(const void* d_table, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                                    const uint32_t* density, size_t density_bits, uint32_t flags, void* stream, uint64_t out_xyz[12]) {
-  if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
-  return msm_dev_entry<1>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
+  return abi_guard([&]() -> int {
+    if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
+    return msm_dev_entry<1>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
+  });
 }
 int mi355zk_bn254_g2_msm_table_dev(const void* d_table, size_t n_bases, size_t base_offset, const void* d_scalars, size_t n_scalars,
                                    const uint32_t* density, size_t density_bits, uint32_t flags, void* stream, uint64_t out_xyz[24]) {
-  if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
-  return msm_dev_entry<2>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
+  return abi_guard([&]() -> int {
+    if (flags & ~MI355ZK_MSM_SCALARS_MONTGOMERY) return ZK_ERR_BAD_ARGS;
+    return msm_dev_entry<2>(d_table, n_bases, base_offset, d_scalars, n_scalars, density, density_bits, stream, out_xyz, 1, 0, flags, nullptr, true);
+  });
 }
 int mi355zk_bn254_g1_dense_multiexp(const uint8_t* bases, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
-  return dense_host<1>(bases, nullptr, scalars, n, out_xyz, nullptr);
+  return abi_guard([&]() -> int {
+    return dense_host<1>(bases, nullptr, scalars, n, out_xyz, nullptr);
+  });
 }
 int mi355zk_bn254_g2_dense_multiexp(const uint8_t* bases, const uint64_t* scalars, size_t n, uint64_t out_xyz[24]) {
-  return dense_host<2>(bases, nullptr, scalars, n, out_xyz, nullptr);
+  return abi_guard([&]() -> int {
+    return dense_host<2>(bases, nullptr, scalars, n, out_xyz, nullptr);
+  });
 }
 int mi355zk_bn254_g1_merge_pairs(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t n, uint64_t out_s[12], uint64_t out_sx[12]) {
-  if (!v2) return ZK_ERR_BAD_ARGS;
-  return dense_host<1>(v1, v2, rho, n, out_s, out_sx);
+  return abi_guard([&]() -> int {
+    if (!v2) return ZK_ERR_BAD_ARGS;
+    return dense_host<1>(v1, v2, rho, n, out_s, out_sx);
+  });
 }
 int mi355zk_bn254_g2_merge_pairs(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t n, uint64_t out_s[24], uint64_t out_sx[24]) {
-  if (!v2) return ZK_ERR_BAD_ARGS;
-  return dense_host<2>(v1, v2, rho, n, out_s, out_sx);
+  return abi_guard([&]() -> int {
+    if (!v2) return ZK_ERR_BAD_ARGS;
+    return dense_host<2>(v1, v2, rho, n, out_s, out_sx);
+  });
 }
 int mi355zk_bn254_g1_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[12]) {
-  if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
-  return msm_g1_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
+  return abi_guard([&]() -> int {
+    if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+    return msm_g1_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
+  });
 }
 int mi355zk_bn254_g2_dense_multiexp_dev(const void* d_bases, const void* d_scalars, size_t n, void* stream, uint64_t out_xyz[24]) {
-  if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
-  return msm_g2_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
+  return abi_guard([&]() -> int {
+    if (!out_xyz || (n && (!d_bases || !d_scalars)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+    return msm_g2_dense_device(d_bases, nullptr, d_scalars, n, (hipStream_t)stream, out_xyz, nullptr);
+  });
 }
 int mi355zk_bn254_g1_merge_pairs_dev(const void* d_v1, const void* d_v2, const void* d_rho, size_t n, void* stream, uint64_t out_s[12],
                                      uint64_t out_sx[12]) {
-  if (!out_s || !out_sx || (n && (!d_v1 || !d_v2 || !d_rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
-  return msm_g1_dense_device(d_v1, d_v2, d_rho, n, (hipStream_t)stream, out_s, out_sx);
+  return abi_guard([&]() -> int {
+    if (!out_s || !out_sx || (n && (!d_v1 || !d_v2 || !d_rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+    return msm_g1_dense_device(d_v1, d_v2, d_rho, n, (hipStream_t)stream, out_s, out_sx);
+  });
 }
 int mi355zk_bn254_g2_merge_pairs_dev(const void* d_v1, const void* d_v2, const void* d_rho, size_t n, void* stream, uint64_t out_s[24],
                                      uint64_t out_sx[24]) {
-  if (!out_s || !out_sx || (n && (!d_v1 || !d_v2 || !d_rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
-  return msm_g2_dense_device(d_v1, d_v2, d_rho, n, (hipStream_t)stream, out_s, out_sx);
+  return abi_guard([&]() -> int {
+    if (!out_s || !out_sx || (n && (!d_v1 || !d_v2 || !d_rho)) || n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
+    return msm_g2_dense_device(d_v1, d_v2, d_rho, n, (hipStream_t)stream, out_s, out_sx);
+  });
 }
 long long mi355zk_last_error_index(void) { return t_last_err_index; }
 int mi355zk_msm_window_bits(size_t n_scalars, int* n_windows) {
-  uint32_t c = 0, W = 0;
-  msm_geometry(n_scalars, 1, &c, &W);
-  if (n_windows) *n_windows = (int)W;
-  return (int)c;
+  return abi_guard([&]() -> int {
+    uint32_t c = 0, W = 0;
+    msm_geometry(n_scalars, 1, &c, &W);
+    if (n_windows) *n_windows = (int)W;
+    return (int)c;
+  });
 }
 int mi355zk_msm_window_bits_groups(size_t n_scalars, uint32_t window_groups, int* n_windows) {
-  uint32_t c = 0, W = 0;
-  msm_geometry(n_scalars, window_groups, &c, &W);
-  if (n_windows) *n_windows = (int)W;
-  return (int)c;
+  return abi_guard([&]() -> int {
+    uint32_t c = 0, W = 0;
+    msm_geometry(n_scalars, window_groups, &c, &W);
+    if (n_windows) *n_windows = (int)W;
+    return (int)c;
+  });
 }
 // (test hook) digit extraction of one scalar on the host: see msm_selftest_digits in msm_g1.hip
 int mi355zk_selftest_msm_digits(size_t n_scalars, uint32_t window_groups, const uint32_t scalar[8], uint32_t w_start, uint32_t w_stop, int direct,
                                 int32_t* digits, uint32_t* geom) {
-  return msm_selftest_digits(n_scalars, window_groups, scalar, w_start, w_stop, direct, digits, geom);
+  return abi_guard([&]() -> int {
+    return msm_selftest_digits(n_scalars, window_groups, scalar, w_start, w_stop, direct, digits, geom);
+  });
 }
 
 int mi355zk_bn254_fr_ntt(uint64_t* a, uint32_t log_n, const uint64_t omega[4]) {
-  if (!omega) return ZK_ERR_BAD_ARGS;
-  return ntt_host(a, log_n, -1, omega);
+  return abi_guard([&]() -> int {
+    if (!omega) return ZK_ERR_BAD_ARGS;
+    return ntt_host(a, log_n, -1, omega);
+  });
 }
 int mi355zk_bn254_fr_domain_op(uint64_t* a, uint32_t log_n, int op) {
-  if (op < 0 || op > 3) return ZK_ERR_BAD_ARGS;
-  return ntt_host(a, log_n, op, nullptr);
+  return abi_guard([&]() -> int {
+    if (op < 0 || op > 3) return ZK_ERR_BAD_ARGS;
+    return ntt_host(a, log_n, op, nullptr);
+  });
 }
-int mi355zk_bn254_fr_fft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_FFT, nullptr); }
-int mi355zk_bn254_fr_ifft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_IFFT, nullptr); }
-int mi355zk_bn254_fr_coset_fft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_COSET_FFT, nullptr); }
-int mi355zk_bn254_fr_icoset_fft(uint64_t* a, uint32_t log_n) { return ntt_host(a, log_n, MI355ZK_OP_ICOSET_FFT, nullptr); }
+int mi355zk_bn254_fr_fft(uint64_t* a, uint32_t log_n) { return abi_guard([&]() -> int { return ntt_host(a, log_n, MI355ZK_OP_FFT, nullptr); }); }
+int mi355zk_bn254_fr_ifft(uint64_t* a, uint32_t log_n) { return abi_guard([&]() -> int { return ntt_host(a, log_n, MI355ZK_OP_IFFT, nullptr); }); }
+int mi355zk_bn254_fr_coset_fft(uint64_t* a, uint32_t log_n) { return abi_guard([&]() -> int { return ntt_host(a, log_n, MI355ZK_OP_COSET_FFT, nullptr); }); }
+int mi355zk_bn254_fr_icoset_fft(uint64_t* a, uint32_t log_n) { return abi_guard([&]() -> int { return ntt_host(a, log_n, MI355ZK_OP_ICOSET_FFT, nullptr); }); }
 int mi355zk_bn254_fr_ntt_dev(void* d_a, uint32_t log_n, const uint64_t omega[4], void* stream) {
-  if (!d_a || !omega || log_n > 28) return ZK_ERR_BAD_ARGS;
-  Fr w;
-  std::memcpy(&w, omega, 32);
-  return ntt_run((Fr*)d_a, log_n, w, (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if (!d_a || !omega || log_n > 28) return ZK_ERR_BAD_ARGS;
+    Fr w;
+    std::memcpy(&w, omega, 32);
+    return ntt_run((Fr*)d_a, log_n, w, (hipStream_t)stream);
+  });
 }
 int mi355zk_bn254_fr_domain_op_dev(void* d_a, uint32_t log_n, int op, void* stream) {
-  if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;
-  return domain_op_dev((Fr*)d_a, log_n, op, (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;
+    return domain_op_dev((Fr*)d_a, log_n, op, (hipStream_t)stream);
+  });
 }
 int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_t omegainv[4], uint64_t geninv[4], uint64_t minv[4]) {
-  DomainConsts D;
-  int rc = domain_consts(log_n, &D);
-  if (rc) return rc;
-  if (omega) std::memcpy(omega, &D.omega, 32);
-  if (omegainv) std::memcpy(omegainv, &D.omegainv, 32);
-  if (geninv) std::memcpy(geninv, &D.geninv, 32);
-  if (minv) std::memcpy(minv, &D.minv, 32);
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    DomainConsts D;
+    int rc = domain_consts(log_n, &D);
+    if (rc) return rc;
+    if (omega) std::memcpy(omega, &D.omega, 32);
+    if (omegainv) std::memcpy(omegainv, &D.omegainv, 32);
+    if (geninv) std::memcpy(geninv, &D.geninv, 32);
+    if (minv) std::memcpy(minv, &D.minv, 32);
+    return ZK_OK;
+  });
 }
 
 // EvaluationDomain::z (domain.rs:207-212) and divide_by_z_on_coset (domain.rs:217-234)
 int mi355zk_bn254_fr_domain_z(uint32_t log_n, const uint64_t tau[4], uint64_t out[4]) {
-  if (!tau || !out || log_n > 28) return ZK_ERR_BAD_ARGS;
-  Fr t;
-  std::memcpy(&t, tau, 32);
-  for (uint32_t i = 0; i < log_n; ++i) t = sqr(t);   // tau.pow(&[m]) with m = 2^log_n
-  t = sub(t, Fr::one());
-  std::memcpy(out, &t, 32);
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if (!tau || !out || log_n > 28) return ZK_ERR_BAD_ARGS;
+    Fr t;
+    std::memcpy(&t, tau, 32);
+    for (uint32_t i = 0; i < log_n; ++i) t = sqr(t);   // tau.pow(&[m]) with m = 2^log_n
+    t = sub(t, Fr::one());
+    std::memcpy(out, &t, 32);
+    return ZK_OK;
+  });
 }
 int mi355zk_bn254_fr_divide_by_z_on_coset_dev(void* d_a, uint32_t log_n, void* stream) {
-  if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;
-  Fr z = fr_from_u64(7);                             // E::Fr::multiplicative_generator() (fr.rs:5)
-  for (uint32_t i = 0; i < log_n; ++i) z = sqr(z);
-  z = sub(z, Fr::one());
-  return ntt_scale((Fr*)d_a, log_n, inv(z), nullptr, (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;
+    Fr z = fr_from_u64(7);                             // E::Fr::multiplicative_generator() (fr.rs:5)
+    for (uint32_t i = 0; i < log_n; ++i) z = sqr(z);
+    z = sub(z, Fr::one());
+    return ntt_scale((Fr*)d_a, log_n, inv(z), nullptr, (hipStream_t)stream);
+  });
 }
 
 // EvaluationDomain<Point<G1>>::{fft, ifft} on affine records (group.rs:22-51, domain.rs:154-173; prepare_phase2.rs:68-131)
 int mi355zk_bn254_g1_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {
-  if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
-  DomainConsts D;
-  int rc = domain_consts(log_n, &D);
-  if (rc) return rc;
-  return point_fft_g1(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
+    DomainConsts D;
+    int rc = domain_consts(log_n, &D);
+    if (rc) return rc;
+    return point_fft_g1(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+  });
 }
 
 // point codecs (ec.rs:763-946, 1136-1344): wire encodings <-> raw affine records
 int mi355zk_bn254_g1_decode_dev(void* d_out_affine, const void* d_in_bytes, size_t n, int compressed, int checked, void* stream, long long* err_index) {
-  if ((n && (!d_out_affine || !d_in_bytes)) || ((uintptr_t)d_in_bytes & 3)) return ZK_ERR_BAD_ARGS;
-  return codec_decode(1, d_out_affine, d_in_bytes, n, compressed, checked, (hipStream_t)stream, err_index);
+  return abi_guard([&]() -> int {
+    if ((n && (!d_out_affine || !d_in_bytes)) || ((uintptr_t)d_in_bytes & 3)) return ZK_ERR_BAD_ARGS;
+    return codec_decode(1, d_out_affine, d_in_bytes, n, compressed, checked, (hipStream_t)stream, err_index);
+  });
 }
 int mi355zk_bn254_g2_decode_dev(void* d_out_affine, const void* d_in_bytes, size_t n, int compressed, int checked, void* stream, long long* err_index) {
-  if ((n && (!d_out_affine || !d_in_bytes)) || ((uintptr_t)d_in_bytes & 3)) return ZK_ERR_BAD_ARGS;
-  return codec_decode(2, d_out_affine, d_in_bytes, n, compressed, checked, (hipStream_t)stream, err_index);
+  return abi_guard([&]() -> int {
+    if ((n && (!d_out_affine || !d_in_bytes)) || ((uintptr_t)d_in_bytes & 3)) return ZK_ERR_BAD_ARGS;
+    return codec_decode(2, d_out_affine, d_in_bytes, n, compressed, checked, (hipStream_t)stream, err_index);
+  });
 }
 int mi355zk_bn254_g1_encode_dev(void* d_out_bytes, const void* d_in_affine, size_t n, int compressed, void* stream) {
-  if ((n && (!d_out_bytes || !d_in_affine)) || ((uintptr_t)d_out_bytes & 3)) return ZK_ERR_BAD_ARGS;
-  return codec_encode(1, d_out_bytes, d_in_affine, n, compressed, (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if ((n && (!d_out_bytes || !d_in_affine)) || ((uintptr_t)d_out_bytes & 3)) return ZK_ERR_BAD_ARGS;
+    return codec_encode(1, d_out_bytes, d_in_affine, n, compressed, (hipStream_t)stream);
+  });
 }
 int mi355zk_bn254_g2_encode_dev(void* d_out_bytes, const void* d_in_affine, size_t n, int compressed, void* stream) {
-  if ((n && (!d_out_bytes || !d_in_affine)) || ((uintptr_t)d_out_bytes & 3)) return ZK_ERR_BAD_ARGS;
-  return codec_encode(2, d_out_bytes, d_in_affine, n, compressed, (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if ((n && (!d_out_bytes || !d_in_affine)) || ((uintptr_t)d_out_bytes & 3)) return ZK_ERR_BAD_ARGS;
+    return codec_encode(2, d_out_bytes, d_in_affine, n, compressed, (hipStream_t)stream);
+  });
 }
 
 int mi355zk_bn254_g2_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {
-  if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
-  DomainConsts D;
-  int rc = domain_consts(log_n, &D);
-  if (rc) return rc;
-  return point_fft_g2(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+  return abi_guard([&]() -> int {
+    if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
+    DomainConsts D;
+    int rc = domain_consts(log_n, &D);
+    if (rc) return rc;
+    return point_fft_g2(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+  });
 }
 
 int mi355zk_bn254_g2_subgroup_check_dev(const void* d_points_affine, size_t n, void* stream, long long* bad_index) {
-  return g2_subgroup_check(d_points_affine, n, stream, bad_index);
+  return abi_guard([&]() -> int {
+    return g2_subgroup_check(d_points_affine, n, stream, bad_index);
+  });
 }
 int mi355zk_selftest_g2_in_subgroup(const uint64_t affine_pt[16]) {  // the same test on the HOST: 1 in the subgroup, 0 not, < 0 bad arguments
   if (!affine_pt) return -1;
@@ -2329,59 +2428,83 @@ int mi355zk_selftest_g2_in_subgroup(const uint64_t affine_pt[16]) {  // the same
   return g2_in_subgroup(p) ? 1 : 0;
 }
 int mi355zk_bn254_g1_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[8], const void* d_scalars, size_t n, void* stream) {
-  return batch_mul<Fq>(d_out_affine, base_affine, d_scalars, n, stream);
+  return abi_guard([&]() -> int {
+    return batch_mul<Fq>(d_out_affine, base_affine, d_scalars, n, stream);
+  });
 }
 int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affine[16], const void* d_scalars, size_t n, void* stream) {
-  return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
+  return abi_guard([&]() -> int {
+    return batch_mul<Fq2>(d_out_affine, base_affine, d_scalars, n, stream);
+  });
 }
 int mi355zk_bn254_g1_sparse_matvec(uint8_t* out_affine, const uint8_t* bases_affine, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col,
                                    const uint64_t* coeffs, size_t n_rows, size_t nnz) {
-  return sparse_matvec_host<Fq>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 1);
+  return abi_guard([&]() -> int {
+    return sparse_matvec_host<Fq>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 1);
+  });
 }
 int mi355zk_bn254_g2_sparse_matvec(uint8_t* out_affine, const uint8_t* bases_affine, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col,
                                    const uint64_t* coeffs, size_t n_rows, size_t nnz) {
-  return sparse_matvec_host<Fq2>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 2);
+  return abi_guard([&]() -> int {
+    return sparse_matvec_host<Fq2>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 2);
+  });
 }
 int mi355zk_bn254_g1_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
                                        const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
-  return sparse_matvec<Fq>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1);
+  return abi_guard([&]() -> int {
+    return sparse_matvec<Fq>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1);
+  });
 }
 int mi355zk_bn254_g2_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
                                        const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
-  return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
+  return abi_guard([&]() -> int {
+    return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
+  });
 }
 
 int mi355zk_bn254_g1_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int same_scalar) {
-  return batch_exp_host<Fq>(out_affine, bases_affine, scalars, n, same_scalar);
+  return abi_guard([&]() -> int {
+    return batch_exp_host<Fq>(out_affine, bases_affine, scalars, n, same_scalar);
+  });
 }
 int mi355zk_bn254_g2_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int same_scalar) {
-  return batch_exp_host<Fq2>(out_affine, bases_affine, scalars, n, same_scalar);
+  return abi_guard([&]() -> int {
+    return batch_exp_host<Fq2>(out_affine, bases_affine, scalars, n, same_scalar);
+  });
 }
 int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
-  return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+  return abi_guard([&]() -> int {
+    return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+  });
 }
 int mi355zk_bn254_g2_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
-  return batch_exp<Fq2>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+  return abi_guard([&]() -> int {
+    return batch_exp<Fq2>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+  });
 }
 
 // host-side group helpers (joining per-GPU partial sums, normalising results)
 int mi355zk_bn254_g1_add(uint64_t acc_xyz[12], const uint64_t other_xyz[12]) {
-  if (!acc_xyz || !other_xyz) return ZK_ERR_BAD_ARGS;
-  G1Jacobian a, b;
-  std::memcpy(&a, acc_xyz, sizeof a);
-  std::memcpy(&b, other_xyz, sizeof b);
-  jac_add(a, b);
-  std::memcpy(acc_xyz, &a, sizeof a);
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if (!acc_xyz || !other_xyz) return ZK_ERR_BAD_ARGS;
+    G1Jacobian a, b;
+    std::memcpy(&a, acc_xyz, sizeof a);
+    std::memcpy(&b, other_xyz, sizeof b);
+    jac_add(a, b);
+    std::memcpy(acc_xyz, &a, sizeof a);
+    return ZK_OK;
+  });
 }
 int mi355zk_bn254_g2_add(uint64_t acc_xyz[24], const uint64_t other_xyz[24]) {
-  if (!acc_xyz || !other_xyz) return ZK_ERR_BAD_ARGS;
-  G2Jacobian a, b;
-  std::memcpy(&a, acc_xyz, sizeof a);
-  std::memcpy(&b, other_xyz, sizeof b);
-  jac_add(a, b);
-  std::memcpy(acc_xyz, &a, sizeof a);
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if (!acc_xyz || !other_xyz) return ZK_ERR_BAD_ARGS;
+    G2Jacobian a, b;
+    std::memcpy(&a, acc_xyz, sizeof a);
+    std::memcpy(&b, other_xyz, sizeof b);
+    jac_add(a, b);
+    std::memcpy(acc_xyz, &a, sizeof a);
+    return ZK_OK;
+  });
 }
 // acc = k * acc on the host (CurveProjective::mul_assign, ec.rs:538-560: most significant bit first, leading zeros skipped): the
 // handful of single-point products a proof assembly makes (prover.rs:300-333: vk.delta_g1.mul(r) ...)
@@ -2400,67 +2523,83 @@ static int host_scalar_mul(uint64_t* acc_xyz, const uint64_t k[4]) {
   std::memcpy(acc_xyz, &res, sizeof res);
   return ZK_OK;
 }
-int mi355zk_bn254_g1_mul(uint64_t acc_xyz[12], const uint64_t scalar[4]) { return host_scalar_mul<G1Jacobian>(acc_xyz, scalar); }
-int mi355zk_bn254_g2_mul(uint64_t acc_xyz[24], const uint64_t scalar[4]) { return host_scalar_mul<G2Jacobian>(acc_xyz, scalar); }
+int mi355zk_bn254_g1_mul(uint64_t acc_xyz[12], const uint64_t scalar[4]) { return abi_guard([&]() -> int { return host_scalar_mul<G1Jacobian>(acc_xyz, scalar); }); }
+int mi355zk_bn254_g2_mul(uint64_t acc_xyz[24], const uint64_t scalar[4]) { return abi_guard([&]() -> int { return host_scalar_mul<G2Jacobian>(acc_xyz, scalar); }); }
 // into_affine (ec.rs:596-629); infinity -> all-zero record
 int mi355zk_bn254_g1_to_affine(uint64_t out_xy[8], const uint64_t xyz[12]) {
-  if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;
-  G1Jacobian p;
-  std::memcpy(&p, xyz, sizeof p);
-  G1Affine r{Fq::zero(), Fq::zero()};
-  if (!p.is_zero()) {
-    Fq zi = inv(p.z), zi2 = sqr(zi);
-    r.x = mul(p.x, zi2);
-    r.y = mul(p.y, mul(zi2, zi));
-  }
-  std::memcpy(out_xy, &r, sizeof r);
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;
+    G1Jacobian p;
+    std::memcpy(&p, xyz, sizeof p);
+    G1Affine r{Fq::zero(), Fq::zero()};
+    if (!p.is_zero()) {
+      Fq zi = inv(p.z), zi2 = sqr(zi);
+      r.x = mul(p.x, zi2);
+      r.y = mul(p.y, mul(zi2, zi));
+    }
+    std::memcpy(out_xy, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 int mi355zk_bn254_g2_to_affine(uint64_t out_xy[16], const uint64_t xyz[24]) {
-  if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;
-  G2Jacobian p;
-  std::memcpy(&p, xyz, sizeof p);
-  G2Affine r{Fq2::zero(), Fq2::zero()};
-  if (!p.is_zero()) {
-    Fq2 zi = inv(p.z), zi2 = sqr(zi);
-    r.x = mul(p.x, zi2);
-    r.y = mul(p.y, mul(zi2, zi));
-  }
-  std::memcpy(out_xy, &r, sizeof r);
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if (!out_xy || !xyz) return ZK_ERR_BAD_ARGS;
+    G2Jacobian p;
+    std::memcpy(&p, xyz, sizeof p);
+    G2Affine r{Fq2::zero(), Fq2::zero()};
+    if (!p.is_zero()) {
+      Fq2 zi = inv(p.z), zi2 = sqr(zi);
+      r.x = mul(p.x, zi2);
+      r.y = mul(p.y, mul(zi2, zi));
+    }
+    std::memcpy(out_xy, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
 int mi355zk_malloc(void** d_ptr, size_t bytes) {
-  if (!d_ptr) return ZK_ERR_BAD_ARGS;
-  ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    if (!d_ptr) return ZK_ERR_BAD_ARGS;
+    ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ZK_OK;
+  });
 }
 int mi355zk_free(void* d_ptr) {
-  ZK_HIP(hipFree(d_ptr));
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    ZK_HIP(hipFree(d_ptr));
+    return ZK_OK;
+  });
 }
 int mi355zk_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
-  ZK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    ZK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return ZK_OK;
+  });
 }
 int mi355zk_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
-  ZK_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    ZK_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ZK_OK;
+  });
 }
 int mi355zk_sync(void* stream) {
-  ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return ZK_OK;
+  return abi_guard([&]() -> int {
+    ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return ZK_OK;
+  });
 }
 
-void mi355zk_prof_enable(int on) { prof_enable(on != 0); }
-void mi355zk_prof_reset(void) { prof_reset(); }
+void mi355zk_prof_enable(int on) { abi_guard_void([&] { prof_enable(on != 0); }); }
+void mi355zk_prof_reset(void) { abi_guard_void([&] { prof_reset(); }); }
 int mi355zk_prof_get(const char* kernel, double* total_ms, long* count) {
-  double t = 0;
-  long c = 0;
-  bool ok = kernel && prof_get(kernel, &t, &c);
-  if (total_ms) *total_ms = t;
-  if (count) *count = c;
-  return ok ? ZK_OK : ZK_ERR_BAD_ARGS;
+  return abi_guard([&]() -> int {
+    double t = 0;
+    long c = 0;
+    bool ok = kernel && prof_get(kernel, &t, &c);
+    if (total_ms) *total_ms = t;
+    if (count) *count = c;
+    return ok ? ZK_OK : ZK_ERR_BAD_ARGS;
+  });
 }
 
 }  // extern "C"

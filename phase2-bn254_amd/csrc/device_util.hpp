@@ -132,4 +132,23 @@ int prof_slot(const char* name);  // find-or-create
 bool prof_get(const char* name, double* total_ms, long* count);
 void prof_reset();
 
+// Every extern "C" entry point runs its body through one of these: the library's hosts are C / Rust / ctypes callers, and a C++
+// exception (std::bad_alloc from a staging vector, std::system_error from a lock) must not unwind across that boundary.  It becomes
+// a device error (rc < 0: the caller falls back to its own CPU path).
+template <class Fn>
+inline int abi_guard(Fn&& fn) noexcept {
+  try {
+    return fn();
+  } catch (...) {
+    return ZK_ERR_DEVICE;
+  }
+}
+template <class Fn>
+inline void abi_guard_void(Fn&& fn) noexcept {
+  try {
+    fn();
+  } catch (...) {
+  }
+}
+
 }  // namespace zk

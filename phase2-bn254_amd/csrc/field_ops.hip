@@ -145,70 +145,82 @@ extern "C" {
 // the product by a table constant (fieldu.hpp u_mul_shoup): a on 9 u32 limbs, w_plain the canonical integer w < p on 8 x 32-bit words;
 // out = a * w - q * p (N-form, < 2p for a < 160p), out_wq = floor(w * 2^261 / p) on 9 limbs
 int mi355zk_selftest_u_mul_shoup(int which, const uint32_t a[9], const uint32_t w_plain[8], uint32_t out[9], uint32_t out_wq[9]) {
-  if (!a || !w_plain || !out || !out_wq) return ZK_ERR_BAD_ARGS;
-  if (which == 0) selftest_u_mul_shoup<zk::FqParams>(a, w_plain, out, out_wq);
-  else selftest_u_mul_shoup<zk::FrParams>(a, w_plain, out, out_wq);
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (!a || !w_plain || !out || !out_wq) return ZK_ERR_BAD_ARGS;
+    if (which == 0) selftest_u_mul_shoup<zk::FqParams>(a, w_plain, out, out_wq);
+    else selftest_u_mul_shoup<zk::FrParams>(a, w_plain, out, out_wq);
+    return ZK_OK;
+  });
 }
 
 // a, b, out: 9 u32 limbs (radix 2^29).  which: 0 Fq, 1 Fr.  out = a*b*2^-261 mod p (N-form, lazily reduced)
 int mi355zk_selftest_u_mul(int which, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
-  if (!a || !b || !out) return ZK_ERR_BAD_ARGS;
-  if (which == 0) selftest_u_mul<zk::FqParams>(a, b, out);
-  else selftest_u_mul<zk::FrParams>(a, b, out);
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (!a || !b || !out) return ZK_ERR_BAD_ARGS;
+    if (which == 0) selftest_u_mul<zk::FqParams>(a, b, out);
+    else selftest_u_mul<zk::FrParams>(a, b, out);
+    return ZK_OK;
+  });
 }
 // out = carry(a + k*p - b) for the (k, s) pairs the kernels use
 int mi355zk_selftest_u_sub(int which, int k, int s, const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
-  if (!a || !b || !out) return ZK_ERR_BAD_ARGS;
-  return which == 0 ? selftest_u_sub<zk::FqParams>(k, s, a, b, out) : selftest_u_sub<zk::FrParams>(k, s, a, b, out);
+  return zk::abi_guard([&]() -> int {
+    if (!a || !b || !out) return ZK_ERR_BAD_ARGS;
+    return which == 0 ? selftest_u_sub<zk::FqParams>(k, s, a, b, out) : selftest_u_sub<zk::FrParams>(k, s, a, b, out);
+  });
 }
 // memory format <-> U limbs round trip pieces: out_u = u_from_std(a);  out_std = u_to_std_lt2p(in_u) (needs in_u < 2p, N-form)
 int mi355zk_selftest_u_pack(int which, const uint64_t a_std[4], uint32_t out_u[9], const uint32_t in_u[9], uint64_t out_std[4]) {
-  if (which == 0) {
-    if (a_std && out_u) { zk::Fq x; std::memcpy(&x, a_std, 32); zk::FqU u = zk::u_from_std(x); std::memcpy(out_u, &u, 36); }
-    if (in_u && out_std) { zk::FqU u; std::memcpy(&u, in_u, 36); zk::Fq x = zk::u_to_std_lt2p(u); std::memcpy(out_std, &x, 32); }
-  } else {
-    if (a_std && out_u) { zk::Fr x; std::memcpy(&x, a_std, 32); zk::FrU u = zk::u_from_std(x); std::memcpy(out_u, &u, 36); }
-    if (in_u && out_std) { zk::FrU u; std::memcpy(&u, in_u, 36); zk::Fr x = zk::u_to_std_lt2p(u); std::memcpy(out_std, &x, 32); }
-  }
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (which == 0) {
+      if (a_std && out_u) { zk::Fq x; std::memcpy(&x, a_std, 32); zk::FqU u = zk::u_from_std(x); std::memcpy(out_u, &u, 36); }
+      if (in_u && out_std) { zk::FqU u; std::memcpy(&u, in_u, 36); zk::Fq x = zk::u_to_std_lt2p(u); std::memcpy(out_std, &x, 32); }
+    } else {
+      if (a_std && out_u) { zk::Fr x; std::memcpy(&x, a_std, 32); zk::FrU u = zk::u_from_std(x); std::memcpy(out_u, &u, 36); }
+      if (in_u && out_std) { zk::FrU u; std::memcpy(&u, in_u, 36); zk::Fr x = zk::u_to_std_lt2p(u); std::memcpy(out_std, &x, 32); }
+    }
+    return ZK_OK;
+  });
 }
 // out_std = u_to_std_lt32p(in_u): canonical reduction of an N-form value < 32p without a product (the NTT's closing step)
 int mi355zk_selftest_u_reduce32(int which, const uint32_t in_u[9], uint64_t out_std[4]) {
-  if (!in_u || !out_std) return ZK_ERR_BAD_ARGS;
-  if (which == 0) { zk::FqU u; std::memcpy(&u, in_u, 36); zk::Fq x = zk::u_to_std_lt32p(u); std::memcpy(out_std, &x, 32); }
-  else { zk::FrU u; std::memcpy(&u, in_u, 36); zk::Fr x = zk::u_to_std_lt32p(u); std::memcpy(out_std, &x, 32); }
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (!in_u || !out_std) return ZK_ERR_BAD_ARGS;
+    if (which == 0) { zk::FqU u; std::memcpy(&u, in_u, 36); zk::Fq x = zk::u_to_std_lt32p(u); std::memcpy(out_std, &x, 32); }
+    else { zk::FrU u; std::memcpy(&u, in_u, 36); zk::Fr x = zk::u_to_std_lt32p(u); std::memcpy(out_std, &x, 32); }
+    return ZK_OK;
+  });
 }
 // bucket accumulation of n signed affine G1 points on the HOST: mode 0 = saturated-limb XYZZ (curve.hpp),
 // mode 1 = U-form XYZZ (curveu.hpp).  out = memory-format XYZZ (X, Y, ZZ, ZZZ; 16 u64).
 int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const uint8_t* negate, size_t n, uint64_t out_xyzz[16]) {
-  if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
-  if (!out_xyzz) return ZK_ERR_BAD_ARGS;
-  zk::G1XYZZ r;
-  if (mode == 0) {
-    zk::G1XYZZ acc = zk::G1XYZZ::zero();
-    for (size_t i = 0; i < n; ++i) {
-      zk::G1Affine p;
-      std::memcpy(&p, affine_pts + 8 * i, 64);
-      zk::xyzz_add_mixed(acc, p.x, p.y, negate[i] != 0);
+  return zk::abi_guard([&]() -> int {
+    if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
+    if (!out_xyzz) return ZK_ERR_BAD_ARGS;
+    zk::G1XYZZ r;
+    if (mode == 0) {
+      zk::G1XYZZ acc = zk::G1XYZZ::zero();
+      for (size_t i = 0; i < n; ++i) {
+        zk::G1Affine p;
+        std::memcpy(&p, affine_pts + 8 * i, 64);
+        zk::xyzz_add_mixed(acc, p.x, p.y, negate[i] != 0);
+      }
+      r = acc;
+    } else {
+      // mode 2: the accumulator goes through an R-domain record after every third point (xyzzu_to_r, then xyzzu_from_r): what a
+      // bucket carried across the chunks of a streamed multiexp does
+      zk::XYZZU<zk::FqParams> acc = zk::XYZZU<zk::FqParams>::zero();
+      for (size_t i = 0; i < n; ++i) {
+        zk::G1Affine p;
+        std::memcpy(&p, affine_pts + 8 * i, 64);
+        zk::xyzzu_add_mixed(acc, p.x, p.y, negate[i] != 0);
+        if (mode == 2 && i % 3 == 2) acc = zk::xyzzu_from_r(zk::xyzzu_to_r(acc));
+      }
+      r = mode == 2 ? zk::xyzzr_to_std(zk::xyzzu_to_r(acc)) : zk::xyzzu_to_std(acc);
     }
-    r = acc;
-  } else {
-    // mode 2: the accumulator goes through an R-domain record after every third point (xyzzu_to_r, then xyzzu_from_r): what a
-    // bucket carried across the chunks of a streamed multiexp does
-    zk::XYZZU<zk::FqParams> acc = zk::XYZZU<zk::FqParams>::zero();
-    for (size_t i = 0; i < n; ++i) {
-      zk::G1Affine p;
-      std::memcpy(&p, affine_pts + 8 * i, 64);
-      zk::xyzzu_add_mixed(acc, p.x, p.y, negate[i] != 0);
-      if (mode == 2 && i % 3 == 2) acc = zk::xyzzu_from_r(zk::xyzzu_to_r(acc));
-    }
-    r = mode == 2 ? zk::xyzzr_to_std(zk::xyzzu_to_r(acc)) : zk::xyzzu_to_std(acc);
-  }
-  std::memcpy(out_xyzz, &r, sizeof r);
-  return ZK_OK;
+    std::memcpy(out_xyzz, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
 // The R-domain records of the G1 bucket reduction (curveu.hpp) on the HOST: n signed affine points are accumulated into n_groups
@@ -217,175 +229,193 @@ int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const u
 // (xyzzr_load / xyzzr_store, what the LDS trees do).  out = memory-format XYZZ of the total (xyzzr_to_std).
 int mi355zk_selftest_g1_record_sum(int mode, const uint64_t* affine_pts, const uint8_t* negate, const uint32_t* group, size_t n, size_t n_groups,
                                    uint64_t out_xyzz[16]) {
-  if ((!affine_pts || !negate || !group) && n) return ZK_ERR_BAD_ARGS;
-  if (!out_xyzz || n_groups == 0) return ZK_ERR_BAD_ARGS;
-  std::vector<zk::XYZZU<zk::FqParams>> acc(n_groups, zk::XYZZU<zk::FqParams>::zero());
-  for (size_t i = 0; i < n; ++i) {
-    if (group[i] >= n_groups) return ZK_ERR_BAD_ARGS;
-    zk::G1Affine p;
-    std::memcpy(&p, affine_pts + 8 * i, 64);
-    zk::xyzzu_add_mixed(acc[group[i]], p.x, p.y, negate[i] != 0);
-  }
-  zk::G1XYZZ total = zk::G1XYZZ::zero();
-  zk::XYZZU<zk::FqParams> run = zk::XYZZU<zk::FqParams>::zero();
-  for (size_t g = 0; g < n_groups; ++g) {
-    const zk::G1XYZZ rec = zk::xyzzu_to_r(acc[g]);
-    if (mode == 0) {
-      zk::xyzzr_add(run, zk::xyzzr_load(rec));
-    } else {
-      zk::XYZZU<zk::FqParams> t = zk::xyzzr_load(total);
-      zk::xyzzr_add(t, zk::xyzzr_load(rec));
-      total = zk::xyzzr_store(t);
+  return zk::abi_guard([&]() -> int {
+    if ((!affine_pts || !negate || !group) && n) return ZK_ERR_BAD_ARGS;
+    if (!out_xyzz || n_groups == 0) return ZK_ERR_BAD_ARGS;
+    std::vector<zk::XYZZU<zk::FqParams>> acc(n_groups, zk::XYZZU<zk::FqParams>::zero());
+    for (size_t i = 0; i < n; ++i) {
+      if (group[i] >= n_groups) return ZK_ERR_BAD_ARGS;
+      zk::G1Affine p;
+      std::memcpy(&p, affine_pts + 8 * i, 64);
+      zk::xyzzu_add_mixed(acc[group[i]], p.x, p.y, negate[i] != 0);
     }
-  }
-  if (mode == 0) total = zk::xyzzr_store(run);
-  const zk::G1XYZZ r = zk::xyzzr_to_std(total);
-  std::memcpy(out_xyzz, &r, sizeof r);
-  return ZK_OK;
+    zk::G1XYZZ total = zk::G1XYZZ::zero();
+    zk::XYZZU<zk::FqParams> run = zk::XYZZU<zk::FqParams>::zero();
+    for (size_t g = 0; g < n_groups; ++g) {
+      const zk::G1XYZZ rec = zk::xyzzu_to_r(acc[g]);
+      if (mode == 0) {
+        zk::xyzzr_add(run, zk::xyzzr_load(rec));
+      } else {
+        zk::XYZZU<zk::FqParams> t = zk::xyzzr_load(total);
+        zk::xyzzr_add(t, zk::xyzzr_load(rec));
+        total = zk::xyzzr_store(t);
+      }
+    }
+    if (mode == 0) total = zk::xyzzr_store(run);
+    const zk::G1XYZZ r = zk::xyzzr_to_std(total);
+    std::memcpy(out_xyzz, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
 // the same for G2 (16 u64 per affine point; out = memory-format XYZZ over Fq2: 32 u64)
 int mi355zk_selftest_g2_record_sum(int mode, const uint64_t* affine_pts, const uint8_t* negate, const uint32_t* group, size_t n, size_t n_groups,
                                    uint64_t out_xyzz[32]) {
-  if ((!affine_pts || !negate || !group) && n) return ZK_ERR_BAD_ARGS;
-  if (!out_xyzz || n_groups == 0) return ZK_ERR_BAD_ARGS;
-  std::vector<zk::XYZZU2> acc(n_groups, zk::XYZZU2::zero());
-  for (size_t i = 0; i < n; ++i) {
-    if (group[i] >= n_groups) return ZK_ERR_BAD_ARGS;
-    zk::G2Affine p;
-    std::memcpy(&p, affine_pts + 16 * i, 128);
-    zk::xyzzu2_add_mixed(acc[group[i]], p.x, p.y, negate[i] != 0);
-  }
-  zk::G2XYZZ total = zk::G2XYZZ::zero();
-  zk::XYZZU2 run = zk::XYZZU2::zero();
-  for (size_t g = 0; g < n_groups; ++g) {
-    const zk::G2XYZZ rec = zk::xyzzu_to_r(acc[g]);
-    if (mode == 0) {
-      zk::xyzzr_add(run, zk::xyzzr_load(rec));
-    } else {
-      zk::XYZZU2 t = zk::xyzzr_load(total);
-      zk::xyzzr_add(t, zk::xyzzr_load(rec));
-      total = zk::xyzzr_store(t);
+  return zk::abi_guard([&]() -> int {
+    if ((!affine_pts || !negate || !group) && n) return ZK_ERR_BAD_ARGS;
+    if (!out_xyzz || n_groups == 0) return ZK_ERR_BAD_ARGS;
+    std::vector<zk::XYZZU2> acc(n_groups, zk::XYZZU2::zero());
+    for (size_t i = 0; i < n; ++i) {
+      if (group[i] >= n_groups) return ZK_ERR_BAD_ARGS;
+      zk::G2Affine p;
+      std::memcpy(&p, affine_pts + 16 * i, 128);
+      zk::xyzzu2_add_mixed(acc[group[i]], p.x, p.y, negate[i] != 0);
     }
-  }
-  if (mode == 0) total = zk::xyzzr_store(run);
-  const zk::G2XYZZ r = zk::xyzzr_to_std(total);
-  std::memcpy(out_xyzz, &r, sizeof r);
-  return ZK_OK;
+    zk::G2XYZZ total = zk::G2XYZZ::zero();
+    zk::XYZZU2 run = zk::XYZZU2::zero();
+    for (size_t g = 0; g < n_groups; ++g) {
+      const zk::G2XYZZ rec = zk::xyzzu_to_r(acc[g]);
+      if (mode == 0) {
+        zk::xyzzr_add(run, zk::xyzzr_load(rec));
+      } else {
+        zk::XYZZU2 t = zk::xyzzr_load(total);
+        zk::xyzzr_add(t, zk::xyzzr_load(rec));
+        total = zk::xyzzr_store(t);
+      }
+    }
+    if (mode == 0) total = zk::xyzzr_store(run);
+    const zk::G2XYZZ r = zk::xyzzr_to_std(total);
+    std::memcpy(out_xyzz, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
 // GLV split of a canonical scalar (glv.hpp) on the HOST: out = k1 magnitude (5 u32), k2 magnitude (5 u32), sign of k1, sign of k2
 int mi355zk_selftest_glv_split(const uint32_t k[8], uint32_t out[12]) {
-  if (!k || !out) return ZK_ERR_BAD_ARGS;
-  const zk::GlvSplit g = zk::glv_split(k);
-  for (int i = 0; i < 5; ++i) { out[i] = g.k1[i]; out[5 + i] = g.k2[i]; }
-  out[10] = g.neg1 ? 1u : 0u;
-  out[11] = g.neg2 ? 1u : 0u;
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (!k || !out) return ZK_ERR_BAD_ARGS;
+    const zk::GlvSplit g = zk::glv_split(k);
+    for (int i = 0; i < 5; ++i) { out[i] = g.k1[i]; out[5 + i] = g.k2[i]; }
+    out[10] = g.neg1 ? 1u : 0u;
+    out[11] = g.neg2 ? 1u : 0u;
+    return ZK_OK;
+  });
 }
 
 // the G2 split k = k1 + k2 mu (glv.hpp) on the HOST: out = k1 (5 u32), k2 (5 u32)
 int mi355zk_selftest_glv2_split(const uint32_t k[8], uint32_t out[10]) {
-  if (!k || !out) return ZK_ERR_BAD_ARGS;
-  const zk::Glv2Split g = zk::glv2_split(k);
-  for (int i = 0; i < 5; ++i) { out[i] = g.k1[i]; out[5 + i] = g.k2[i]; }
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (!k || !out) return ZK_ERR_BAD_ARGS;
+    const zk::Glv2Split g = zk::glv2_split(k);
+    for (int i = 0; i < 5; ++i) { out[i] = g.k1[i]; out[5 + i] = g.k2[i]; }
+    return ZK_OK;
+  });
 }
 // psi of an affine G2 point through the table-entry path the kernels use (jacu2_tab_from_affine -> jacu2_tab_psi), Jacobian out
 int mi355zk_selftest_g2_psi(const uint64_t affine_pt[16], uint64_t out_xyz[24]) {
-  if (!affine_pt || !out_xyz) return ZK_ERR_BAD_ARGS;
-  zk::G2Affine p;
-  std::memcpy(&p, affine_pt, sizeof p);
-  const zk::FqU C266 = zk::UPow2<zk::FqParams, 266>::get();
-  const zk::Fq2 cxs = zk::glv2_cx(), cys = zk::glv2_cy();
-  const zk::Fq2U cxU{zk::u_mul(zk::u_from_std(cxs.c0), C266), zk::u_mul(zk::u_from_std(cxs.c1), C266)};
-  const zk::Fq2U cyU{zk::u_mul(zk::u_from_std(cys.c0), C266), zk::u_mul(zk::u_from_std(cys.c1), C266)};
-  const zk::JacTabU2 e = zk::jacu2_tab_psi(zk::jacu2_tab_from_affine(p.x, p.y), cxU, cyU);
-  zk::JacU2 acc = zk::JacU2::zero();
-  zk::jacu2_add_tab(acc, e, false);
-  const zk::G2Jacobian r = zk::jacu2_to_std(acc);
-  std::memcpy(out_xyz, &r, sizeof r);
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if (!affine_pt || !out_xyz) return ZK_ERR_BAD_ARGS;
+    zk::G2Affine p;
+    std::memcpy(&p, affine_pt, sizeof p);
+    const zk::FqU C266 = zk::UPow2<zk::FqParams, 266>::get();
+    const zk::Fq2 cxs = zk::glv2_cx(), cys = zk::glv2_cy();
+    const zk::Fq2U cxU{zk::u_mul(zk::u_from_std(cxs.c0), C266), zk::u_mul(zk::u_from_std(cxs.c1), C266)};
+    const zk::Fq2U cyU{zk::u_mul(zk::u_from_std(cys.c0), C266), zk::u_mul(zk::u_from_std(cys.c1), C266)};
+    const zk::JacTabU2 e = zk::jacu2_tab_psi(zk::jacu2_tab_from_affine(p.x, p.y), cxU, cyU);
+    zk::JacU2 acc = zk::JacU2::zero();
+    zk::jacu2_add_tab(acc, e, false);
+    const zk::G2Jacobian r = zk::jacu2_to_std(acc);
+    std::memcpy(out_xyz, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
 // same for G2 (16 u64 per affine point; out = X, Y, ZZ, ZZZ over Fq2: 32 u64)
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const uint8_t* negate, size_t n, uint64_t out_xyzz[32]) {
-  if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
-  if (!out_xyzz) return ZK_ERR_BAD_ARGS;
-  zk::G2XYZZ r;
-  if (mode == 0) {
-    zk::G2XYZZ acc = zk::G2XYZZ::zero();
-    for (size_t i = 0; i < n; ++i) {
-      zk::G2Affine p;
-      std::memcpy(&p, affine_pts + 16 * i, 128);
-      zk::xyzz_add_mixed(acc, p.x, p.y, negate[i] != 0);
+  return zk::abi_guard([&]() -> int {
+    if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
+    if (!out_xyzz) return ZK_ERR_BAD_ARGS;
+    zk::G2XYZZ r;
+    if (mode == 0) {
+      zk::G2XYZZ acc = zk::G2XYZZ::zero();
+      for (size_t i = 0; i < n; ++i) {
+        zk::G2Affine p;
+        std::memcpy(&p, affine_pts + 16 * i, 128);
+        zk::xyzz_add_mixed(acc, p.x, p.y, negate[i] != 0);
+      }
+      r = acc;
+    } else {
+      zk::XYZZU2 acc = zk::XYZZU2::zero();  // mode 2: through a record after every third point (see the G1 hook)
+      for (size_t i = 0; i < n; ++i) {
+        zk::G2Affine p;
+        std::memcpy(&p, affine_pts + 16 * i, 128);
+        zk::xyzzu2_add_mixed(acc, p.x, p.y, negate[i] != 0);
+        if (mode == 2 && i % 3 == 2) acc = zk::xyzzu_from_r(zk::xyzzu_to_r(acc));
+      }
+      r = mode == 2 ? zk::xyzzr_to_std(zk::xyzzu_to_r(acc)) : zk::xyzzu2_to_std(acc);
     }
-    r = acc;
-  } else {
-    zk::XYZZU2 acc = zk::XYZZU2::zero();  // mode 2: through a record after every third point (see the G1 hook)
-    for (size_t i = 0; i < n; ++i) {
-      zk::G2Affine p;
-      std::memcpy(&p, affine_pts + 16 * i, 128);
-      zk::xyzzu2_add_mixed(acc, p.x, p.y, negate[i] != 0);
-      if (mode == 2 && i % 3 == 2) acc = zk::xyzzu_from_r(zk::xyzzu_to_r(acc));
-    }
-    r = mode == 2 ? zk::xyzzr_to_std(zk::xyzzu_to_r(acc)) : zk::xyzzu2_to_std(acc);
-  }
-  std::memcpy(out_xyzz, &r, sizeof r);
-  return ZK_OK;
+    std::memcpy(out_xyzz, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
 // k * P for ONE G2 point on the HOST with the program batch_exp_win_u2_kernel runs (table 1P..8P, signed 4-bit windows, 256
 // doublings) on the U-form Fq2 Jacobian arithmetic of curveu.hpp.  out = memory-format Jacobian X, Y, Z (24 u64).
 int mi355zk_selftest_g2_scalar_mul_u(const uint64_t affine_pt[16], const uint64_t scalar[4], uint64_t out_xyz[24]) {
-  if (!affine_pt || !scalar || !out_xyz) return ZK_ERR_BAD_ARGS;
-  zk::G2Affine base;
-  std::memcpy(&base, affine_pt, 128);
-  uint32_t s[8];
-  std::memcpy(s, scalar, 32);
-  zk::JacU2 acc = zk::JacU2::zero();
-  if (!base.is_zero()) {
-    zk::JacTabU2 tab[8];
-    tab[0] = zk::jacu2_tab_from_affine(base.x, base.y);
-    for (int e = 2; e <= 8; ++e) {
-      const zk::JacTabU2& src = tab[(e & 1) ? e - 2 : e / 2 - 1];
-      zk::JacU2 q{src.x, src.y, src.z};
-      if (e & 1) zk::jacu2_add_tab(q, tab[0], false);
-      else q = zk::jacu2_double(q);
-      tab[e - 1] = zk::jacu2_tab_entry(q);
+  return zk::abi_guard([&]() -> int {
+    if (!affine_pt || !scalar || !out_xyz) return ZK_ERR_BAD_ARGS;
+    zk::G2Affine base;
+    std::memcpy(&base, affine_pt, 128);
+    uint32_t s[8];
+    std::memcpy(s, scalar, 32);
+    zk::JacU2 acc = zk::JacU2::zero();
+    if (!base.is_zero()) {
+      zk::JacTabU2 tab[8];
+      tab[0] = zk::jacu2_tab_from_affine(base.x, base.y);
+      for (int e = 2; e <= 8; ++e) {
+        const zk::JacTabU2& src = tab[(e & 1) ? e - 2 : e / 2 - 1];
+        zk::JacU2 q{src.x, src.y, src.z};
+        if (e & 1) zk::jacu2_add_tab(q, tab[0], false);
+        else q = zk::jacu2_double(q);
+        tab[e - 1] = zk::jacu2_tab_entry(q);
+      }
+      int dig[65];
+      uint32_t carry = 0;
+      for (int j = 0; j < 64; ++j) {
+        uint32_t d = ((s[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
+        carry = d > 8u ? 1u : 0u;
+        dig[j] = carry ? (int)d - 16 : (int)d;
+      }
+      for (int j = 63; j >= 0; --j) {
+        for (int rep = 0; rep < 4; ++rep) acc = zk::jacu2_double(acc);
+        if (dig[j]) zk::jacu2_add_tab(acc, tab[(dig[j] < 0 ? -dig[j] : dig[j]) - 1], dig[j] < 0);
+      }
     }
-    int dig[65];
-    uint32_t carry = 0;
-    for (int j = 0; j < 64; ++j) {
-      uint32_t d = ((s[j >> 3] >> (4 * (j & 7))) & 15u) + carry;
-      carry = d > 8u ? 1u : 0u;
-      dig[j] = carry ? (int)d - 16 : (int)d;
-    }
-    for (int j = 63; j >= 0; --j) {
-      for (int rep = 0; rep < 4; ++rep) acc = zk::jacu2_double(acc);
-      if (dig[j]) zk::jacu2_add_tab(acc, tab[(dig[j] < 0 ? -dig[j] : dig[j]) - 1], dig[j] < 0);
-    }
-  }
-  const zk::Jacobian<zk::Fq2> r = zk::jacu2_to_std(acc);
-  std::memcpy(out_xyz, &r, sizeof r);
-  return ZK_OK;
+    const zk::Jacobian<zk::Fq2> r = zk::jacu2_to_std(acc);
+    std::memcpy(out_xyz, &r, sizeof r);
+    return ZK_OK;
+  });
 }
 
-int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 0); }
-int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::pointwise(d_a, d_b, n, stream, 1); }
+int mi355zk_bn254_fr_mul_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::abi_guard([&]() -> int { return zk::pointwise(d_a, d_b, n, stream, 0); }); }
+int mi355zk_bn254_fr_sub_assign_dev(void* d_a, const void* d_b, size_t n, void* stream) { return zk::abi_guard([&]() -> int { return zk::pointwise(d_a, d_b, n, stream, 1); }); }
 int mi355zk_bn254_fr_into_repr_dev(void* d_out, const void* d_in, size_t n, void* stream) {
-  if ((!d_out || !d_in) && n) return ZK_ERR_BAD_ARGS;
-  if (n == 0) return ZK_OK;
-  uint64_t blocks = (n + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(zk::fr_into_repr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (zk::Fr*)d_out, (const zk::Fr*)d_in, (uint64_t)n);
-  ZK_HIP(hipGetLastError());
-  return ZK_OK;
+  return zk::abi_guard([&]() -> int {
+    if ((!d_out || !d_in) && n) return ZK_ERR_BAD_ARGS;
+    if (n == 0) return ZK_OK;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(zk::fr_into_repr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (zk::Fr*)d_out, (const zk::Fr*)d_in, (uint64_t)n);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  });
 }
 
 int mi355zk_ubench_fp_mul(int which, uint32_t blocks, uint32_t iters, const uint64_t a[4], const uint64_t b[4], uint64_t out[16], float* ms) {
-  if (!a || !b || !out || !ms) return ZK_ERR_BAD_ARGS;
-  return which == 0 ? zk::ubench<zk::FqParams>(blocks, iters, a, b, out, ms) : zk::ubench<zk::FrParams>(blocks, iters, a, b, out, ms);
+  return zk::abi_guard([&]() -> int {
+    if (!a || !b || !out || !ms) return ZK_ERR_BAD_ARGS;
+    return which == 0 ? zk::ubench<zk::FqParams>(blocks, iters, a, b, out, ms) : zk::ubench<zk::FrParams>(blocks, iters, a, b, out, ms);
+  });
 }
 
 }  // extern "C"

@@ -47,6 +47,7 @@ cd $R
 bash tools/ab_quad.sh > $O/ab_quad.txt 2>/dev/null
 timeout 600 python tools/bench_multi_device.py --log-n 26 --devices 1 2 4 8 > $O/multi_device_2e26.json 2>/dev/null
 bash tools/ab_ntt_lds.sh > $O/ntt_configs.txt 2>/dev/null
+[ -f phase2-bn254_amd/libmi355zk_mont.so ] && bash tools/ab_ntt_shoup.sh > $O/ab_ntt_shoup.txt 2>/dev/null
 cd /tmp; rm -rf /tmp/p_he; timeout 600 rocprofv3 --kernel-trace -d /tmp/p_he -- python $R/tools/trace_host_entry.py > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_he -name "*.db" | head -1) --timeline 140 > $O/host_entry_timeline.txt
 rm -rf /tmp/p_t16; TRACE_LOG_N=16 timeout 300 rocprofv3 --kernel-trace -d /tmp/p_t16 -- python $R/tools/trace_one_msm.py > /dev/null 2>&1

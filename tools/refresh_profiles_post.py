@@ -52,6 +52,7 @@ print(open(os.path.join(DST, "latest_pmc.json")).read())
 for src, dst, hdr in (("ab_quad.txt", "ab_quad.txt", "# bash tools/ab_quad.sh: the reduce tails on quad additions (default) against one lane per addition (MI355ZK_MSM_QUAD=0), same box, same process order;\n# bench.py --log-n L --steps 30 --warmup 10 (ms per call, msm_reduce / msm_accumulate by HIP events, result limb) and tools/bench_g2.py\n"),
                       ("multi_device_2e26.json", "multi_device_2e26.json", None),
                       ("ntt_configs.txt", "ntt_configs.txt", "# bash tools/ab_ntt_lds.sh: tools/bench_ntt.py (warmed up, no per-pass events in the timed loop): (ms per transform, ntt_pass_kernel avg ms, passes)\n"),
+                      ("ab_ntt_shoup.txt", "ab_ntt_shoup.txt", "# bash tools/ab_ntt_shoup.sh: the previous ntt.hip (Montgomery products by twiddles, libmi355zk_mont.so) against the products by a constant with its quotient, same box: (ms per transform, ntt_pass_kernel avg ms, passes)\n"),
                       ("host_entry_timeline.txt", "host_entry_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_host_entry.py: streamed host-buffer G1 multiexps at 2^26 over a pinned vector (page-locked exponents, 5 chunks), last 140 dispatches\n"),
                       ("ab_split.txt", "ab_split.txt", "# bash tools/ab_split.sh (ms per call; msm_accumulate / msm_reduce by HIP events; MI355ZK_MSM_SPLIT=0 = the lane-per-bucket launch alone)\n"),
                       ("bench_small.json", "bench_small.json", None),
