@@ -245,6 +245,7 @@ int mi355zk_selftest_g1_record_sum(int mode, const uint64_t *affine_pts, const u
 int mi355zk_selftest_g2_record_sum(int mode, const uint64_t *affine_pts, const uint8_t *negate, const uint32_t *group, size_t n, size_t n_groups, uint64_t out_xyzz[32]);
 int mi355zk_selftest_msm_digits(size_t n_scalars, uint32_t window_groups, const uint32_t scalar[8], uint32_t w_start, uint32_t w_stop, int direct, int32_t *digits, uint32_t *geom);
 int mi355zk_selftest_glv_split(const uint32_t k[8], uint32_t out[12]);
+int mi355zk_selftest_glv_wnaf5(const uint32_t m[5], int8_t digits[164]);
 int mi355zk_selftest_glv2_split(const uint32_t k[8], uint32_t out[10]);
 int mi355zk_selftest_g2_psi(const uint64_t affine_pt[16], uint64_t out_xyz[24]);
 int mi355zk_selftest_g2_scalar_mul_u(const uint64_t affine_pt[16], const uint64_t scalar[4], uint64_t out_xyz[24]);

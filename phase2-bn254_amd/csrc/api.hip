@@ -282,6 +282,79 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
   zbuf[i] = r.z;
 }
 
+// G1, ONE scalar for every point (phase2 contribute: all of L and H times delta^-1, parameters.rs:423-470): the digit string is the
+// same in every lane, so a sliding window costs no divergence.  Both GLV halves in width-5 non-adjacent form (glv_wnaf5) over a
+// per-lane table of the eight odd multiples P, 3P .. 15P (JacTabU, [entry][lane] like the windowed kernel's): 127 doublings + ~42
+// table additions (2079 mads) + the table (one doubling, one mixed and six table additions) ~ 245k mads per point against the
+// ~271k of the plain NAF's 85 mixed additions (1593) -- measured on one box 85.0 -> 91.6 Mpoint/s (contribute on |L| = 2^20: 24.65 ->
+// 22.9 ms); 198 VGPRs = two waves per SIMD, and forcing three or four (amdgpu_waves_per_eu, 140 / 336 B of spill) changes nothing: the
+// kernel runs at the multiplier's rate.  The digits are made once per call by a one-lane kernel (the scalar lives on the device) and
+// read through uniform (scalar) loads.  MI355ZK_EXP_SAME_NAF=1 runs the plain-NAF kernel for the comparison.
+struct SameDigits {
+  int8_t d1[GLV_WNAF_LEN], d2[GLV_WNAF_LEN];   // digits of |k1|, |k2| with the signs of the split folded in
+  int32_t top;                                   // highest index with a non-zero digit in either string, -1: the scalar is zero
+};
+__global__ void batch_exp_same_digits_kernel(const uint32_t* __restrict__ scalar, SameDigits* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint32_t s[8];
+  for (int l = 0; l < 8; ++l) s[l] = scalar[l];
+  const GlvSplit g = glv_split(s);
+  int8_t a[GLV_WNAF_LEN], b[GLV_WNAF_LEN];
+  const int t1 = glv_wnaf5(g.k1, a), t2 = glv_wnaf5(g.k2, b);
+  for (int j = 0; j < GLV_WNAF_LEN; ++j) {
+    out->d1[j] = g.neg1 ? (int8_t)-a[j] : a[j];
+    out->d2[j] = g.neg2 ? (int8_t)-b[j] : b[j];
+  }
+  out->top = t1 > t2 ? t1 : t2;
+}
+
+__global__ void __launch_bounds__(256) batch_exp_same_kernel(Affine<Fq>* __restrict__ out, const Affine<Fq>* __restrict__ bases, int same_base,
+                                                            uint64_t i0, uint64_t n_chunk, const uint32_t* __restrict__ base_index,
+                                                            Fq* __restrict__ zbuf, JacTabU<FqParams>* __restrict__ tab,
+                                                            const SameDigits* __restrict__ dig) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunk) return;
+  const uint64_t i = i0 + t;
+  const Affine<Fq> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
+  JacU<FqParams> acc = JacU<FqParams>::zero();
+  const int top = dig->top;
+  if (!base.is_zero() && top >= 0) {
+    const FqU C = UPow2<FqParams, 266>::get();             // x*2^256 * 2^266 / 2^261 = x * 2^261
+    const FqU x2 = u_mul(u_from_std(base.x), C);            // < 2p, N
+    const FqU y2 = u_mul(u_from_std(base.y), C);
+    {
+      JacU<FqParams> q{x2, y2, UPow2<FqParams, 261>::get()};
+      tab[t] = jacu_tab_entry(q);                           // P
+      q = jacu_double(q);
+      const JacTabU<FqParams> twice = jacu_tab_entry(q);    // 2P, added six times
+      jacu_add_mixed(q, x2, y2, false);                     // 3P
+      tab[n_chunk + t] = jacu_tab_entry(q);
+#pragma unroll 1
+      for (int e = 2; e < EXP_TAB; ++e) {                   // 5P .. 15P   (a point of the prime-order group: no sum here is the identity)
+        jacu_add_tab(q, twice, false);
+        tab[(uint64_t)e * n_chunk + t] = jacu_tab_entry(q);
+      }
+    }
+    const FqU betaU = u_mul(u_from_std(glv_beta()), C);     // beta, 2^261 domain
+#pragma unroll 1
+    for (int j = top; j >= 0; --j) {
+      acc = jacu_double(acc);                               // (infinity returns at once)
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {                // ONE inlined jacu_add_tab for both halves
+        const int d = half ? dig->d2[j] : dig->d1[j];
+        if (d == 0) continue;
+        const int mag = d < 0 ? -d : d;
+        JacTabU<FqParams> e = tab[(uint64_t)(mag >> 1) * n_chunk + t];
+        if (half) e.x = u_mul(e.x, betaU);                  // phi of the entry: X * beta (X < 6p: < 1.08p)
+        jacu_add_tab(acc, e, d < 0);
+      }
+    }
+  }
+  const Jacobian<Fq> r = jacu_to_std(acc);
+  out[i] = Affine<Fq>{r.x, r.y};
+  zbuf[i] = r.z;
+}
+
 // G2: the same fixed signed 4-bit windows on the U-form Fq2 Jacobian accumulator of curveu.hpp (JacU2: 29-bit lazy limbs, one
 // v_mad_u64_u32 per partial product, shared Montgomery reductions) -- round 1 ran this on memory-format Fq2 at 9 Mpoint/s.
 // Table build and main loop run through ONE loop with a single inlined jacu2_double and a single inlined jacu2_add_tab: the Fq2
@@ -542,7 +615,10 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
     const bool shortcut = shortcut_unit_scalars && windowed && !same_base;
     const size_t list_bytes = shortcut ? ((n + 1) * 4 + 255) & ~(size_t)255 : 0;
     void* p = nullptr;
-    int rc = exp_scratch(z_bytes + list_bytes + (windowed ? (size_t)EXP_TAB * chunk * sizeof(JacTabU<FqParams>) : 0), stream, &p);
+    static const bool same_naf = std::getenv("MI355ZK_EXP_SAME_NAF") != nullptr;   // (the plain-NAF kernel of rounds 2-3, for the comparison)
+    const bool same_win = !windowed && !same_naf;          // one scalar for all points: the sliding-window kernel
+    const size_t tab_bytes = (windowed || same_win) ? (size_t)EXP_TAB * chunk * sizeof(JacTabU<FqParams>) : 0;
+    int rc = exp_scratch(z_bytes + list_bytes + tab_bytes + (same_win ? 512 : 0), stream, &p);
     if (rc) return rc;
     Fq* zbuf = (Fq*)p;
     uint32_t* list = shortcut ? (uint32_t*)((char*)p + z_bytes) : nullptr;   // [0] = count, then the general terms
@@ -558,6 +634,16 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
         hipLaunchKernelGGL(batch_exp_win_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
                            same_base, (const uint32_t*)d_scalars, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab,
                            shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
+      }
+    } else if (same_win) {
+      JacTabU<FqParams>* tab = (JacTabU<FqParams>*)((char*)p + z_bytes + list_bytes);
+      SameDigits* dig = (SameDigits*)((char*)p + z_bytes + list_bytes + tab_bytes);
+      static_assert(sizeof(SameDigits) <= 512, "digit buffer");
+      hipLaunchKernelGGL(batch_exp_same_digits_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)d_scalars, dig);
+      for (size_t i0 = 0; i0 < n; i0 += chunk) {
+        const size_t m = n - i0 < chunk ? n - i0 : chunk;
+        hipLaunchKernelGGL(batch_exp_same_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
+                           same_base, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab, (const SameDigits*)dig);
       }
     } else {
       hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, (const Affine<F>*)d_bases,

@@ -302,6 +302,15 @@ int mi355zk_selftest_glv_split(const uint32_t k[8], uint32_t out[12]) {
   });
 }
 
+// width-5 non-adjacent form (glv.hpp glv_wnaf5) of a magnitude on 5 u32 limbs, on the HOST: digits[164]; returns the top digit's index (-1: zero)
+int mi355zk_selftest_glv_wnaf5(const uint32_t m[5], int8_t digits[164]) {
+  return zk::abi_guard([&]() -> int {
+    if (!m || !digits) return -2;
+    static_assert(zk::GLV_WNAF_LEN == 164, "header comment");
+    return zk::glv_wnaf5(m, digits);
+  });
+}
+
 // the G2 split k = k1 + k2 mu (glv.hpp) on the HOST: out = k1 (5 u32), k2 (5 u32)
 int mi355zk_selftest_glv2_split(const uint32_t k[8], uint32_t out[10]) {
   return zk::abi_guard([&]() -> int {

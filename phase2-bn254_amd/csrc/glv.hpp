@@ -185,4 +185,38 @@ ZK_HD void glv_naf(const uint32_t m[5], uint32_t pos[6], uint32_t neg[6]) {
   }
 }
 
+// width-5 non-adjacent form of a magnitude m < 2^159 (5 limbs): m = sum d_j 2^j with every non-zero d_j odd, |d_j| <= 15, and at least four
+// zeros after each -- one addition per six bits on average against the NAF's three, over a table of the eight odd multiples.  digits[j],
+// j < GLV_WNAF_LEN (the form of an n-bit number has at most n + 1 digits); returns the index of the top non-zero digit, -1 for m == 0.
+constexpr int GLV_WNAF_LEN = 164;
+ZK_HD int glv_wnaf5(const uint32_t m_in[5], int8_t digits[GLV_WNAF_LEN]) {
+  uint32_t m[6] = {m_in[0], m_in[1], m_in[2], m_in[3], m_in[4], 0u};
+  int top = -1;
+  for (int j = 0; j < GLV_WNAF_LEN; ++j) {
+    int d = 0;
+    if (m[0] & 1u) {
+      d = (int)(m[0] & 31u);
+      if (d >= 16) d -= 32;
+      // m -= d: clears the low five bits (d > 0) or carries into bit 5 (d < 0)
+      if (d > 0) {
+        m[0] -= (uint32_t)d;
+      } else {
+        uint64_t c = (uint64_t)m[0] + (uint32_t)(-d);
+        m[0] = (uint32_t)c;
+        c >>= 32;
+        for (int l = 1; l < 6; ++l) {
+          c += m[l];
+          m[l] = (uint32_t)c;
+          c >>= 32;
+        }
+      }
+      top = j;
+    }
+    digits[j] = (int8_t)d;
+    for (int l = 0; l < 5; ++l) m[l] = (m[l] >> 1) | (m[l + 1] << 31);
+    m[5] >>= 1;
+  }
+  return top;
+}
+
 }  // namespace zk

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mi355zk_selftest_g2_record_sum": (_i, [_i, _vp, _vp, _vp, _sz, _sz, _vp]),
     "mi355zk_selftest_msm_digits": (_i, [_sz, _u32, _vp, _u32, _u32, _i, _vp, _vp]),
     "mi355zk_selftest_glv_split": (_i, [_vp, _vp]),
+    "mi355zk_selftest_glv_wnaf5": (_i, [_vp, _vp]),
     "mi355zk_selftest_glv2_split": (_i, [_vp, _vp]),
     "mi355zk_selftest_g2_psi": (_i, [_vp, _vp]),
     "mi355zk_selftest_u_mul": (_i, [_i, _vp, _vp, _vp]),

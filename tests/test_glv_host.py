@@ -67,3 +67,23 @@ def test_g2_split_and_psi():
         assert lib.mi355zk_selftest_g2_psi(np.ascontiguousarray(p).ctypes.data, out.ctypes.data) == 0
         want = O.G2.to_affine(O.G2.mul(O.G2.from_affine(p), mu_limbs))
         assert np.array_equal(O.G2.to_affine(out), want)
+
+
+def test_width5_non_adjacent_form():
+    """glv_wnaf5 (the digit string of the one-scalar-for-all-points batch_exp kernel): m = sum d_j 2^j, every non-zero digit odd and at most 15
+    in magnitude, at least four zeros after each, the returned top index right; magnitudes up to 2^159 (the split's halves are < 2^128)."""
+    import phase2_bn254_amd as zk
+
+    lib = zk.lib.load()
+    rnd = random.Random(55)
+    cases = [0, 1, 2, 15, 16, 17, 31, 32, (1 << 128) - 1, 1 << 127, (1 << 159) - 1, 0xAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA, 0x5555555555555555]
+    cases += [rnd.getrandbits(rnd.choice([8, 64, 127, 128, 140, 159])) for _ in range(300)]
+    for m in cases:
+        limbs = np.array([(m >> (32 * i)) & 0xFFFFFFFF for i in range(5)], dtype=np.uint32)
+        dig = np.zeros(164, dtype=np.int8)
+        top = lib.mi355zk_selftest_glv_wnaf5(limbs.ctypes.data, dig.ctypes.data)
+        assert sum(int(d) << j for j, d in enumerate(dig)) == m
+        nz = [j for j, d in enumerate(dig) if d]
+        assert top == (nz[-1] if nz else -1)
+        assert all(int(dig[j]) % 2 != 0 and abs(int(dig[j])) <= 15 for j in nz)
+        assert all(b - a >= 5 for a, b in zip(nz, nz[1:]))
