@@ -176,7 +176,11 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         genr = np.ascontiguousarray(gen)
         fn = L.mi355zk_bn254_g1_batch_mul_dev if group == 1 else L.mi355zk_bn254_g2_batch_mul_dev
         assert fn(C.c_void_p(b.data_ptr()), genr.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
-        for _ in range(5):
+        # warm-up: the CPU baseline of the previous leg has just had every host core busy (its worker threads, numpy / torch pools that keep
+        # spinning for a while after their last parallel region): a 2-ms call is ~27 kernel launches, and launches issued beside spinning
+        # threads measured 0.2 ms per call slower with IDENTICAL kernel times (profiles/r04_final_bench_n1.json against bench_2e20.json)
+        time.sleep(0.3)
+        for _ in range(25 if group == 1 else 12):
             zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
         iters = 20 if group == 1 else 10
         t = time.perf_counter()
