@@ -352,8 +352,11 @@ int mi355zk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
 int mi355zk_sync(void *stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg.
- * names: "msm_digits" "msm_sort" "msm_accumulate_heavy" "msm_accumulate" "msm_reduce" "ntt_pass" "ntt_scale" */
+ * names: "msm_digits" "msm_sort" "msm_accumulate_heavy" "msm_accumulate" "msm_reduce" "ntt_pass" "ntt_scale"
+ * mi355zk_prof_enable: 0 off; 1 every kernel group (~20 event records per multiexp: 0.1-0.2 ms of host time per call); 2 only the
+ * group named by mi355zk_prof_only (two records per call: what bench.py leaves on inside its timed region, for the dominant kernel). */
 void mi355zk_prof_enable(int on);
+void mi355zk_prof_only(const char *kernel);
 void mi355zk_prof_reset(void);
 int mi355zk_prof_get(const char *kernel, double *total_ms, long *count);
 

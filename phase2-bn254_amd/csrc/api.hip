@@ -62,16 +62,37 @@ struct ProfSlot {
   std::string name;
   double total_ms = 0;
   long count = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  struct Pair {
+    int dev;
+    hipEvent_t a, b;
+  };
+  std::vector<Pair> pending;
   hipEvent_t open = nullptr;
+  int open_dev = -1;
 };
 std::mutex g_prof_mu;
 std::vector<ProfSlot> g_prof;
-bool g_prof_on = false;
+int g_prof_on = 0;                     // 0 off, 1 every slot, 2 only the slot named by prof_only (the dominant kernel: two events per call)
+int g_prof_only = -1;
+std::map<int, std::vector<hipEvent_t>> g_prof_free;   // per device; events are reused: creating one costs several microseconds on the launching thread
+hipEvent_t prof_event(int* dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  *dev_out = dev;
+  auto& pool = g_prof_free[dev];
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
 }  // namespace
 
-void prof_enable(bool on) { g_prof_on = on; }
-bool prof_enabled() { return g_prof_on; }
+void prof_enable(int on) { g_prof_on = on; }
+bool prof_enabled() { return g_prof_on != 0; }
 int prof_slot(const char* name) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (size_t i = 0; i < g_prof.size(); ++i)
@@ -80,37 +101,46 @@ int prof_slot(const char* name) {
   g_prof.back().name = name;
   return (int)g_prof.size() - 1;
 }
+void prof_only(const char* name) { g_prof_only = name ? prof_slot(name) : -1; }
 void prof_begin(int slot, hipStream_t st) {
-  if (!g_prof_on) return;
+  if (g_prof_on == 0 || (g_prof_on == 2 && slot != g_prof_only)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEvent_t e;
-  if (hipEventCreate(&e) != hipSuccess) return;
+  int dev = 0;
+  hipEvent_t e = prof_event(&dev);
+  if (e == nullptr) return;
   (void)hipEventRecord(e, st);
+  if (g_prof[slot].open) g_prof_free[g_prof[slot].open_dev].push_back(g_prof[slot].open);   // (a begin without its end: several host threads on one slot)
   g_prof[slot].open = e;
+  g_prof[slot].open_dev = dev;
 }
 void prof_end(int slot, hipStream_t st) {
-  if (!g_prof_on) return;
+  if (g_prof_on == 0 || (g_prof_on == 2 && slot != g_prof_only)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof[slot].open) return;
-  hipEvent_t e;
-  if (hipEventCreate(&e) != hipSuccess) return;
+  int dev = 0;
+  hipEvent_t e = prof_event(&dev);
+  if (e == nullptr) return;
+  if (dev != g_prof[slot].open_dev) {   // the pair must be on one device
+    g_prof_free[dev].push_back(e);
+    return;
+  }
   (void)hipEventRecord(e, st);
-  g_prof[slot].pending.emplace_back(g_prof[slot].open, e);
+  g_prof[slot].pending.push_back(ProfSlot::Pair{dev, g_prof[slot].open, e});
   g_prof[slot].open = nullptr;
 }
 void prof_collect() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& s : g_prof) {
     for (auto& pr : s.pending) {
-      if (hipEventSynchronize(pr.second) == hipSuccess) {
+      if (hipEventSynchronize(pr.b) == hipSuccess) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
           s.total_ms += ms;
           s.count += 1;
         }
       }
-      (void)hipEventDestroy(pr.first);
-      (void)hipEventDestroy(pr.second);
+      g_prof_free[pr.dev].push_back(pr.a);
+      g_prof_free[pr.dev].push_back(pr.b);
     }
     s.pending.clear();
   }
@@ -2675,7 +2705,8 @@ int mi355zk_sync(void* stream) {
   });
 }
 
-void mi355zk_prof_enable(int on) { abi_guard_void([&] { prof_enable(on != 0); }); }
+void mi355zk_prof_enable(int on) { abi_guard_void([&] { prof_enable(on < 0 ? 0 : on > 2 ? 1 : on); }); }
+void mi355zk_prof_only(const char* name) { abi_guard_void([&] { prof_only(name); }); }
 void mi355zk_prof_reset(void) { abi_guard_void([&] { prof_reset(); }); }
 int mi355zk_prof_get(const char* kernel, double* total_ms, long* count) {
   return abi_guard([&]() -> int {

@@ -122,7 +122,8 @@ struct KernelTimer {
   long count = 0;
 };
 
-void prof_enable(bool on);
+void prof_enable(int on);   // 0 off, 1 every slot, 2 only the slot of prof_only
+void prof_only(const char* name);
 bool prof_enabled();
 // record start/stop events around a launch on `st`; resolved lazily by prof_collect()
 void prof_begin(int slot, hipStream_t st);

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mi355zk_memcpy_d2h": (_i, [_vp, _vp, _sz]),
     "mi355zk_sync": (_i, [_vp]),
     "mi355zk_prof_enable": (None, [_i]),
+    "mi355zk_prof_only": (None, [C.c_char_p]),
     "mi355zk_prof_reset": (None, []),
     "mi355zk_prof_get": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
 }
