@@ -156,6 +156,15 @@ bool prof_get(const char* name, double* total_ms, long* count) {
     }
   return false;
 }
+void prof_release_all() {   // mi355zk_shutdown: the pooled events go back to their devices
+  prof_collect();
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& kv : g_prof_free) {
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    for (hipEvent_t e : kv.second) (void)hipEventDestroy(e);
+  }
+  g_prof_free.clear();
+}
 void prof_reset() {
   prof_collect();
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -2219,6 +2228,8 @@ int mi355zk_device_count(void) {
 
 void mi355zk_shutdown(void) {
   abi_guard_void([&] {
+    DeviceGuard guard;
+    prof_release_all();
     ntt_release_all();
     exp_scratch_release_all();
     mul_slots_release_all();
