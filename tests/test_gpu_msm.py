@@ -319,12 +319,13 @@ def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group
     got = d_o.cpu().numpy().view(np.uint64)
     for i in range(n):
         assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), np.array(M.to_limbs(vals[i] % R), dtype=np.uint64)))), hex(vals[i])
-    for v in vals[:8]:                                                   # the same values as the ONE scalar of a phase2-style call
+    # the same values as the ONE scalar of a phase2-style call (G1: the sliding-window kernel -- every value, and 0 / 1 / 2 / 3 / r - 1)
+    for v in (vals + [0, 1, 2, 3, R - 1, 31, 32, 33, (1 << 127) - 1] if group == 1 else vals[:8]):
         one = torch.from_numpy(np.array([M.to_limbs(v)], dtype=np.uint64).view(np.int64)).cuda()
         assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(one.data_ptr()), n, 1, None) == 0
         torch.cuda.synchronize()
         got = d_o.cpu().numpy().view(np.uint64)
-        k = np.array(M.to_limbs(v), dtype=np.uint64)
+        k = np.array(M.to_limbs(v % R), dtype=np.uint64)
         for i in range(0, n, 5):
             assert np.array_equal(got[i], G.to_affine(G.mul(G.from_affine(bases[i]), k))), hex(v)
 
