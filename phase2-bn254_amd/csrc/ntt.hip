@@ -66,7 +66,6 @@ struct NttPassParams {
   uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h)
   uint32_t post_h;
   uint32_t xcd_pair;        // 1: tiles 2j and 2j + 1 run on the same XCD, one dispatch round apart (see the kernel)
-  uint32_t in_u, out_u;     // the source / destination is the inter-pass scratch in U-FORM: nine 29-bit limbs, 36 B per element, value < 2p (experiment, round 4)
 };
 
 // table entry (round 4): a twiddle as the PLAIN canonical integer w on nine 29-bit limbs followed by wq = floor(w * 2^261 / p) --
@@ -154,19 +153,6 @@ __device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-__device__ __forceinline__ FrU uload(const Fr* base, uint64_t i) {   // element i of a U-form scratch array (36-byte stride)
-  const uint32_t* q = reinterpret_cast<const uint32_t*>(base) + i * 9;
-  FrU r;
-#pragma unroll
-  for (int l = 0; l < 9; ++l) r.l[l] = q[l];
-  return r;
-}
-__device__ __forceinline__ void ustore(Fr* base, uint64_t i, const FrU& v) {
-  uint32_t* q = reinterpret_cast<uint32_t*>(base) + i * 9;
-#pragma unroll
-  for (int l = 0; l < 9; ++l) q[l] = v.l[l];
-}
-
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
 // Row-local LDS position of element x: the low five bits (the bank) are XOR-ed with the next five.  Any 32
@@ -207,7 +193,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     if (P.load_x_fastest) { x = e & (np - 1); g = e >> LOG_NP; }
     else { g = e % P.g; x = e / P.g; }
     const uint64_t gi = in_base + x * P.in_xs + g * P.in_gs;
-    FrU v = P.in_u ? uload(in, gi) : u_from_std(gload(in + gi));           // < p (< 2p from a U-form scratch), N
+    FrU v = u_from_std(gload(in + gi));                                   // < p, N
     if (P.pre) {                                                          // distribute_powers (domain.rs:176-189)
       v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));                    // g^i = A[i >> h] * B[i & mask]: two products by constants
       v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));     // < 2p, N
@@ -371,8 +357,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       w = post_c;                                                         // minv (ifft, domain.rs:163-173)
     }
     const FrU prod = tw_mul(v, w);                                         // v < 30p, limbs < 4*2^29: < 2p
-    if (P.out_u) ustore(out, go, prod);                                    // the next pass takes it as it is
-    else gstore(out + go, u_to_std_lt2p(prod));
+    gstore(out + go, u_to_std_lt2p(prod));
   }
 }
 
@@ -626,8 +611,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     int dev = 0;
     ZK_HIP(hipGetDevice(&dev));
     ScratchBuf& sb = g_scratch[std::make_pair(dev, st)];
-    static const bool uscratch_sz = std::getenv("MI355ZK_NTT_USCRATCH") != nullptr;
-    const size_t scratch_bytes = uscratch_sz ? n * 36 : n * sizeof(Fr);
+    const size_t scratch_bytes = n * sizeof(Fr);
     if (sb.bytes < scratch_bytes) {
       if (sb.p) {
         ZK_HIP(hipStreamSynchronize(st));  // earlier passes on this stream may still read the old buffer
@@ -713,11 +697,6 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     static const bool pair_all = std::getenv("MI355ZK_NTT_PAIR_ALL") != nullptr;
     // (narrow tiles only: with 128-byte runs and more the grouping is neutral -- measured with MI355ZK_NTT_PAIR_ALL)
     P.xcd_pair = ((P.g <= 2 || pair_all) && tiles % 256 == 0 && !no_pair) ? (pair_env ? (uint32_t)std::atoi(pair_env) : 5u) : 0u;
-    {
-      static const bool uscratch = std::getenv("MI355ZK_NTT_USCRATCH") != nullptr;   // (experiment: U-form inter-pass scratch, 36 B per element)
-      P.in_u = (uscratch && src == scratch) ? 1u : 0u;
-      P.out_u = (uscratch && dst == scratch) ? 1u : 0u;
-    }
     if (p == 0 && Tpre) { P.pre = 1; P.pre_h = Tpre->h; }
     if (p == R - 1) { P.post = Tpost ? 2 : (post_c ? 1 : 3); P.post_h = Tpost ? Tpost->h : 0; }
     uint32_t pitch = np >= 32 ? (uint32_t)np + 1 : (uint32_t)np;
