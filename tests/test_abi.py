@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 import bn254_model as M
 import inputs
@@ -146,3 +147,17 @@ def test_device_set_queries_work_without_a_gpu():
     ids = (C.c_int * 2)(0, 1 << 20)
     assert lib.mi355zk_init(ids, 2) != 0
     assert lib.mi355zk_init(None, -1) != 0
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/mi355zk.h is what a C / cgo / bindgen consumer includes: it must compile as C99 with warnings on, without HIP or C++."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "mi355zk.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
