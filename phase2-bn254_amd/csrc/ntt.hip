@@ -420,6 +420,30 @@ constexpr uint32_t NTT_FULL_TW_MAX_LOG = 20;
 std::mutex g_mu;
 std::map<Key, PowTables> g_tables;
 
+// The cache is keyed on arbitrary roots (best_fft takes a caller-supplied omega): bounded per device, so that a caller cycling through
+// roots cannot grow device memory without limit.  Called ONCE at the start of a transform (under g_run_mu), before any of its up to
+// three table lookups: a drop between two lookups of one call would free the tables the first lookup has just returned (found by the
+// NTT fuzz: 64 + entries in one process).  Dropping this device's entries is safe once the device is idle.
+constexpr size_t NTT_TABLES_MAX = 64;
+int tables_make_room(size_t need) {
+  int dev = 0;
+  ZK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  size_t mine = 0;
+  for (auto& kv : g_tables) mine += kv.first.dev == dev ? 1 : 0;
+  if (mine + need <= NTT_TABLES_MAX) return ZK_OK;
+  ZK_HIP(hipDeviceSynchronize());
+  for (auto it = g_tables.begin(); it != g_tables.end();) {
+    if (it->first.dev != dev) { ++it; continue; }
+    (void)hipFree(it->second.A);
+    (void)hipFree(it->second.B);
+    (void)hipFree(it->second.full);
+    for (auto* r : it->second.roots) (void)hipFree(r);
+    it = g_tables.erase(it);
+  }
+  return ZK_OK;
+}
+
 int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_roots, const uint32_t* bs, int nb, PowTables** out,
                      uint32_t full_log_s = 0) {
   int dev = 0;
@@ -429,18 +453,6 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
   key.log_n = log_n;
   for (int i = 0; i < 8; ++i) key.w[i] = w.l[i];
   std::lock_guard<std::mutex> lk(g_mu);
-  // The cache is keyed on arbitrary roots (best_fft takes a caller-supplied omega): bounded, so that a caller cycling through
-  // roots cannot grow device memory without limit.  Dropping everything is safe once the device is idle.
-  if (g_tables.find(key) == g_tables.end() && g_tables.size() >= 64) {
-    ZK_HIP(hipDeviceSynchronize());
-    for (auto& kv : g_tables) {
-      (void)hipFree(kv.second.A);
-      (void)hipFree(kv.second.B);
-      (void)hipFree(kv.second.full);
-      for (auto* r : kv.second.roots) (void)hipFree(r);
-    }
-    g_tables.clear();
-  }
   PowTables& T = g_tables[key];
   bool built = false;
   // on any failure the entry is removed again: a half-built entry (A set, B or a roots table missing) would be taken for
@@ -594,6 +606,8 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   // held from the table lookup to the last launch: the table cache may be dropped (when full) only while nobody is between
   // "got a table pointer" and "enqueued the kernels that read it"
   std::lock_guard<std::mutex> run_lk(g_run_mu);
+  rc = tables_make_room(3);
+  if (rc) return rc;
   PowTables* T = nullptr;
   static const bool no_full = std::getenv("MI355ZK_NTT_NO_FULL_TW") != nullptr;  // (the two-level product, kept for the comparison in DESIGN.md)
   const bool full_tw = R == 2 && log_n <= NTT_FULL_TW_MAX_LOG && !no_full;
@@ -751,7 +765,9 @@ int ntt_scale(Fr* d_a, uint32_t log_n, const Fr& c, const Fr* g, hipStream_t st)
   std::lock_guard<std::mutex> run_lk(g_run_mu);
   if (g != nullptr && log_n > 0) {
     PowTables* T = nullptr;
-    int rc = build_pow_tables(st, log_n, *g, false, nullptr, 0, &T);
+    int rc = tables_make_room(1);
+    if (rc) return rc;
+    rc = build_pow_tables(st, log_n, *g, false, nullptr, 0, &T);
     if (rc) return rc;
     A = T->A;
     B = T->B;

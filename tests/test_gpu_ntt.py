@@ -140,3 +140,25 @@ def test_divide_by_z_on_coset_and_z(zk, worker):
     zinv = mont(pow((pow(7, 1 << log_n, r) - 1) % r, -1, r))
     want = O.fe_mul_many(O.FR, a, np.tile(zinv, (1 << log_n, 1))).reshape(-1, 4)
     assert np.array_equal(dom.coeffs.cpu().numpy().view(np.uint64), want)
+
+
+def test_table_cache_drop_between_the_lookups_of_one_transform(zk, worker):
+    """The (device, size, root) table cache holds 64 entries per device and drops them all when a transform needs room.  A coset
+    transform on a fresh size looks up two new tables (omega and g): the drop must happen BEFORE the first lookup, never between the two
+    (the tables the first one returned would be freed under the launch -- found by tools/fuzz_ntt.py once a process had used more than
+    64 (size, root) pairs).  Two sweeps of coset_fft / icoset_fft over 2^1 .. 2^17 (two new entries per call, 68 per sweep) with a
+    one-entry call between them, so that the limit is met at both parities of the count whatever the earlier tests left in the cache;
+    every transform is checked against the oracle."""
+    def run(log_n, op, seed):
+        a = inputs.random_fr_mont(1 << log_n, seed=seed)
+        dom = zk.EvaluationDomain.from_coeffs(a)
+        getattr(dom, op)(worker)
+        assert np.array_equal(dom.into_coeffs(), O.fr_domain_op(a, log_n, op).reshape(-1, 4)), (log_n, op)
+
+    for sweep in range(2):
+        for log_n in range(1, 18):
+            run(log_n, "coset_fft", 7000 + 100 * sweep + log_n)
+            run(log_n, "icoset_fft", 7050 + 100 * sweep + log_n)
+        run(18, "fft", 7300 + sweep)         # one entry: the next sweep meets the limit at the other parity
+    run(18, "coset_fft", 7400)
+    run(19, "icoset_fft", 7401)
