@@ -576,6 +576,20 @@ static int exp_scratch(size_t bytes, void* stream, void** out) {
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_exp_mu);
+  // (one buffer per stream a caller has ever used: bounded.  Past 16 streams on this device everything is dropped once the device
+  // is idle -- the callers hold g_exp_launch_mu, so no other scalar-multiplication kernels are being enqueued meanwhile.)
+  if (g_exp_scratch.find(std::make_pair(dev, stream)) == g_exp_scratch.end()) {
+    size_t mine = 0;
+    for (auto& kv : g_exp_scratch) mine += kv.first.first == dev ? 1 : 0;
+    if (mine >= 16) {
+      ZK_HIP(hipDeviceSynchronize());
+      for (auto it = g_exp_scratch.begin(); it != g_exp_scratch.end();) {
+        if (it->first.first != dev) { ++it; continue; }
+        (void)hipFree(it->second.p);
+        it = g_exp_scratch.erase(it);
+      }
+    }
+  }
   ExpScratch& sb = g_exp_scratch[std::make_pair(dev, stream)];
   if (sb.bytes < bytes) {
     if (sb.p) {

@@ -624,6 +624,21 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   if (R > 1) {
     int dev = 0;
     ZK_HIP(hipGetDevice(&dev));
+    // (one buffer per stream a caller has ever used: bounded -- a caller that makes a stream per call must not pin a buffer per
+    // stream for ever.  Past 16 streams on this device everything is dropped once the device is idle; g_run_mu keeps other
+    // transforms from being enqueued meanwhile.)
+    if (g_scratch.find(std::make_pair(dev, st)) == g_scratch.end()) {
+      size_t mine = 0;
+      for (auto& kv : g_scratch) mine += kv.first.first == dev ? 1 : 0;
+      if (mine >= 16) {
+        ZK_HIP(hipDeviceSynchronize());
+        for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+          if (it->first.first != dev) { ++it; continue; }
+          (void)hipFree(it->second.p);
+          it = g_scratch.erase(it);
+        }
+      }
+    }
     ScratchBuf& sb = g_scratch[std::make_pair(dev, st)];
     const size_t scratch_bytes = n * sizeof(Fr);
     if (sb.bytes < scratch_bytes) {

@@ -162,3 +162,31 @@ def test_table_cache_drop_between_the_lookups_of_one_transform(zk, worker):
         run(18, "fft", 7300 + sweep)         # one entry: the next sweep meets the limit at the other parity
     run(18, "coset_fft", 7400)
     run(19, "icoset_fft", 7401)
+
+
+def test_scratch_buffers_are_bounded_over_many_streams(zk, worker):
+    """The inter-pass scratch of a transform (and the Z / table scratch of batch_exp) is kept per (device, stream); a caller that
+    makes a stream per call must not pin a buffer per stream for ever: past 16 streams the buffers are dropped (device idle) and made
+    again.  40 streams, a two-pass transform and a batch_exp on each, results against the oracle."""
+    import torch
+
+    import bn254_model as M
+
+    log_n = 12
+    a = inputs.random_fr_mont(1 << log_n, seed=7500)
+    want = O.fr_domain_op(a, log_n, "coset_fft").reshape(-1, 4)
+    bases = inputs.bases_progression_cpu(1, 64, seed=7501)
+    k = np.array([M.to_limbs(0x1234567890ABCDEF1234567890ABCDEF)], dtype=np.uint64)
+    want_exp = np.stack([O.G1.to_affine(O.G1.mul(O.G1.from_affine(bases[i]), k[0])) for i in (0, 63)])
+    d_b = torch.from_numpy(bases.view(np.int64)).cuda()
+    d_k = torch.from_numpy(k.view(np.int64)).cuda()
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    for s in streams:
+        with torch.cuda.stream(s):
+            dom = zk.EvaluationDomain.from_coeffs(a)
+            dom.coset_fft(worker)
+            got = dom.into_coeffs()
+            out = zk.ceremony.batch_exp(d_b, d_k, same_scalar=True)
+            s.synchronize()
+        assert np.array_equal(got, want)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64)[[0, 63]], want_exp)
