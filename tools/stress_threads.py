@@ -50,6 +50,9 @@ for g, G in ((1, O.G1), (2, O.G2)):
     jobs.append((f"power_pairs g{g}", fm, np.concatenate([w1, w2])))
 print(f"{len(jobs)} kinds of call prepared", flush=True)
 if a.prof: zk.lib.load().mi355zk_prof_enable(1)
+for _name, _f, _w in jobs: _f()          # every kind once: caches, tables and pools are in place before the memory reading
+torch.cuda.synchronize()
+free0, res0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
 bad, count, lock = [], [0], threading.Lock()
 t_end = time.time() + a.seconds
 def run(tid):
@@ -71,6 +74,9 @@ def run(tid):
             if a.prof and tid == 0 and count[0] % 500 == 0: zk.lib.load().mi355zk_prof_reset()
 ths = [threading.Thread(target=run, args=(i,)) for i in range(a.threads)]
 [t.start() for t in ths]; [t.join() for t in ths]
+torch.cuda.synchronize()
+free1, res1 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+print(f"device memory in use grew by {(free0 - free1) / 2**20:.1f} MiB over the run, {(res1 - res0) / 2**20:.1f} MiB of it in torch's caching allocator (the test's own tensors, per stream); the rest is the library's (per-stream scratch, workspaces of concurrent calls)")
 print(f"stress_threads: {count[0]} calls from {a.threads} threads in {a.seconds:.0f} s, {len(bad)} failures (seed {a.seed}, {a.devices} logical device(s))")
 for b in bad: print("  FAIL", b)
 sys.exit(1 if bad else 0)
