@@ -917,4 +917,146 @@ ZK_HD Jacobian<Fq2> jacu2_to_std(const JacU2& a) {
   return r;
 }
 
+// 2 * (x2, y2) over Fq2 in U-form, x2, y2 canonical memory-format values re-packed (u_from_std)   [mdbl-2008-s-1, as xyzzu_double_affine]
+ZK_HD XYZZU2 xyzzu2_double_affine(const Fq2U& x2, const Fq2U& y2) {
+  const FqU C = UPow2<FqParams, 266>::get();
+  const FqU zero = FqU::zero();
+  const Fq2U x = Fq2U{u_mul(x2.c0, C), u_mul(x2.c1, C)};     // * 2^261, < 2p, N
+  const Fq2U y = Fq2U{u_mul(y2.c0, C), u_mul(y2.c1, C)};
+  const Fq2U u = f2u_carry(f2u_dbl(y));                      // < 4p, N
+  const Fq2U v = f2u_sqr<4>(u);                              // c0 < 8 * 8 c + 1 < 1.38p,  c1 < 32 c + 1 < 1.19p
+  const Fq2U w = f2u_mul<2>(u, v);                           // c0 < (4 * 1.38 + 4 * 2) c + 1 < 1.09p,  c1 < (4 * 1.19 + 4 * 1.38) c + 1 < 1.07p
+  const Fq2U s = f2u_mul<2>(x, v);                           // < 1.05p
+  const Fq2U xx = f2u_sqr<2>(x);                             // c0 < 4 * 4 c + 1 < 1.1p,  c1 < 8 c + 1 < 1.05p
+  const Fq2U m = f2u_carry(f2u_add(f2u_dbl(xx), xx));        // 3 xx < 3.3p, N
+  const Fq2U mm = f2u_sqr<4>(m);                             // c0 < 6.6 * 7.3 c + 1 < 1.29p,  c1 < 21.8 c + 1 < 1.13p
+  XYZZU2 r;
+  r.x = Fq2U{u_sub<4, 2>(mm.c0, u_dbl(s.c0)), u_sub<4, 2>(mm.c1, u_dbl(s.c1))};   // 2s < 2.1p <= 4p, limbs < 2^30;  X < 5.3p
+  const Fq2U d = f2u_sub<8>(s, r.x);                         // < 9.05p
+  const FqU nd1 = u_sub<16, 1>(zero, d.c1), ny0 = u_sub<2, 1>(zero, y.c0), ny1 = u_sub<2, 1>(zero, y.c1);
+  // M D - W y:  c0 = M0 D0 + M1 (16p - D1) + W0 (2p - y0) + W1 y1;  c1 = M0 D1 + M1 D0 + W0 (2p - y1) + W1 (2p - y0)
+  r.y.c0 = u_mul4(m.c0, d.c0, m.c1, nd1, w.c0, ny0, w.c1, y.c1);   // (29.9 + 52.8 + 2.2 + 2.2) c + 1 < 1.52p
+  r.y.c1 = u_mul4(m.c0, d.c1, m.c1, d.c0, w.c0, ny1, w.c1, ny0);   // (29.9 + 29.9 + 2.2 + 2.2) c + 1 < 1.38p
+  r.zz = Fq2U{u_mul(v.c0, C), u_mul(v.c1, C)};               // * 2^266, < 2p
+  r.zzz = Fq2U{u_mul(w.c0, C), u_mul(w.c1, C)};
+  return r;
+}
+
+#if defined(__HIPCC__)
+// ---- the G2 bucket accumulator held by a PAIR of lanes (lanes 2k, 2k + 1 of a wave; msm_impl.hpp: msm_accumulate_pair_kernel).
+// The one-lane Fq2 accumulation needs the accumulator (72 registers), the operands and the temporaries of 8M + 2S over Fq2 at
+// once: 256 VGPRs + ~150 AGPRs, ONE wave per SIMD, and its multipliers run at 61 % of their rate (G1, four waves: 76 - 83 %).
+// Here the EVEN lane keeps (X, ZZ) and the ODD lane (Y, ZZZ) -- 36 registers each -- and the mixed addition is five rounds in
+// which both lanes run the SAME product routine on their own operands (no divergence), all nine products of the addition
+// exactly once over the pair:
+//     round 1  f2u_mul    even: U2 = x2 ZZ            odd: S2 = y2 ZZZ          then  P = U2 - X  |  R = S2 - Y
+//     round 2  square     even: PP = P^2              odd: RR = R^2
+//     round 3  f2u_mul    even: Q = X PP              odd: PPP = P PP           then  X3 = RR - PPP - 2Q,  D = Q - X3  (both lanes)
+//     round 4  f2u_mul    even: ZZ3 = ZZ PP           odd: ZZZ3 = ZZZ PPP
+//     round 5  u_mul4     even: Y3.c0                 odd: Y3.c1                (R D - Y PPP, one reduction per component)
+// 18 Fq products + 9 reductions per lane, 36 + 18 per pair (one lane: 37 + 18).  Values cross between the two lanes by DPP
+// quad permutes (v_mov_b32 quad_perm, full rate, no LDS): P, R, PP, RR, Q, PPP, Y and Y3.c0 -- ~170 moves and ~110 selects per
+// addition against ~2400 multiplier instructions per lane.  Each lane gathers only ITS coordinate of the base (64 B).
+// Bounds are those of xyzzu2_add_mixed except where noted.  BOTH lanes of a pair must be active wherever this is called.
+constexpr int PAIR_SWAP = 0xB1, PAIR_EVEN = 0xA0, PAIR_ODD = 0xF5;   // quad_perm [1,0,3,2] / [0,0,2,2] / [1,1,3,3]
+template <int CTRL>
+__device__ __forceinline__ uint32_t pair_dpp(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+#else
+  return v;   // (host pass of hipcc: never executed)
+#endif
+}
+template <int CTRL>
+__device__ __forceinline__ FqU pair_dpp(const FqU& a) {
+  FqU r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = pair_dpp<CTRL>(a.l[i]);
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ Fq2U pair_dpp(const Fq2U& a) { return Fq2U{pair_dpp<CTRL>(a.c0), pair_dpp<CTRL>(a.c1)}; }
+__device__ __forceinline__ Fq2U pick2(bool second, const Fq2U& a, const Fq2U& b) { return Fq2U{pick2(second, a.c0, b.c0), pick2(second, a.c1, b.c1)}; }
+// a + k p - b with k = KE on the even lane and KO on the odd one (u_sub's preconditions with the lane's k; S as there)
+template <int KE, int KO, int S>
+__device__ __forceinline__ FqU u_sub_role(bool odd, const FqU& a, const FqU& b) {
+  FqU t;
+  for_limbs<9>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr uint32_t ke = USubConst<FqParams, KE, S>::limb(i), ko = USubConst<FqParams, KO, S>::limb(i);
+    t.l[i] = a.l[i] + (odd ? ko : ke) - b.l[i];
+  });
+  return u_carry(t);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_PAIR_ROUND() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZK_PAIR_ROUND() ((void)0)
+#endif
+
+struct PairAcc2 {
+  Fq2U a, z;   // even lane: (X, ZZ), odd lane: (Y, ZZZ);  domains and bounds of XYZZU2.  Infinity: z == literal zeros in BOTH lanes
+  __device__ __forceinline__ static PairAcc2 zero() { return PairAcc2{Fq2U::zero(), Fq2U::zero()}; }
+  __device__ __forceinline__ bool is_zero() const { return z.limbs_all_zero(); }
+};
+
+// acc += (+/-)(x2, y2);  c2s = this lane's coordinate of the base (even: x2, odd: y2; canonical memory format), not infinity.
+__device__ __forceinline__ PairAcc2 pair_add_mixed(PairAcc2 acc, const Fq2& c2s, bool negate, bool odd) {
+  const FqU zero = FqU::zero();
+  Fq2U c2 = f2u_from_std(c2s);                               // < p
+  {
+    const FqU n0 = u_sub<1, 1>(zero, c2.c0), n1 = u_sub<1, 1>(zero, c2.c1);   // p - y, N
+    const bool ng = negate && odd;
+    c2 = Fq2U{pick2(ng, c2.c0, n0), pick2(ng, c2.c1, n1)};
+  }
+  if (acc.is_zero()) {                                       // (uniform over the pair)
+    const FqU C = UPow2<FqParams, 266>::get();
+    acc.a = Fq2U{u_mul(c2.c0, C), u_mul(c2.c1, C)};          // * 2^261, < 2p
+    acc.z = Fq2U{C, zero};                                   // (1, 0) * 2^266
+    return acc;
+  }
+  const Fq2U m = f2u_mul<2>(c2, acc.z);                      // even: U2, odd: S2;  < 1.03p
+  const Fq2U d1 = Fq2U{u_sub_role<8, 2, 1>(odd, m.c0, acc.a.c0), u_sub_role<8, 2, 1>(odd, m.c1, acc.a.c1)};   // even: P < 10p (X < 6p);  odd: R < 4p (Y < 2p)
+  ZK_PAIR_ROUND();
+  Fq2U sq;                                                   // (v0 + v1)(v0 - v1) + 2 v0 v1 u
+  sq.c0 = u_mul(u_carry(u_add(d1.c0, d1.c1)), u_sub_role<10, 4, 1>(odd, d1.c0, d1.c1));   // even: 20 * 20 c + 1 < 3.37p;  odd: 8 * 8 c + 1 < 1.39p
+  sq.c1 = u_mul(u_dbl(d1.c0), d1.c1);                        // even: 200 c + 1 < 2.19p;  odd: 32 c + 1 < 1.2p
+  ZK_PAIR_ROUND();
+  const Fq2U pp = pair_dpp<PAIR_EVEN>(sq), rr = pair_dpp<PAIR_ODD>(sq);
+  const Fq2U p = pair_dpp<PAIR_EVEN>(d1), r = pair_dpp<PAIR_ODD>(d1);
+  const Fq2U m3 = f2u_mul<4>(pick2(odd, acc.a, p), pp);      // even: Q = X PP: (6 * 3.37 + 6 * 4) c + 1 < 1.27p, (6 * 2.19 + 6 * 3.37) c + 1 < 1.2p
+                                                             // odd: PPP = P PP: (33.7 + 40) c + 1 < 1.44p, (21.9 + 33.7) c + 1 < 1.33p
+  ZK_PAIR_ROUND();
+  const Fq2U q = pair_dpp<PAIR_EVEN>(m3), ppp = pair_dpp<PAIR_ODD>(m3);
+  const Fq2U z3 = f2u_mul<4>(acc.z, pick2(odd, pp, ppp));    // even: ZZ3 = ZZ PP < 1.09p;  odd: ZZZ3 = ZZZ PPP < 1.07p
+  ZK_PAIR_ROUND();
+  Fq2U x3;
+  x3.c0 = u_sub<4, 3>(rr.c0, u_add(ppp.c0, u_dbl(q.c0)));    // PPP + 2Q < 1.44p + 2.53p < 4p, limbs < 3 * 2^29;  X3 < 5.4p
+  x3.c1 = u_sub<4, 3>(rr.c1, u_add(ppp.c1, u_dbl(q.c1)));
+  const Fq2U d = f2u_sub<8>(q, x3);                          // < 9.3p
+  const Fq2U y = pair_dpp<PAIR_ODD>(acc.a);
+  const FqU ny0 = u_sub<2, 1>(zero, y.c0), ny1 = u_sub<2, 1>(zero, y.c1), nd1 = u_sub<16, 1>(zero, d.c1);
+  // even: R0 D0 + R1 (16p - D1) + (2p - Y0) PPP0 + Y1 PPP1 < 1.65p;   odd: R0 D1 + R1 D0 + (2p - Y0) PPP1 + (2p - Y1) PPP0 < 1.48p
+  const FqU t = u_mul4(r.c0, pick2(odd, d.c0, d.c1), r.c1, pick2(odd, nd1, d.c0), ny0, pick2(odd, ppp.c0, ppp.c1), pick2(odd, y.c1, ny1),
+                       pick2(odd, ppp.c1, ppp.c0));
+  ZK_PAIR_ROUND();
+  const FqU t0 = pair_dpp<PAIR_EVEN>(t);
+  if (u_is_zero_lt2p(z3.c0) && u_is_zero_lt2p(z3.c1)) {
+    // P == 0 (ZZ3 = ZZ P^2 and ZZZ3 = ZZZ P^3 vanish together: uniform over the pair): same x.  Same point -> double
+    // (ec.rs:483-485), opposite -> infinity (ec.rs:487).  Rare: the whole doubling in U-form, in both lanes.
+    PairAcc2 res = PairAcc2::zero();
+    if (u_is_zero_lt8p(r.c0) && u_is_zero_lt8p(r.c1)) {
+      const Fq2U o2 = pair_dpp<PAIR_SWAP>(c2);               // the other lane's coordinate (y already carries the sign)
+      const XYZZU2 dbl = xyzzu2_double_affine(pick2(odd, c2, o2), pick2(odd, o2, c2));
+      res = PairAcc2{pick2(odd, dbl.x, dbl.y), pick2(odd, dbl.zz, dbl.zzz)};
+    }
+    return res;
+  }
+  acc.a = Fq2U{pick2(odd, x3.c0, t0), pick2(odd, x3.c1, t)};
+  acc.z = z3;
+  return acc;
+}
+#endif  // __HIPCC__
+
 }  // namespace zk

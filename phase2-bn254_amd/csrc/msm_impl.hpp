@@ -1314,6 +1314,96 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   store_vec(buckets + b, xyzzu_to_r(accumulate_run<F, A4>(acc, bases, vals, j, e, 1, skip_zero != 0, err_base)));
 }
 
+// 4b'. G2: one PAIR of lanes per bucket (curveu.hpp: PairAcc2 / pair_add_mixed -- the even lane keeps (X, ZZ) and gathers the
+//     base's x, the odd lane keeps (Y, ZZZ) and gathers y; the same products as the one-lane addition, split evenly, at half the
+//     registers per lane).  Same lists, same order, same records as msm_accumulate_kernel<Fq2>: bit-identical bucket sums.
+constexpr uint32_t MSM_PAIR_MAX_BUCKETS = 3u << 17;   // (2^18 points: 17 windows x 2^14 buckets = 278 k -> pairs; 2^19: 16 x 2^15 = 524 k -> lanes)
+template <bool A4>
+__device__ __forceinline__ PairAcc2 accumulate_run_pair(PairAcc2 acc, const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
+                                                        bool odd, bool skip_zero, unsigned long long* __restrict__ err_base) {
+  // (accumulate_run with stride 1; both lanes of the pair walk the same list and stay together)
+  uint4 q = make_uint4(0, 0, 0, 0);
+  uint32_t v;
+  if constexpr (A4) {
+    q = *reinterpret_cast<const uint4*>(vals + j);
+    v = q.x;
+  } else {
+    v = vals[j];
+  }
+  const uint32_t co = odd ? 1u : 0u;
+  Fq2 p = load_vec(reinterpret_cast<const Fq2*>(bases + (v & ~SIGN_BIT)) + co);
+  for (;;) {
+    const uint32_t jn = j + 1;
+    const bool more = jn < e;
+    uint32_t vn = 0;
+    Fq2 pn = p;
+    if constexpr (A4) {
+      if ((jn & 3u) == 0) {
+        if (more) q = *reinterpret_cast<const uint4*>(vals + jn);
+      } else {
+        q.x = q.y; q.y = q.z; q.z = q.w;
+      }
+      vn = q.x;
+      if (more) pn = load_vec(reinterpret_cast<const Fq2*>(bases + (vn & ~SIGN_BIT)) + co);
+    } else if (more) {
+      vn = vals[jn];
+      pn = load_vec(reinterpret_cast<const Fq2*>(bases + (vn & ~SIGN_BIT)) + co);
+    }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nz |= p.c0.l[k] | p.c1.l[k];
+    const uint32_t ynz = pair_dpp<PAIR_ODD>(nz);   // the all-zero record is the point at infinity: y == 0 (the odd lane's coordinate)
+    if (ynz != 0) {
+      acc = pair_add_mixed(acc, p, (v & SIGN_BIT) != 0, odd);
+    } else if (!skip_zero && odd) {
+      atomicMin(err_base, (unsigned long long)(v & ~SIGN_BIT));
+    }
+    if (!more) break;
+    v = vn;
+    p = pn;
+    j = jn;
+  }
+  return acc;
+}
+
+template <bool A4, bool CARRY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_accumulate_pair_kernel(const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                                                 const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                                 const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
+                                                                 XYZZ<Fq2>* __restrict__ buckets, int skip_zero, unsigned long long* __restrict__ err_base) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, i = gt >> 1;
+  const bool odd = (gt & 1u) != 0;
+  if (i >= n_buckets) return;                          // (whole pairs leave: every test up to the loop is on i)
+  const uint32_t b = order[i];
+  const uint32_t j = first[b], e = last[b];
+  if (i < hb && e - j > heavy) return;
+  Fq2* rec = reinterpret_cast<Fq2*>(buckets + b);      // {x, y, zz, zzz}: this lane's coordinates are rec[odd] and rec[2 + odd]
+  const uint32_t co = odd ? 1u : 0u;
+  if (j >= e) {
+    if constexpr (!CARRY) {
+      store_vec(rec + co, Fq2::zero());
+      store_vec(rec + 2 + co, Fq2::zero());
+    }
+    return;
+  }
+  PairAcc2 acc = PairAcc2::zero();
+  if constexpr (CARRY) {                               // xyzzu_from_r, coordinate by coordinate (the zero record gives zero limbs)
+    const Fq2 ra = load_vec(rec + co), rz = load_vec(rec + 2 + co);
+    const FqU c266 = UPow2<FqParams, 266>::get();
+    acc.a = f2u_from_std(ra);
+    acc.z = Fq2U{u_mul(u_from_std(rz.c0), c266), u_mul(u_from_std(rz.c1), c266)};
+  }
+  acc = accumulate_run_pair<A4>(acc, bases, vals, j, e, odd, skip_zero != 0, err_base);
+  Fq2 oa = Fq2::zero(), oz = Fq2::zero();
+  if (!acc.is_zero()) {                                // xyzzu_to_r, coordinate by coordinate
+    const FqU c256 = UPow2<FqParams, 256>::get();
+    oa = Fq2{u_to_std_lt32p(acc.a.c0), u_to_std_lt32p(acc.a.c1)};
+    oz = Fq2{u_to_std_lt2p(u_mul(acc.z.c0, c256)), u_to_std_lt2p(u_mul(acc.z.c1, c256))};
+  }
+  store_vec(rec + co, oa);
+  store_vec(rec + 2 + co, oz);
+}
+
 // 4c. SHORT calls: the launch above lasts as long as its LONGEST bucket -- a lane adds a point every ~8 us however idle the device is,
 //     and among 2^18 buckets of 4 points on average some hold 14 (2^16 points: 139 us of accumulation where the additions themselves
 //     are 80 us of the device's time).  Buckets longer than `split_t` (and not heavy) are therefore taken out of the lane-per-bucket
@@ -2246,7 +2336,29 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
                          C.split_t, C.heavy, C.split_hb, buckets, dense ? 1 : 0, d_err);
       ZK_HIP(hipGetLastError());
     }
-    if (carry) {
+    bool pair_done = false;
+    if constexpr (std::is_same<F, Fq2>::value) {
+      // G2: a pair of lanes per bucket (msm_accumulate_pair_kernel) while the bucket lanes do not fill the device several times over:
+      // there a launch lasts as long as its lanes' chains of dependent additions, and the pair's chain is half as long (2^16 points:
+      // accumulate 0.416 -> 0.312 ms, the call 1.27 -> 1.17; 2^12: 0.845 -> 0.82; 2^18: 2.09 -> 2.04).  With >= 2^19 buckets both
+      // forms run at the multiplier's rate and the pair pays its ~280 moves / selects per addition (2^20: 3.37 -> 3.48 ms, 2^22:
+      // 13.1 -> 13.7): tools/ab_g2_pair.sh, profiles/r04_ab_g2_pair.txt.  MI355ZK_G2_PAIR=0 / 1: never / always.
+      static const int pair_mode = [] { const char* s = std::getenv("MI355ZK_G2_PAIR"); return !s ? -1 : s[0] == '0' ? 0 : 1; }();
+      const bool pair = pair_mode < 0 ? n_buckets <= MSM_PAIR_MAX_BUCKETS : pair_mode != 0;
+      if (pair) {
+        const dim3 pgrid((uint32_t)((2ull * n_buckets + 255) / 256));
+        if (carry) {
+          if (a4) hipLaunchKernelGGL((msm_accumulate_pair_kernel<true, true>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+          else hipLaunchKernelGGL((msm_accumulate_pair_kernel<false, true>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+        } else {
+          if (a4) hipLaunchKernelGGL((msm_accumulate_pair_kernel<true, false>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+          else hipLaunchKernelGGL((msm_accumulate_pair_kernel<false, false>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+        }
+        pair_done = true;
+      }
+    }
+    if (pair_done) {
+    } else if (carry) {
       if (a4)
         hipLaunchKernelGGL((msm_accumulate_kernel<F, true, true>), grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets,
                            buckets, dense ? 1 : 0, d_err);
