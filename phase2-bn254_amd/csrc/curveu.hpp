@@ -1001,6 +1001,52 @@ struct PairAcc2 {
   __device__ __forceinline__ bool is_zero() const { return z.limbs_all_zero(); }
 };
 
+// ---- the same split for G1 (short calls: msm_accumulate_pair_g1_kernel): U2 | S2, PP | RR, Q | PPP, ZZ3 | ZZZ3 as single products, then
+// Y3 = R D - Y PPP (one u_mul2) in both lanes: 3 u_mul + 1 u_sqr + 1 u_mul2 deep (891 multiplier instructions) instead of the
+// 1467 of the one-lane addition.  No throughput to gain (the pair issues 1782) -- it is for launches that last as long as their
+// lanes' chains of dependent additions.  Bounds of xyzzu_add_mixed.
+struct PairAcc1 {
+  FqU a, z;   // even lane: (X, ZZ), odd lane: (Y, ZZZ);  domains and bounds of XYZZU.  Infinity: z == literal zeros in BOTH lanes
+  __device__ __forceinline__ static PairAcc1 zero() { return PairAcc1{FqU::zero(), FqU::zero()}; }
+  __device__ __forceinline__ bool is_zero() const { return z.limbs_all_zero(); }
+};
+__device__ __forceinline__ PairAcc1 pair_add_mixed(PairAcc1 acc, const Fq& c2s, bool negate, bool odd) {
+  const FqU zero = FqU::zero();
+  FqU c2 = u_from_std(c2s);                                  // < p
+  c2 = pick2(negate && odd, c2, u_sub<1, 1>(zero, c2));      // odd lane: (+/-) y2
+  if (acc.is_zero()) {                                       // (uniform over the pair)
+    const FqU C = UPow2<FqParams, 266>::get();
+    acc.a = u_mul(c2, C);                                    // * 2^261, < 2p
+    acc.z = C;                                               // 1 * 2^266
+    return acc;
+  }
+  const FqU m = u_mul(c2, acc.z);                            // even: U2, odd: S2;  < 2p
+  const FqU d1 = u_sub_role<8, 2, 1>(odd, m, acc.a);         // even: P < 10p (X < 6p);  odd: R < 4p (Y < 2p)
+  const FqU sq = u_sqr(d1);                                  // even: PP < 100 c + 1 < 1.6p;  odd: RR < 16 c + 1 < 1.1p
+  const FqU pp = pair_dpp<PAIR_EVEN>(sq), rr = pair_dpp<PAIR_ODD>(sq);
+  const FqU p = pair_dpp<PAIR_EVEN>(d1), r = pair_dpp<PAIR_ODD>(d1);
+  const FqU m3 = u_mul(pick2(odd, acc.a, p), pp);            // even: Q = X PP < 1.06p;  odd: PPP = P PP < 1.1p
+  const FqU q = pair_dpp<PAIR_EVEN>(m3), ppp = pair_dpp<PAIR_ODD>(m3);
+  const FqU z3 = u_mul(acc.z, pick2(odd, pp, ppp));          // even: ZZ3 = ZZ PP;  odd: ZZZ3 = ZZZ PPP;  < 2p
+  const FqU x3 = u_sub<4, 3>(rr, u_add(ppp, u_dbl(q)));      // PPP + 2Q < 3.3p <= 4p, limbs < 3 * 2^29;  X3 < 5.1p
+  const FqU d = u_sub<8, 1>(q, x3);                          // < 9.1p
+  const FqU y = pair_dpp<PAIR_ODD>(acc.a);
+  const FqU y3 = u_mul2(r, d, u_sub<2, 1>(zero, y), ppp);    // R D - Y PPP < 1.24p  (both lanes; the odd one keeps it)
+  if (u_is_zero_lt2p(z3)) {
+    // P == 0 (uniform over the pair, see the G2 form): same point -> double (ec.rs:483-485), opposite -> infinity (ec.rs:487)
+    PairAcc1 res = PairAcc1::zero();
+    if (u_is_zero_lt8p(r)) {
+      const FqU o2 = pair_dpp<PAIR_SWAP>(c2);
+      const XYZZU<FqParams> dbl = xyzzu_double_affine(pick2(odd, c2, o2), pick2(odd, o2, c2));
+      res = PairAcc1{pick2(odd, dbl.x, dbl.y), pick2(odd, dbl.zz, dbl.zzz)};
+    }
+    return res;
+  }
+  acc.a = pick2(odd, x3, y3);
+  acc.z = z3;
+  return acc;
+}
+
 // acc += (+/-)(x2, y2);  c2s = this lane's coordinate of the base (even: x2, odd: y2; canonical memory format), not infinity.
 __device__ __forceinline__ PairAcc2 pair_add_mixed(PairAcc2 acc, const Fq2& c2s, bool negate, bool odd) {
   const FqU zero = FqU::zero();
@@ -1057,6 +1103,40 @@ __device__ __forceinline__ PairAcc2 pair_add_mixed(PairAcc2 acc, const Fq2& c2s,
   acc.z = z3;
   return acc;
 }
+// record <-> pair accumulator, coordinate by coordinate (xyzzu_from_r / xyzzu_to_r): ra / oa = this lane's x or y, rz / oz = its zz or zzz
+__device__ __forceinline__ PairAcc1 pair_from_r(const Fq& ra, const Fq& rz) {     // (the zero record gives zero limbs)
+  return PairAcc1{u_from_std(ra), u_mul(u_from_std(rz), UPow2<FqParams, 266>::get())};
+}
+__device__ __forceinline__ PairAcc2 pair_from_r(const Fq2& ra, const Fq2& rz) {
+  const FqU c266 = UPow2<FqParams, 266>::get();
+  return PairAcc2{f2u_from_std(ra), Fq2U{u_mul(u_from_std(rz.c0), c266), u_mul(u_from_std(rz.c1), c266)}};
+}
+__device__ __forceinline__ void pair_to_r(const PairAcc1& acc, Fq& oa, Fq& oz) {
+  oa = Fq::zero();
+  oz = Fq::zero();
+  if (!acc.is_zero()) {
+    oa = u_to_std_lt32p(acc.a);                              // X < 6p / Y < 2p
+    oz = u_to_std_lt2p(u_mul(acc.z, UPow2<FqParams, 256>::get()));
+  }
+}
+__device__ __forceinline__ void pair_to_r(const PairAcc2& acc, Fq2& oa, Fq2& oz) {
+  oa = Fq2::zero();
+  oz = Fq2::zero();
+  if (!acc.is_zero()) {
+    const FqU c256 = UPow2<FqParams, 256>::get();
+    oa = Fq2{u_to_std_lt32p(acc.a.c0), u_to_std_lt32p(acc.a.c1)};
+    oz = Fq2{u_to_std_lt2p(u_mul(acc.z.c0, c256)), u_to_std_lt2p(u_mul(acc.z.c1, c256))};
+  }
+}
+__device__ __forceinline__ uint32_t coord_or(const Fq& c) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o |= c.l[k];
+  return o;
+}
+__device__ __forceinline__ uint32_t coord_or(const Fq2& c) { return coord_or(c.c0) | coord_or(c.c1); }
+template <class F> struct PairAccOf { using type = PairAcc1; };
+template <> struct PairAccOf<Fq2> { using type = PairAcc2; };
 #endif  // __HIPCC__
 
 }  // namespace zk

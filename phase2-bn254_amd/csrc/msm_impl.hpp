@@ -1318,9 +1318,10 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
 //     base's x, the odd lane keeps (Y, ZZZ) and gathers y; the same products as the one-lane addition, split evenly, at half the
 //     registers per lane).  Same lists, same order, same records as msm_accumulate_kernel<Fq2>: bit-identical bucket sums.
 constexpr uint32_t MSM_PAIR_MAX_BUCKETS = 3u << 17;   // (2^18 points: 17 windows x 2^14 buckets = 278 k -> pairs; 2^19: 16 x 2^15 = 524 k -> lanes)
-template <bool A4>
-__device__ __forceinline__ PairAcc2 accumulate_run_pair(PairAcc2 acc, const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ vals, uint32_t j, uint32_t e,
-                                                        bool odd, bool skip_zero, unsigned long long* __restrict__ err_base) {
+template <class F, bool A4>
+__device__ __forceinline__ typename PairAccOf<F>::type accumulate_run_pair(typename PairAccOf<F>::type acc, const Affine<F>* __restrict__ bases,
+                                                                           const uint32_t* __restrict__ vals, uint32_t j, uint32_t e, bool odd, bool skip_zero,
+                                                                           unsigned long long* __restrict__ err_base) {
   // (accumulate_run with stride 1; both lanes of the pair walk the same list and stay together)
   uint4 q = make_uint4(0, 0, 0, 0);
   uint32_t v;
@@ -1331,12 +1332,12 @@ __device__ __forceinline__ PairAcc2 accumulate_run_pair(PairAcc2 acc, const Affi
     v = vals[j];
   }
   const uint32_t co = odd ? 1u : 0u;
-  Fq2 p = load_vec(reinterpret_cast<const Fq2*>(bases + (v & ~SIGN_BIT)) + co);
+  F p = load_vec(reinterpret_cast<const F*>(bases + (v & ~SIGN_BIT)) + co);
   for (;;) {
     const uint32_t jn = j + 1;
     const bool more = jn < e;
     uint32_t vn = 0;
-    Fq2 pn = p;
+    F pn = p;
     if constexpr (A4) {
       if ((jn & 3u) == 0) {
         if (more) q = *reinterpret_cast<const uint4*>(vals + jn);
@@ -1344,15 +1345,12 @@ __device__ __forceinline__ PairAcc2 accumulate_run_pair(PairAcc2 acc, const Affi
         q.x = q.y; q.y = q.z; q.z = q.w;
       }
       vn = q.x;
-      if (more) pn = load_vec(reinterpret_cast<const Fq2*>(bases + (vn & ~SIGN_BIT)) + co);
+      if (more) pn = load_vec(reinterpret_cast<const F*>(bases + (vn & ~SIGN_BIT)) + co);
     } else if (more) {
       vn = vals[jn];
-      pn = load_vec(reinterpret_cast<const Fq2*>(bases + (vn & ~SIGN_BIT)) + co);
+      pn = load_vec(reinterpret_cast<const F*>(bases + (vn & ~SIGN_BIT)) + co);
     }
-    uint32_t nz = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) nz |= p.c0.l[k] | p.c1.l[k];
-    const uint32_t ynz = pair_dpp<PAIR_ODD>(nz);   // the all-zero record is the point at infinity: y == 0 (the odd lane's coordinate)
+    const uint32_t ynz = pair_dpp<PAIR_ODD>(coord_or(p));   // the all-zero record is the point at infinity: y == 0 (the odd lane's coordinate)
     if (ynz != 0) {
       acc = pair_add_mixed(acc, p, (v & SIGN_BIT) != 0, odd);
     } else if (!skip_zero && odd) {
@@ -1366,42 +1364,46 @@ __device__ __forceinline__ PairAcc2 accumulate_run_pair(PairAcc2 acc, const Affi
   return acc;
 }
 
-template <bool A4, bool CARRY>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_accumulate_pair_kernel(const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ vals,
-                                                                 const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                                 const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets,
-                                                                 XYZZ<Fq2>* __restrict__ buckets, int skip_zero, unsigned long long* __restrict__ err_base) {
+template <class F, bool A4, bool CARRY>
+__device__ __forceinline__ void accumulate_pair_body(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first,
+                                                     const uint32_t* __restrict__ last, const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb,
+                                                     uint32_t n_buckets, XYZZ<F>* __restrict__ buckets, int skip_zero, unsigned long long* __restrict__ err_base) {
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, i = gt >> 1;
   const bool odd = (gt & 1u) != 0;
   if (i >= n_buckets) return;                          // (whole pairs leave: every test up to the loop is on i)
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
   if (i < hb && e - j > heavy) return;
-  Fq2* rec = reinterpret_cast<Fq2*>(buckets + b);      // {x, y, zz, zzz}: this lane's coordinates are rec[odd] and rec[2 + odd]
+  F* rec = reinterpret_cast<F*>(buckets + b);          // {x, y, zz, zzz}: this lane's coordinates are rec[odd] and rec[2 + odd]
   const uint32_t co = odd ? 1u : 0u;
   if (j >= e) {
     if constexpr (!CARRY) {
-      store_vec(rec + co, Fq2::zero());
-      store_vec(rec + 2 + co, Fq2::zero());
+      store_vec(rec + co, F::zero());
+      store_vec(rec + 2 + co, F::zero());
     }
     return;
   }
-  PairAcc2 acc = PairAcc2::zero();
-  if constexpr (CARRY) {                               // xyzzu_from_r, coordinate by coordinate (the zero record gives zero limbs)
-    const Fq2 ra = load_vec(rec + co), rz = load_vec(rec + 2 + co);
-    const FqU c266 = UPow2<FqParams, 266>::get();
-    acc.a = f2u_from_std(ra);
-    acc.z = Fq2U{u_mul(u_from_std(rz.c0), c266), u_mul(u_from_std(rz.c1), c266)};
-  }
-  acc = accumulate_run_pair<A4>(acc, bases, vals, j, e, odd, skip_zero != 0, err_base);
-  Fq2 oa = Fq2::zero(), oz = Fq2::zero();
-  if (!acc.is_zero()) {                                // xyzzu_to_r, coordinate by coordinate
-    const FqU c256 = UPow2<FqParams, 256>::get();
-    oa = Fq2{u_to_std_lt32p(acc.a.c0), u_to_std_lt32p(acc.a.c1)};
-    oz = Fq2{u_to_std_lt2p(u_mul(acc.z.c0, c256)), u_to_std_lt2p(u_mul(acc.z.c1, c256))};
-  }
+  typename PairAccOf<F>::type acc = PairAccOf<F>::type::zero();
+  if constexpr (CARRY) acc = pair_from_r(load_vec(rec + co), load_vec(rec + 2 + co));
+  acc = accumulate_run_pair<F, A4>(acc, bases, vals, j, e, odd, skip_zero != 0, err_base);
+  F oa, oz;
+  pair_to_r(acc, oa, oz);
   store_vec(rec + co, oa);
   store_vec(rec + 2 + co, oz);
+}
+template <bool A4, bool CARRY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_accumulate_pair_kernel(
+    const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+    const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets, XYZZ<Fq2>* __restrict__ buckets, int skip_zero,
+    unsigned long long* __restrict__ err_base) {
+  accumulate_pair_body<Fq2, A4, CARRY>(bases, vals, first, last, order, heavy, hb, n_buckets, buckets, skip_zero, err_base);
+}
+template <bool A4, bool CARRY>
+__global__ void __launch_bounds__(256) msm_accumulate_pair_g1_kernel(
+    const Affine<Fq>* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+    const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets, XYZZ<Fq>* __restrict__ buckets, int skip_zero,
+    unsigned long long* __restrict__ err_base) {
+  accumulate_pair_body<Fq, A4, CARRY>(bases, vals, first, last, order, heavy, hb, n_buckets, buckets, skip_zero, err_base);
 }
 
 // 4c. SHORT calls: the launch above lasts as long as its LONGEST bucket -- a lane adds a point every ~8 us however idle the device is,
@@ -1863,10 +1865,12 @@ MsmGeom choose_geom(uint64_t n, int group, uint32_t wgroups = 1) {
   if (wgroups == 1 && n < (1ull << 20)) {
     uint32_t lg = 0;
     while ((1ull << lg) < n) ++lg;
-    uint32_t c = lg <= 10 ? 10u : lg <= 12 ? 11u : lg == 13 ? 12u : lg == 14 ? 13u : lg <= 17 ? 15u : 16u;
+    uint32_t c = lg <= 10 ? 10u : lg <= 12 ? 11u : lg == 13 ? 12u : lg <= 15 ? 13u : lg <= 17 ? 15u : 16u;
     // G2 (profiles/r03_small_n_window_sweep.txt, second half): an addition costs three times G1's and so does every step of the
     // reduce chain -- one bit narrower between 2^14 and 2^18 (2^14: 1.43 -> 1.33 ms, 2^16: 1.71 -> 1.61, 2^18: 2.54 -> 2.49)
-    if (group == 2) c = lg <= 10 ? 10u : lg == 11 ? 11u : lg <= 14 ? 12u : lg <= 16 ? 14u : lg <= 18 ? 15u : 16u;
+    if (group == 2) c = lg <= 10 ? 10u : lg == 11 ? 11u : lg <= 15 ? 12u : lg <= 17 ? 14u : lg == 18 ? 15u : 16u;
+    // (end of round 4, with the pair-per-bucket accumulation: profiles/r04_small_n_sweep_pair.txt -- G1 2^15: c = 15 -> 13, 0.475 -> 0.45 ms;
+    // G2 2^15: 14 -> 12, 1.08 -> 0.99 ms; G2 2^17: 15 -> 14, 1.52 -> 1.46 ms; every other entry stayed the minimum)
     return make_geom(c);
   }
   // wgroups > 1: the windows are dealt out to that many ranks, so W must divide evenly (per-rank cost ~ total / wgroups)
@@ -2337,22 +2341,30 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       ZK_HIP(hipGetLastError());
     }
     bool pair_done = false;
-    if constexpr (std::is_same<F, Fq2>::value) {
-      // G2: a pair of lanes per bucket (msm_accumulate_pair_kernel) while the bucket lanes do not fill the device several times over:
-      // there a launch lasts as long as its lanes' chains of dependent additions, and the pair's chain is half as long (2^16 points:
-      // accumulate 0.416 -> 0.312 ms, the call 1.27 -> 1.17; 2^12: 0.845 -> 0.82; 2^18: 2.09 -> 2.04).  With >= 2^19 buckets both
-      // forms run at the multiplier's rate and the pair pays its ~280 moves / selects per addition (2^20: 3.37 -> 3.48 ms, 2^22:
-      // 13.1 -> 13.7): tools/ab_g2_pair.sh, profiles/r04_ab_g2_pair.txt.  MI355ZK_G2_PAIR=0 / 1: never / always.
-      static const int pair_mode = [] { const char* s = std::getenv("MI355ZK_G2_PAIR"); return !s ? -1 : s[0] == '0' ? 0 : 1; }();
+    {
+      // A PAIR of lanes per bucket (msm_accumulate_pair_kernel / _g1_kernel) while the bucket lanes do not fill the device several times
+      // over: there a launch lasts as long as its lanes' chains of dependent additions, and the pair's chain is half as long.
+      // G2 (<= 3 * 2^17 buckets, i.e. <= 2^18 points): 2^16 points accumulate 0.416 -> 0.312 ms, the call 1.27 -> 1.17; 2^12: 0.845 -> 0.82;
+      // 2^18: 2.09 -> 2.04.  With >= 2^19 buckets both forms run at the multiplier's rate and the pair pays its ~280 moves / selects per
+      // addition (2^20: 3.37 -> 3.48 ms, 2^22: 13.1 -> 13.7): tools/ab_g2_pair.sh, profiles/r04_ab_g2_pair.txt.
+      // G1 (same gate: <= 2^17 points): the pair does 1782 multiplier instructions where the lane does 1467, but the chain is 891 deep:
+      // accumulate 2^12 0.097 -> 0.079 ms, 2^15 0.085 -> 0.053, 2^16 0.139 -> 0.095, 2^17 0.192 -> 0.171; 2^18 (lanes) 0.272 vs 0.305,
+      // 2^20 1.07 vs 1.27: tools/ab_g1_pair.sh, profiles/r04_ab_g1_pair.txt.
+      // MI355ZK_G2_PAIR / MI355ZK_G1_PAIR = 0 / 1: never / always.
+      constexpr bool g2 = std::is_same<F, Fq2>::value;
+      static const int pair_mode = [] { const char* s = std::getenv(g2 ? "MI355ZK_G2_PAIR" : "MI355ZK_G1_PAIR"); return !s ? -1 : s[0] == '0' ? 0 : 1; }();
       const bool pair = pair_mode < 0 ? n_buckets <= MSM_PAIR_MAX_BUCKETS : pair_mode != 0;
       if (pair) {
         const dim3 pgrid((uint32_t)((2ull * n_buckets + 255) / 256));
-        if (carry) {
-          if (a4) hipLaunchKernelGGL((msm_accumulate_pair_kernel<true, true>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
-          else hipLaunchKernelGGL((msm_accumulate_pair_kernel<false, true>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+        };
+        if constexpr (g2) {
+          if (carry) { if (a4) go(msm_accumulate_pair_kernel<true, true>); else go(msm_accumulate_pair_kernel<false, true>); }
+          else { if (a4) go(msm_accumulate_pair_kernel<true, false>); else go(msm_accumulate_pair_kernel<false, false>); }
         } else {
-          if (a4) hipLaunchKernelGGL((msm_accumulate_pair_kernel<true, false>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
-          else hipLaunchKernelGGL((msm_accumulate_pair_kernel<false, false>), pgrid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+          if (carry) { if (a4) go(msm_accumulate_pair_g1_kernel<true, true>); else go(msm_accumulate_pair_g1_kernel<false, true>); }
+          else { if (a4) go(msm_accumulate_pair_g1_kernel<true, false>); else go(msm_accumulate_pair_g1_kernel<false, false>); }
         }
         pair_done = true;
       }

@@ -905,12 +905,13 @@ def test_prover_like_exponents_at_2e22_take_the_big_bin_path(zk, worker):
     assert t_skew < 1.2 * t_uniform, f"prover-like exponents: {t_skew * 1e3:.2f} ms against {t_uniform * 1e3:.2f} ms uniform"
 
 
-def test_g2_pair_and_lane_kernels_agree():
-    """G2 accumulation, both kernels at every size: MI355ZK_G2_PAIR=1 (a pair of lanes per bucket -- the even lane keeps (X, ZZ), the
-    odd lane (Y, ZZZ): msm_accumulate_pair_kernel) and =0 (one lane per bucket), each in its own process (the switch is read once).
-    Every case of tests/g2_pair_mode_check.py is held against the CPU oracle inside the child where the oracle is quick (n <= 4096,
-    equal points colliding in a bucket, an identity base's error); the 2^17 / 2^19-point results and the streamed (carried-bucket)
-    call must come out byte-identical from both kernels."""
+@pytest.mark.parametrize("group", [1, 2])
+def test_pair_and_lane_kernels_agree(group):
+    """The accumulation, both kernels at every size: MI355ZK_G{1,2}_PAIR=1 (a pair of lanes per bucket -- the even lane keeps (X, ZZ),
+    the odd lane (Y, ZZZ): msm_accumulate_pair_kernel / _g1_kernel) and =0 (one lane per bucket), each in its own process (the switch is
+    read once).  Every case of tests/pair_mode_check.py is held against the CPU oracle inside the child where the oracle is quick
+    (n <= 4096, equal points colliding in a bucket, an identity base's error); the 2^17 / 2^19-point results and the streamed
+    (carried-bucket) call must come out byte-identical from both kernels."""
     import json
     import os
     import subprocess
@@ -919,8 +920,8 @@ def test_g2_pair_and_lane_kernels_agree():
     here = os.path.dirname(os.path.abspath(__file__))
     res = {}
     for mode in ("0", "1"):
-        env = dict(os.environ, MI355ZK_G2_PAIR=mode)
-        p = subprocess.run([sys.executable, os.path.join(here, "g2_pair_mode_check.py")], env=env, capture_output=True, text=True, timeout=600)
+        env = dict(os.environ, **{"MI355ZK_G%d_PAIR" % group: mode})
+        p = subprocess.run([sys.executable, os.path.join(here, "pair_mode_check.py"), str(group)], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (mode, p.stdout[-2000:], p.stderr[-4000:])
         res[mode] = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["0"].keys() == res["1"].keys()
