@@ -198,7 +198,45 @@ int mi355zk_selftest_g1_accumulate(int mode, const uint64_t* affine_pts, const u
     if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
     if (!out_xyzz) return ZK_ERR_BAD_ARGS;
     zk::G1XYZZ r;
-    if (mode == 0) {
+    if (mode == 3) {
+      // the PAIR-per-bucket addition (curveu.hpp: pair_add_mixed(PairAcc1, ..), msm_accumulate_pair_g1_kernel) replayed on the host as
+      // its two lanes E = (X, ZZ), O = (Y, ZZZ): the same rounds, subtraction constants, exchanges and rare branches, on the same
+      // host + device primitives (the device version differs by the DPP moves and the selects that pick a lane's operands)
+      using namespace zk;
+      const FqU zero = FqU::zero(), C = UPow2<FqParams, 266>::get();
+      FqU Ea = zero, Ez = zero, Oa = zero, Oz = zero;
+      for (size_t i = 0; i < n; ++i) {
+        G1Affine p;
+        std::memcpy(&p, affine_pts + 8 * i, 64);
+        const FqU x2 = u_from_std(p.x);
+        FqU y2 = u_from_std(p.y);
+        if (negate[i]) y2 = u_sub<1, 1>(zero, y2);
+        if (Ez.limbs_all_zero()) {
+          if (!Oz.limbs_all_zero()) return ZK_ERR_BAD_ARGS;   // (the lanes agree on infinity)
+          Ea = u_mul(x2, C); Oa = u_mul(y2, C); Ez = C; Oz = C;
+          continue;
+        }
+        const FqU P = u_sub<8, 1>(u_mul(x2, Ez), Ea), R = u_sub<2, 1>(u_mul(y2, Oz), Oa);   // round 1
+        const FqU PP = u_sqr(P), RR = u_sqr(R);                                              // round 2
+        const FqU Q = u_mul(Ea, PP), PPP = u_mul(P, PP);                                     // round 3
+        const FqU ZZ3 = u_mul(Ez, PP), ZZZ3 = u_mul(Oz, PPP);                                // round 4
+        const FqU X3 = u_sub<4, 3>(RR, u_add(PPP, u_dbl(Q)));
+        const FqU D = u_sub<8, 1>(Q, X3);
+        const FqU Y3 = u_mul2(R, D, u_sub<2, 1>(zero, Oa), PPP);                             // round 5
+        if (u_is_zero_lt2p(ZZ3) != u_is_zero_lt2p(ZZZ3)) return ZK_ERR_BAD_ARGS;            // (the lanes agree on P == 0)
+        if (u_is_zero_lt2p(ZZ3)) {
+          if (u_is_zero_lt8p(R)) {
+            const XYZZU<FqParams> dbl = xyzzu_double_affine(x2, y2);
+            Ea = dbl.x; Oa = dbl.y; Ez = dbl.zz; Oz = dbl.zzz;
+          } else {
+            Ea = Oa = Ez = Oz = zero;
+          }
+          continue;
+        }
+        Ea = X3; Oa = Y3; Ez = ZZ3; Oz = ZZZ3;
+      }
+      r = xyzzu_to_std(XYZZU<FqParams>{Ea, Oa, Ez, Oz});
+    } else if (mode == 0) {
       zk::G1XYZZ acc = zk::G1XYZZ::zero();
       for (size_t i = 0; i < n; ++i) {
         zk::G1Affine p;
@@ -345,7 +383,50 @@ int mi355zk_selftest_g2_accumulate(int mode, const uint64_t* affine_pts, const u
     if ((!affine_pts || !negate) && n) return ZK_ERR_BAD_ARGS;
     if (!out_xyzz) return ZK_ERR_BAD_ARGS;
     zk::G2XYZZ r;
-    if (mode == 0) {
+    if (mode == 3) {
+      // the PAIR-per-bucket addition over Fq2 (curveu.hpp: pair_add_mixed(PairAcc2, ..), msm_accumulate_pair_kernel) replayed on the host
+      // as its two lanes E = (X, ZZ), O = (Y, ZZZ) -- see the G1 hook; the rare doubling runs xyzzu2_double_affine as on the device
+      using namespace zk;
+      const FqU zero = FqU::zero(), C = UPow2<FqParams, 266>::get();
+      Fq2U Ea = Fq2U::zero(), Ez = Fq2U::zero(), Oa = Fq2U::zero(), Oz = Fq2U::zero();
+      auto sqr = [&](const Fq2U& v, const FqU& diff) { return Fq2U{u_mul(u_carry(u_add(v.c0, v.c1)), diff), u_mul(u_dbl(v.c0), v.c1)}; };
+      for (size_t i = 0; i < n; ++i) {
+        G2Affine p;
+        std::memcpy(&p, affine_pts + 16 * i, 128);
+        const Fq2U x2 = f2u_from_std(p.x);
+        Fq2U y2 = f2u_from_std(p.y);
+        if (negate[i]) y2 = Fq2U{u_sub<1, 1>(zero, y2.c0), u_sub<1, 1>(zero, y2.c1)};
+        if (Ez.limbs_all_zero()) {
+          if (!Oz.limbs_all_zero()) return ZK_ERR_BAD_ARGS;
+          Ea = Fq2U{u_mul(x2.c0, C), u_mul(x2.c1, C)};
+          Oa = Fq2U{u_mul(y2.c0, C), u_mul(y2.c1, C)};
+          Ez = Oz = Fq2U{C, zero};
+          continue;
+        }
+        const Fq2U U2 = f2u_mul<2>(x2, Ez), S2 = f2u_mul<2>(y2, Oz);                          // round 1
+        const Fq2U P{u_sub<8, 1>(U2.c0, Ea.c0), u_sub<8, 1>(U2.c1, Ea.c1)}, R{u_sub<2, 1>(S2.c0, Oa.c0), u_sub<2, 1>(S2.c1, Oa.c1)};
+        const Fq2U PP = sqr(P, u_sub<10, 1>(P.c0, P.c1)), RR = sqr(R, u_sub<4, 1>(R.c0, R.c1));   // round 2
+        const Fq2U Q = f2u_mul<4>(Ea, PP), PPP = f2u_mul<4>(P, PP);                           // round 3
+        const Fq2U ZZ3 = f2u_mul<4>(Ez, PP), ZZZ3 = f2u_mul<4>(Oz, PPP);                      // round 4
+        const Fq2U X3{u_sub<4, 3>(RR.c0, u_add(PPP.c0, u_dbl(Q.c0))), u_sub<4, 3>(RR.c1, u_add(PPP.c1, u_dbl(Q.c1)))};
+        const Fq2U D = f2u_sub<8>(Q, X3);
+        const FqU ny0 = u_sub<2, 1>(zero, Oa.c0), ny1 = u_sub<2, 1>(zero, Oa.c1), nd1 = u_sub<16, 1>(zero, D.c1);
+        const Fq2U Y3{u_mul4(R.c0, D.c0, R.c1, nd1, ny0, PPP.c0, Oa.c1, PPP.c1), u_mul4(R.c0, D.c1, R.c1, D.c0, ny0, PPP.c1, ny1, PPP.c0)};   // round 5
+        const bool ze = u_is_zero_lt2p(ZZ3.c0) && u_is_zero_lt2p(ZZ3.c1), zo = u_is_zero_lt2p(ZZZ3.c0) && u_is_zero_lt2p(ZZZ3.c1);
+        if (ze != zo) return ZK_ERR_BAD_ARGS;
+        if (ze) {
+          if (u_is_zero_lt8p(R.c0) && u_is_zero_lt8p(R.c1)) {
+            const XYZZU2 dbl = xyzzu2_double_affine(x2, y2);
+            Ea = dbl.x; Oa = dbl.y; Ez = dbl.zz; Oz = dbl.zzz;
+          } else {
+            Ea = Oa = Ez = Oz = Fq2U::zero();
+          }
+          continue;
+        }
+        Ea = X3; Oa = Y3; Ez = ZZ3; Oz = ZZZ3;
+      }
+      r = xyzzu2_to_std(XYZZU2{Ea, Oa, Ez, Oz});
+    } else if (mode == 0) {
       zk::G2XYZZ acc = zk::G2XYZZ::zero();
       for (size_t i = 0; i < n; ++i) {
         zk::G2Affine p;

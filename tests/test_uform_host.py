@@ -154,12 +154,12 @@ def _xyzz_to_affine(x):
     return (X * pow(ZZ, -1, M.Q) % M.Q, Y * pow(ZZ, -1 if False else -1, M.Q) * 0 + Y * pow(ZZZ, -1, M.Q) % M.Q)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_g1_bucket_accumulation_on_host(lib, mode):
     """sum of signed points, incl. the same point twice in a row (doubling branch), P then -P (infinity) and
-    restarting from infinity: saturated XYZZ (mode 0), U-form XYZZ (mode 1) and the U-form accumulator CARRIED through an
-    R-domain record after every third point (mode 2: xyzzu_to_r / xyzzu_from_r, the chunks of a streamed multiexp) against
-    the big-int model."""
+    restarting from infinity: saturated XYZZ (mode 0), U-form XYZZ (mode 1), the U-form accumulator CARRIED through an
+    R-domain record after every third point (mode 2: xyzzu_to_r / xyzzu_from_r, the chunks of a streamed multiexp) and the
+    PAIR-per-bucket addition replayed as its two lanes (mode 3: the rounds of pair_add_mixed) against the big-int model."""
     n = 40
     raw = inputs.bases_cpu(1, n, seed=123)
     pts = [M.g1_affine_from_raw(r) for r in raw]
@@ -186,11 +186,11 @@ def test_u_accumulation_long_chain_keeps_invariants(lib):
     raw = inputs.bases_progression_cpu(1, n, seed=321)
     neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
     outs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         out = np.zeros(16, np.uint64)
         assert lib.mi355zk_selftest_g1_accumulate(mode, raw.ctypes.data, neg.ctypes.data, n, out.ctypes.data) == 0
         outs.append(_xyzz_to_affine(out))
-    assert outs[0] == outs[1] == outs[2] and outs[0] is not None
+    assert outs[0] == outs[1] == outs[2] == outs[3] and outs[0] is not None
     acc = O.G1.from_affine(np.zeros(8, np.uint64))
     for i in range(n):
         pt = raw[i].copy()
@@ -247,8 +247,9 @@ def _xyzz2_to_affine(x):
     return (M.f2_mul(X, M.f2_inv(ZZ)), M.f2_mul(Y, M.f2_inv(ZZZ)))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_g2_bucket_accumulation_on_host(lib, mode):
+    """(mode 3: the pair-per-bucket addition over Fq2 replayed as its two lanes, the doubling through xyzzu2_double_affine)"""
     n = 24
     raw = inputs.bases_cpu(2, n, seed=223)
     pts = [M.g2_affine_from_raw(r) for r in raw]
@@ -307,11 +308,11 @@ def test_g2_u_accumulation_long_chain(lib):
     raw = inputs.bases_progression_cpu(2, n, seed=421)
     neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
     outs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         out = np.zeros(32, np.uint64)
         assert lib.mi355zk_selftest_g2_accumulate(mode, raw.ctypes.data, neg.ctypes.data, n, out.ctypes.data) == 0
         outs.append(_xyzz2_to_affine(out))
-    assert outs[0] == outs[1] == outs[2] and outs[0] is not None
+    assert outs[0] == outs[1] == outs[2] == outs[3] and outs[0] is not None
 
 
 def test_g2_scalar_mul_on_u_form_jacobian_host(lib):
