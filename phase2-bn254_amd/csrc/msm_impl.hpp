@@ -1313,6 +1313,28 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
   if constexpr (CARRY) acc = xyzzu_from_r(load_vec(buckets + b));
   store_vec(buckets + b, xyzzu_to_r(accumulate_run<F, A4>(acc, bases, vals, j, e, 1, skip_zero != 0, err_base)));
 }
+// G2 with >= 2^19 buckets: the same kernel at TWO waves per SIMD.  With the rare doubling in U-form (xyzzu2_double_affine) the Fq2 loop
+// needs 262 registers -- it took 256 + 147 with the saturated-limb doubling inlined -- and at a budget of 256 the seven that do not
+// fit (32 B of scratch per lane) cost less than the second wave brings.  (A kernel of its own, so that the G1 instantiation of the
+// template above keeps its code.)
+template <bool A4, bool CARRY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_accumulate_g2w2_kernel(
+    const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+    const uint32_t* __restrict__ order, uint32_t heavy, uint32_t hb, uint32_t n_buckets, XYZZ<Fq2>* __restrict__ buckets, int skip_zero,
+    unsigned long long* __restrict__ err_base) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_buckets) return;
+  const uint32_t b = order[i];
+  const uint32_t j = first[b], e = last[b];
+  if (i < hb && e - j > heavy) return;  // done by msm_accumulate_heavy_kernel
+  if (j >= e) {
+    if constexpr (!CARRY) store_vec(buckets + b, XYZZ<Fq2>::zero());
+    return;
+  }
+  XYZZU2 acc = XYZZU2::zero();
+  if constexpr (CARRY) acc = xyzzu_from_r(load_vec(buckets + b));
+  store_vec(buckets + b, xyzzu_to_r(accumulate_run<Fq2, A4>(acc, bases, vals, j, e, 1, skip_zero != 0, err_base)));
+}
 
 // 4b'. G2: one PAIR of lanes per bucket (curveu.hpp: PairAcc2 / pair_add_mixed -- the even lane keeps (X, ZZ) and gathers the
 //     base's x, the odd lane keeps (Y, ZZZ) and gathers y; the same products as the one-lane addition, split evenly, at half the
@@ -2366,6 +2388,18 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
           if (carry) { if (a4) go(msm_accumulate_pair_g1_kernel<true, true>); else go(msm_accumulate_pair_g1_kernel<false, true>); }
           else { if (a4) go(msm_accumulate_pair_g1_kernel<true, false>); else go(msm_accumulate_pair_g1_kernel<false, false>); }
         }
+        pair_done = true;
+      }
+    }
+    if constexpr (std::is_same<F, Fq2>::value) {
+      // the one-lane G2 kernel at two waves per SIMD (MI355ZK_G2_WAVES=1: the one-wave instantiation, for the comparison)
+      static const bool w2 = [] { const char* s = std::getenv("MI355ZK_G2_WAVES"); return !(s && s[0] == '1'); }();
+      if (!pair_done && w2) {
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);
+        };
+        if (carry) { if (a4) go(msm_accumulate_g2w2_kernel<true, true>); else go(msm_accumulate_g2w2_kernel<false, true>); }
+        else { if (a4) go(msm_accumulate_g2w2_kernel<true, false>); else go(msm_accumulate_g2w2_kernel<false, false>); }
         pair_done = true;
       }
     }
