@@ -4,6 +4,8 @@
 
 namespace zk {
 
+std::atomic<int> g_msm_inflight[16];
+
 int msm_g1_device(const void* d_bases, uint64_t n_bases, uint64_t base_offset, const void* d_scalars, uint64_t n, const uint32_t* d_density,
                   const uint32_t* d_dprefix, hipStream_t st, uint64_t out_xyz[12], long long* err_index, uint32_t wgroups, uint32_t wgroup,
                   bool scalars_mont, MsmChunks* chunks, uint64_t table_stride, uint32_t table_c) {

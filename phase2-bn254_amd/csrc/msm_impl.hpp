@@ -38,11 +38,16 @@
 #include <vector>
 
 #include <type_traits>
+#include <atomic>
 
 #include "curveu.hpp"
 #include "device_util.hpp"
 
 namespace zk {
+
+// multiexps inside msm_device per device, G1 and G2 together (defined in msm_g1.hip): a call that has the device to itself may
+// take every register of a SIMD (the two-wave G2 accumulation); one of the prover's eight concurrent calls leaves room for the others
+extern std::atomic<int> g_msm_inflight[16];
 
 namespace {  // one copy per translation unit (msm_g1.hip / msm_g2.hip): compiled in parallel
 
@@ -1993,6 +1998,11 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
   if (n_bases > 0x7fffffffull || n > 0x7fffffffull) return ZK_ERR_BAD_ARGS;
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
+  struct Inflight {
+    std::atomic<int>& c;
+    explicit Inflight(std::atomic<int>& x) : c(x) { c.fetch_add(1, std::memory_order_relaxed); }
+    ~Inflight() { c.fetch_sub(1, std::memory_order_relaxed); }
+  } inflight(g_msm_inflight[dev & 15]);
   if (wgroups == 0 || wgroup >= wgroups) return ZK_ERR_BAD_ARGS;
   const bool tmode = table_stride != 0;
   if (tmode && (wgroups != 1 || (chunks != nullptr && chunks->n_chunks != 1) || d_bases2 != nullptr || table_c < 4 || table_c > 24 || base_offset > table_stride)) return ZK_ERR_BAD_ARGS;
@@ -2392,8 +2402,12 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
       }
     }
     if constexpr (std::is_same<F, Fq2>::value) {
-      // the one-lane G2 kernel at two waves per SIMD (MI355ZK_G2_WAVES=1: the one-wave instantiation, for the comparison)
-      static const bool w2 = [] { const char* s = std::getenv("MI355ZK_G2_WAVES"); return !(s && s[0] == '1'); }();
+      // the one-lane G2 kernel at two waves per SIMD -- for a call that is ALONE on its device: beside the prover's other seven
+      // multiexps the two-wave kernel fills every register of the SIMDs it runs on and their waves cannot share them (eight threads with
+      // window tables at 2^20: 6.3 - 6.6 ms with one wave, 6.6 - 7.0 with two; alone: accumulate 3.36 -> 3.21 ms).
+      // MI355ZK_G2_WAVES = 1 / 2: always one / always two.
+      static const int w_mode = [] { const char* s = std::getenv("MI355ZK_G2_WAVES"); return !s ? 0 : s[0] == '1' ? 1 : 2; }();
+      const bool w2 = w_mode == 0 ? g_msm_inflight[dev & 15].load(std::memory_order_relaxed) <= 1 : w_mode == 2;
       if (!pair_done && w2) {
         auto go = [&](auto kern) {
           hipLaunchKernelGGL(kern, grid, block, 0, st, bases_set, vals_b, first, last, order, skip_len, skip_hb, n_buckets, buckets, dense ? 1 : 0, d_err);

@@ -113,7 +113,7 @@ hand = [("`r04_exp_cu_mask.txt`", "`tools/exp_cu_mask.py`", "CU-masked side stre
         ("`r04_ntt20_isa_ledger.txt`", "`tools/ntt_isa_ledger.py [-DZK_NTT_LDS_PLANES]`", "static instruction ledger of `ntt_pass_kernel<10, radix-4>` by class, element-major LDS tiles against the limb planes of rounds 1-3 (84 vs 125 VGPRs)"),
         ("`r04_fuzz_msm.txt`", "`CASES=40 SEED=11 tools/fuzz_msm.sh`", "1240 differential fuzz cases against the oracle (window layouts, streamed chunks, table mode, 2 / 3 / 8 logical devices, one-lane tails): 0 mismatches"),
         ("`r04_ab_g1_pair.txt`, `r04_ab_g2_pair.txt`", "`tools/ab_g1_pair.sh`, `tools/ab_g2_pair.sh`", "the accumulation by a PAIR of lanes per bucket (`MI355ZK_G{1,2}_PAIR=1`) against one lane per bucket (`=0`) and the library's gate (auto), same box, 2^10 .. 2^22"),
-        ("`r04_ab_g2_waves.txt`, `r04_ab_g2_small.txt`", "`tools/ab_g2_waves.sh`, `tools/ab_g2_small.sh`", "the one-lane G2 accumulation at two waves per SIMD against one (2^19 .. 2^24); the G2 short calls after the U-form doubling in the record additions"),
+        ("`r04_ab_g2_waves.txt`, `r04_ab_g2_waves_prover.txt`, `r04_ab_g2_small.txt`", "`tools/ab_g2_waves.sh`, `tools/ab_g2_waves_prover.sh`, `tools/ab_g2_small.sh`", "the one-lane G2 accumulation at two waves per SIMD against one: single calls 2^19 .. 2^24, and inside the prover's eight concurrent multiexps (why only a call that is alone takes two); the G2 short calls after the U-form doubling in the record additions"),
         ("`r04_small_n_sweep_pair.txt`", "`tools/sweep_small_n_pair.sh`", "every window width at 2^12 .. 2^18 with the pair kernels, G1 and G2: three table entries moved (G1 2^15, G2 2^15, G2 2^17)"),
         ("`r04_fuzz_msm_seed41.txt`", "`CASES=30 SEED=41 tools/fuzz_msm.sh`", "the differential fuzz on the final sources (every case of <= 3000 points now runs the pair kernels, plain and carried): 0 mismatches"),
         ("`r04_host_entry_timeline.txt`, `r04_multi_device_2e26.json`", "mid-round copies of the files above", "kept: DESIGN cites them")]
