@@ -116,6 +116,7 @@ hand = [("`r04_exp_cu_mask.txt`", "`tools/exp_cu_mask.py`", "CU-masked side stre
         ("`r04_ab_g2_waves.txt`, `r04_ab_g2_waves_prover.txt`, `r04_ab_g2_small.txt`", "`tools/ab_g2_waves.sh`, `tools/ab_g2_waves_prover.sh`, `tools/ab_g2_small.sh`", "the one-lane G2 accumulation at two waves per SIMD against one: single calls 2^19 .. 2^24, and inside the prover's eight concurrent multiexps (why only a call that is alone takes two); the G2 short calls after the U-form doubling in the record additions"),
         ("`r04_small_n_sweep_pair.txt`", "`tools/sweep_small_n_pair.sh`", "every window width at 2^12 .. 2^18 with the pair kernels, G1 and G2: three table entries moved (G1 2^15, G2 2^15, G2 2^17)"),
         ("`r04_fuzz_msm_seed41.txt`", "`CASES=30 SEED=41 tools/fuzz_msm.sh`", "the differential fuzz on the final sources (every case of <= 3000 points now runs the pair kernels, plain and carried): 0 mismatches"),
+        ("`r04_fuzz_msm_seed53.txt`", "`CASES=40 SEED=53 tools/fuzz_msm.sh` + seed 59 with `MI355ZK_G{1,2}_PAIR` forced", "1400 more differential cases on the final sources: 0 mismatches"),
         ("`r04_ab_split_pair.txt`", "`tools/ab_split.sh` on the final sources", "the quad-per-long-bucket launch on top of the pair kernels: still 1 - 4 % for G1 2^13 .. 2^15"),
         ("`r04_final_bench_n1_driver_style.json`", "`python bench.py` on a fresh box after the re-lock", "the line as the driver takes it: `roofline.traffic` filled from `latest_pmc.json` (same kernel sources), 1015 Mscalar-mul/s on that box"),
         ("`r04_host_entry_timeline.txt`, `r04_multi_device_2e26.json`", "mid-round copies of the files above", "kept: DESIGN cites them")]
