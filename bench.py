@@ -205,14 +205,26 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         # the same call in TABLE MODE (include/mi355zk.h: a precomputed window table of the base vector, one bucket set for all
         # windows) -- for vectors that do not change between calls, like the Parameters a prover queries; same affine point
         tb = zk.MsmTable(b)
-        zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
-        t = time.perf_counter()
+        torch.cuda.synchronize()
+        for _ in range(25 if group == 1 else 12):      # the plain leg's warm-up (round 4 gave this leg ONE call: BENCH_r04's 3.24 ms was a cold figure)
+            zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
+        calls = []
         for _ in range(iters):
+            t = time.perf_counter()
             res_t = zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
-        dt_t = (time.perf_counter() - t) / iters
+            calls.append(time.perf_counter() - t)
+        dt_t = sum(calls) / iters
+        L.mi355zk_prof_reset()
+        L.mi355zk_prof_enable(1)
+        for _ in range(5):
+            zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
+        L.mi355zk_prof_enable(0)
+        kern_t = _prof(L, ("msm_digits", "msm_sort", "msm_accumulate_heavy", "msm_accumulate", "msm_reduce"))
         Gt = O.G1 if group == 1 else O.G2
         entry["table_mode"] = {"value": round(n / dt_t / 1e6, 2), "unit": "Mscalar-mul/s", "ms": round(dt_t * 1e3, 3), "window_bits": tb.window_bits,
                                "windows": tb.n_windows, "table_MB": round(tb.table.numel() * 8 / 2**20, 1),
+                               "ms_min_median_max": [round(sorted(calls)[i] * 1e3, 3) for i in (0, iters // 2, iters - 1)],
+                               "kernel_ms": {kk: (round(v, 4) if v is not None else None) for kk, v in kern_t.items()},
                                "same_point": bool(np.array_equal(Gt.to_affine(res_t), Gt.to_affine(res)))}
         del tb
         if cpu:

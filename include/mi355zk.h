@@ -251,6 +251,21 @@ int mi355zk_selftest_g2_psi(const uint64_t affine_pt[16], uint64_t out_xyz[24]);
 int mi355zk_selftest_g2_scalar_mul_u(const uint64_t affine_pt[16], const uint64_t scalar[4], uint64_t out_xyz[24]);
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[32]);
 
+/* ---- mode / flag bits of the scalar-multiplication entry points below (batch_exp: `mode`; point_fft: `mode`; sparse_matvec: `flags`).
+ * Every one of them returns, by default, the reference's result for EVERY record the reference's decoders admit: its `mul` is a wNAF
+ * double-and-add (pairing/src/wnaf.rs:4-71, ec.rs:538-560, 983-997), i.e. the plain group law, and its bn256 decoders test the curve
+ * equation at most (ec.rs:133-150, 1136-1344) -- never membership in the order-r subgroup of the twist -- while `compute_constrained`
+ * reads its challenge unchecked (powersoftau/src/bin/compute_constrained.rs:16).  The G2 kernels therefore run PLAIN fixed windows over
+ * the whole scalar.  MI355ZK_G2_TRUSTED_SUBGROUP is the caller's PROMISE that every G2 record of the call lies in the order-r subgroup
+ * (honest ceremony data does; mi355zk_bn254_g2_subgroup_check_dev establishes it for untrusted data): the kernels then split each
+ * scalar over the twist's endomorphism psi (k P = k1 P + k2 psi(P), k1, k2 < 2^128; psi(P) = mu P holds in that subgroup only) and
+ * run 1.3-1.4 x faster (profiles/r05_g2_exact_cost.json).  A broken promise is not detected: a record with a cofactor component then
+ * yields a point that is not k P.  The bit is accepted and ignored by the G1 entry points: E(Fq) has prime order r, so G1's split over
+ * phi(x, y) = (beta x, y) is exact for every point ON the curve. */
+#define MI355ZK_EXP_SAME_SCALAR 1      /* batch_exp: ONE scalar for all points (phase2 contribute) instead of one per point */
+#define MI355ZK_FFT_INVERSE 1          /* point_fft: omega^-1 and the 1/m scaling */
+#define MI355ZK_G2_TRUSTED_SUBGROUP 2  /* all three: the promise above */
+
 /* ---- QAP evaluation: the per-variable sparse sums of MPCParameters::new
  * (phase2/src/parameters.rs:225-294: `a_g1[v] += coeffs_g1[lag].mul(coeff)` over the terms of variable v, then
  * batch_normalization) as one CSR-matrix x point-vector product:
@@ -258,19 +273,19 @@ int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const u
  * row_ptr: u32[n_rows + 1] (row_ptr[n_rows] == nnz), col: u32[nnz], coeff: nnz canonical FrRepr; all device pointers.
  * The index arrays are validated on the device (col[t] < n_bases, row_ptr monotone from 0 to nnz): 3 = bad arguments otherwise.
  * `ext` of the reference (three products added) is one call on the concatenated term lists / bases.
- * Synchronises `stream` before returning. */
+ * flags: 0 or MI355ZK_G2_TRUSTED_SUBGROUP (other bits: 3 = bad arguments).  Synchronises `stream` before returning. */
 int mi355zk_bn254_g1_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, size_t n_bases, const uint32_t *d_row_ptr,
-                                       const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
+                                       const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream, int flags);
 int mi355zk_bn254_g2_sparse_matvec_dev(void *d_out_affine, const void *d_bases_affine, size_t n_bases, const uint32_t *d_row_ptr,
-                                       const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream);
+                                       const uint32_t *d_col, const void *d_coeffs, size_t n_rows, size_t nnz, void *stream, int flags);
 
 /* The same on HOST buffers, over the device set of mi355zk_init (MPCParameters::new in one process on N GPUs): the rows are independent,
  * so device d evaluates the d-th contiguous row range -- its slice of (col, coeff), the whole base vector -- and writes its rows; no
  * exchange.  Same validation (3 = bad arguments) and output as the _dev form.  Synchronous. */
 int mi355zk_bn254_g1_sparse_matvec(uint8_t *out_affine, const uint8_t *bases_affine, size_t n_bases, const uint32_t *row_ptr, const uint32_t *col,
-                                   const uint64_t *coeffs, size_t n_rows, size_t nnz);
+                                   const uint64_t *coeffs, size_t n_rows, size_t nnz, int flags);
 int mi355zk_bn254_g2_sparse_matvec(uint8_t *out_affine, const uint8_t *bases_affine, size_t n_bases, const uint32_t *row_ptr, const uint32_t *col,
-                                   const uint64_t *coeffs, size_t n_rows, size_t nnz);
+                                   const uint64_t *coeffs, size_t n_rows, size_t nnz, int flags);
 
 /* ---- point codecs: the reference's wire encodings <-> raw affine records.
  * Replaces EncodedPoint::{into_affine, into_affine_unchecked, from_affine} for G1Uncompressed (64 B), G1Compressed
@@ -293,39 +308,36 @@ int mi355zk_bn254_g2_encode_dev(void *d_out_bytes, const void *d_in_affine, size
 /* ---- FFT over curve points: EvaluationDomain<Point<G1>>::fft / ifft (bellman/src/group.rs:22-51
  * under domain.rs:154-173), the Lagrange-basis conversion of powersoftau/src/bin/prepare_phase2.rs:68-131.  In
  * place on 2^log_n AFFINE raw records (64 B, all-zero = infinity); the output is normalised to affine, i.e. what
- * `batch_normalization` + `into_affine` leave (ec.rs:251-299, 596-629).  inverse != 0: omega^-1 and the 1/m scaling.
- * Synchronises `stream` before returning. */
-int mi355zk_bn254_g1_point_fft_dev(void *d_points_affine, uint32_t log_n, int inverse, void *stream);
-/* the same over G2 (128-byte affine records; `coeffs_g2` of prepare_phase2.rs:102-105) */
-int mi355zk_bn254_g2_point_fft_dev(void *d_points_affine, uint32_t log_n, int inverse, void *stream);
+ * `batch_normalization` + `into_affine` leave (ec.rs:251-299, 596-629).  mode: MI355ZK_FFT_INVERSE (omega^-1 and the 1/m scaling)
+ * | MI355ZK_G2_TRUSTED_SUBGROUP; other bits: 3 = bad arguments.  Synchronises `stream` before returning. */
+int mi355zk_bn254_g1_point_fft_dev(void *d_points_affine, uint32_t log_n, int mode, void *stream);
+/* the same over G2 (128-byte affine records; `coeffs_g2` of prepare_phase2.rs:102-105): exact for every vector of points of the twist
+ * (plain windows) unless the caller promises the subgroup */
+int mi355zk_bn254_g2_point_fft_dev(void *d_points_affine, uint32_t log_n, int mode, void *stream);
 
 /* ---- batch fixed-base scalar multiplication out[i] = k[i] * P, affine (all-zero = infinity).
  * Building block of the per-point `batch_exp` path (powersoftau/src/batched_accumulator.rs:1130-1181,
  * SURVEY 8f row 1); used here to synthesise tau-table-like bases on the device. */
 int mi355zk_bn254_g1_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[8], const void *d_scalars, size_t n, void *stream);
 int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affine[16], const void *d_scalars, size_t n, void *stream);
-/* ---- per-point batch exponentiation out[i] = k[i] * P[i] (same_scalar == 0; powersoftau `batch_exp`,
- * batched_accumulator.rs:1130-1181) or out[i] = k[0] * P[i] (same_scalar != 0; phase2 contribute,
- * phase2/src/parameters.rs:423-470), normalised to affine like `batch_normalization` (ec.rs:251-299);
- * the all-zero record is infinity on both sides.  Asynchronous on `stream`.
- * PRECONDITION (G2): the points lie in the order-r subgroup.  The scalar is split over the twist's endomorphism psi
- * (k P = k1 P + k2 psi(P), glv.hpp), and psi(P) = mu P holds in that subgroup only; the reference's wNAF `mul` is exact for ANY
- * point of the twist, and its decoders (like this library's) check the curve equation, not the subgroup (ec.rs:1136-1344).  For
- * an on-curve G2 point with a cofactor component the result here is NOT k P.  Honest ceremony data is always in the subgroup;
- * a caller that processes untrusted G2 points and needs the reference's answer for such inputs tests them first with
- * mi355zk_bn254_g2_subgroup_check_dev (this entry point cannot be used for the test: it evaluates r P through the same
- * split).  The same holds for the G2 point FFT and the G2 sparse matrix-vector product, which multiply by the same kernel.  G1 needs nothing: E(Fq) has prime order r, so phi(P) = lambda P for every point ON the curve -- but
- * `checked = 0` decoding can admit off-curve G1 records, for which no endomorphism identity holds either. */
-int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
-int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int same_scalar, void *stream);
+/* ---- per-point batch exponentiation out[i] = k[i] * P[i] (powersoftau `batch_exp`, batched_accumulator.rs:1130-1181) or, with
+ * MI355ZK_EXP_SAME_SCALAR in `mode`, out[i] = k[0] * P[i] (phase2 contribute, phase2/src/parameters.rs:423-470), normalised to affine
+ * like `batch_normalization` (ec.rs:251-299); the all-zero record is infinity on both sides.  mode: MI355ZK_EXP_SAME_SCALAR |
+ * MI355ZK_G2_TRUSTED_SUBGROUP (other bits: 3 = bad arguments).  Asynchronous on `stream`.
+ * G2 is the reference's `mul` for every record -- in the subgroup, on the twist outside it, or (checked = 0 decoding) on no curve at
+ * all: the plain windows are the group law of y^2 = x^3 + (y0^2 - x0^3), which no formula names.  G1 is exact for every point ON the
+ * curve; an off-curve G1 record (checked = 0 decoding only) has no order-r structure for the split to use and is NOT the reference's
+ * value -- decode G1 with checked != 0, as every reference binary but compute_constrained does. */
+int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int mode, void *stream);
+int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int mode, void *stream);
 /* The same on HOST buffers, spread over the device set of mi355zk_init: what MPCParameters::contribute (parameters.rs:423-470) and
  * powersoftau's batch_exp (batched_accumulator.rs:1130-1181) are to a single-process caller.  The points are independent, so device d takes
  * the d-th contiguous point range -- upload, kernels, download from its own host thread, no exchange -- and with one device the
  * vector is one range.  out / bases: n raw affine records (64 / 128 B, all-zero = infinity; out may not alias bases); scalars: n canonical
- * FrRepr, or ONE when same_scalar != 0.  Synchronous.  G2: the subgroup precondition above. */
-int mi355zk_bn254_g1_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int same_scalar);
-int mi355zk_bn254_g2_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int same_scalar);
-/* The test that establishes the precondition above: *bad_index = the lowest index of a G2 record that is on the twist but NOT in
+ * FrRepr, or ONE with MI355ZK_EXP_SAME_SCALAR.  Synchronous.  mode as above. */
+int mi355zk_bn254_g1_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int mode);
+int mi355zk_bn254_g2_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int mode);
+/* The test that lets a caller give the promise MI355ZK_G2_TRUSTED_SUBGROUP for data it did not produce: *bad_index = the lowest index of a G2 record that is on the twist but NOT in
  * the order-r subgroup (-1: all n records are; the all-zero record is the identity).  psi(P) == mu P, mu P by a plain
  * double-and-add (no split).  The reference has no counterpart -- its bn256 decoders do not test membership either -- so this
  * is an addition for callers that handle untrusted G2 data, not a drop-in for anything.  Synchronises `stream`. */

@@ -16,6 +16,11 @@ prepare_phase2 (prepare_phase2.rs:60-160), contribute_accumulator (compute_const
 
 Points are raw affine records (n x 8 int64 for G1, n x 16 for G2; all-zero = infinity), scalars canonical FrRepr
 (n x 4 int64).  The group (1 or 2) is taken from the record width.  Work is issued on torch's current stream.
+
+trusted_subgroup (batch_exp, eval_qap, point_fft / point_ifft and the flows over them): the caller's PROMISE that every G2 record lies
+in the order-r subgroup (MI355ZK_G2_TRUSTED_SUBGROUP; honest ceremony data does, g2_subgroup_check establishes it) -- the G2 kernels then
+split their scalars over the twist's endomorphism and run ~1.3x faster.  Default False: plain windows, the reference's wNAF result
+(pairing/src/wnaf.rs:4-71) for EVERY record its decoders admit.  Ignored for G1.
 """
 from __future__ import annotations
 
@@ -58,17 +63,21 @@ def _check(rc: int, what: str):
         raise DeviceError(f"{what} failed (rc={rc})")
 
 
-def batch_exp(bases, exps, same_scalar: bool = False):
+def _mode(first: bool, trusted_subgroup: bool) -> int:
+    return (1 if first else 0) | (_lib.G2_TRUSTED_SUBGROUP if trusted_subgroup else 0)
+
+
+def batch_exp(bases, exps, same_scalar: bool = False, trusted_subgroup: bool = False):
     """out[i] = exps[i] * bases[i]  (same_scalar: exps is one scalar applied to every point); affine, normalised."""
     import torch
 
     g = _group(bases)
     out = torch.empty_like(bases)
-    _check(_fn("batch_exp_dev", g)(_p(out), _p(bases), _p(exps), bases.shape[0], 1 if same_scalar else 0, _stream_ptr()), "batch_exp")
+    _check(_fn("batch_exp_dev", g)(_p(out), _p(bases), _p(exps), bases.shape[0], _mode(same_scalar, trusted_subgroup), _stream_ptr()), "batch_exp")
     return out
 
 
-def batch_exp_host(bases: np.ndarray, exps: np.ndarray, same_scalar: bool = False) -> np.ndarray:
+def batch_exp_host(bases: np.ndarray, exps: np.ndarray, same_scalar: bool = False, trusted_subgroup: bool = False) -> np.ndarray:
     """batch_exp on HOST arrays ((n, 8) / (n, 16) u64 records, (n, 4) or (1, 4) u64 scalars): mi355zk_bn254_g{1,2}_batch_exp, which spreads
     the points over the device set of the last Worker (contiguous point ranges, no exchange) -- phase2 `contribute` in ONE process on N GPUs."""
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
@@ -76,7 +85,7 @@ def batch_exp_host(bases: np.ndarray, exps: np.ndarray, same_scalar: bool = Fals
     g = {8: 1, 16: 2}[bases.shape[1]]
     out = np.empty_like(bases)
     fn = _lib.load().mi355zk_bn254_g1_batch_exp if g == 1 else _lib.load().mi355zk_bn254_g2_batch_exp
-    _check(fn(out.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), exps.ctypes.data_as(C.c_void_p), bases.shape[0], 1 if same_scalar else 0),
+    _check(fn(out.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), exps.ctypes.data_as(C.c_void_p), bases.shape[0], _mode(same_scalar, trusted_subgroup)),
            "batch_exp (host buffers)")
     return out
 
@@ -131,7 +140,7 @@ def power_pairs(v, rho):
     return merge_pairs(v[:-1], v[1:], rho)
 
 
-def eval_qap(bases, row_ptr, col, coeff):
+def eval_qap(bases, row_ptr, col, coeff, trusted_subgroup: bool = False):
     """out[v] = sum over the terms t of variable v of coeff[t] * bases[col[t]] (CSR: row_ptr int32 (n_rows + 1), col int32), affine."""
     import torch
 
@@ -143,14 +152,15 @@ def eval_qap(bases, row_ptr, col, coeff):
     if not (bases.is_contiguous() and coeff.is_contiguous()) or coeff.shape[0] != col.shape[0]:
         raise ValueError("bases / coeff must be contiguous, one coefficient per term")
     out = torch.zeros((n_rows, 8 * g), dtype=bases.dtype, device=bases.device)
-    rc = _fn("sparse_matvec_dev", g)(_p(out), _p(bases), bases.shape[0], _p(row_ptr), _p(col), _p(coeff), n_rows, col.shape[0], _stream_ptr())
+    rc = _fn("sparse_matvec_dev", g)(_p(out), _p(bases), bases.shape[0], _p(row_ptr), _p(col), _p(coeff), n_rows, col.shape[0], _stream_ptr(),
+                                     _mode(False, trusted_subgroup))
     if rc == _lib.ERR_BAD_ARGS:
         raise ValueError("eval_qap: a column index is out of range or row_ptr is not a CSR offset array")
     _check(rc, "eval_qap")
     return out
 
 
-def eval_qap_host(bases: np.ndarray, row_ptr: np.ndarray, col: np.ndarray, coeff: np.ndarray) -> np.ndarray:
+def eval_qap_host(bases: np.ndarray, row_ptr: np.ndarray, col: np.ndarray, coeff: np.ndarray, trusted_subgroup: bool = False) -> np.ndarray:
     """eval_qap on HOST arrays (bases (n, 8|16) u64, row_ptr / col uint32, coeff (nnz, 4) u64): mi355zk_bn254_g{1,2}_sparse_matvec, which gives
     every device of the last Worker's set a contiguous range of rows (MPCParameters::new in ONE process on N GPUs)."""
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
@@ -162,30 +172,30 @@ def eval_qap_host(bases: np.ndarray, row_ptr: np.ndarray, col: np.ndarray, coeff
     out = np.zeros((n_rows, 8 * g), dtype=np.uint64)
     fn = _lib.load().mi355zk_bn254_g1_sparse_matvec if g == 1 else _lib.load().mi355zk_bn254_g2_sparse_matvec
     rc = fn(out.ctypes.data_as(C.c_void_p), bases.ctypes.data_as(C.c_void_p), bases.shape[0], row_ptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
-            coeff.ctypes.data_as(C.c_void_p), n_rows, col.shape[0])
+            coeff.ctypes.data_as(C.c_void_p), n_rows, col.shape[0], _mode(False, trusted_subgroup))
     if rc == _lib.ERR_BAD_ARGS:
         raise ValueError("eval_qap: a column index is out of range or row_ptr is not a CSR offset array")
     _check(rc, "eval_qap (host buffers)")
     return out
 
 
-def _point_fft(points, inverse: int):
+def _point_fft(points, inverse: int, trusted_subgroup: bool = False):
     g = _group(points)
     n = points.shape[0]
     if n == 0 or n & (n - 1):
         raise ValueError("the number of points must be a power of two")
-    _check(_fn("point_fft_dev", g)(_p(points), n.bit_length() - 1, inverse, _stream_ptr()), "point fft")
+    _check(_fn("point_fft_dev", g)(_p(points), n.bit_length() - 1, _mode(bool(inverse), trusted_subgroup), _stream_ptr()), "point fft")
     return points
 
 
-def point_fft(points):
+def point_fft(points, trusted_subgroup: bool = False):
     """in place; returns its argument"""
-    return _point_fft(points, 0)
+    return _point_fft(points, 0, trusted_subgroup)
 
 
-def point_ifft(points):
+def point_ifft(points, trusted_subgroup: bool = False):
     """in place, including the 1/m scaling and the normalisation to affine (prepare_phase2.rs:102-131)"""
-    return _point_fft(points, 1)
+    return _point_fft(points, 1, trusted_subgroup)
 
 
 _ENC_SIZE = {(1, False): 64, (1, True): 32, (2, False): 128, (2, True): 64}
@@ -315,7 +325,7 @@ def write_phase1radix2m(params):
     return torch.cat([encode_points(params[name], False).reshape(-1) for name, _, _ in _RADIX_FIELDS])
 
 
-def prepare_phase2(acc, m: int):
+def prepare_phase2(acc, m: int, trusted_subgroup: bool = False):
     """The device work of powersoftau/src/bin/prepare_phase2.rs:60-160 for one degree m = 2^k: Lagrange-basis conversion of the
     tau powers (four point iffts) and the H bases  h[i] = tau_g1[i + m] - tau_g1[i]  (:137-147), all normalised to affine; returns
     the dict write_phase1radix2m serialises.  `acc` is what read_accumulator returns."""
@@ -326,7 +336,7 @@ def prepare_phase2(acc, m: int):
     dev = acc["tau_g1"].device
     out = {"alpha_g1": acc["alpha_g1"][:1].clone(), "beta_g1": acc["beta_g1"][:1].clone(), "beta_g2": acc["beta_g2"][:1].clone()}
     for name, src in (("coeffs_g1", "tau_g1"), ("coeffs_g2", "tau_g2"), ("alpha_coeffs_g1", "alpha_g1"), ("beta_coeffs_g1", "beta_g1")):
-        out[name] = point_ifft(acc[src][:m].clone())
+        out[name] = point_ifft(acc[src][:m].clone(), trusted_subgroup)
     # h[i] = 1 * tau_g1[i + m] + (r - 1) * tau_g1[i]: a two-term row of the sparse matrix x point vector product
     n_h = m - 1
     r_minus_1 = [0x43E1F593F0000000, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029]
@@ -413,7 +423,7 @@ def scalar_powers(base: int, n: int, device, coeff: int = 1):
     return pw
 
 
-def contribute_accumulator(acc, tau: int, alpha: int, beta: int):
+def contribute_accumulator(acc, tau: int, alpha: int, beta: int, trusted_subgroup: bool = False):
     """The device work of powersoftau `compute_constrained` (batched_accumulator.rs:1119-1292: every tau power by tau^i, the alpha /
     beta vectors by alpha tau^i / beta tau^i, beta_g2 by beta), `batch_exp` + normalisation per vector.  Returns a new dict."""
     dev = acc["tau_g1"].device
@@ -421,14 +431,14 @@ def contribute_accumulator(acc, tau: int, alpha: int, beta: int):
     tp = scalar_powers(tau, n1, dev)
     out = {"hash": acc["hash"].clone()}
     out["tau_g1"] = batch_exp(acc["tau_g1"], tp)
-    out["tau_g2"] = batch_exp(acc["tau_g2"], tp[:n].contiguous())
+    out["tau_g2"] = batch_exp(acc["tau_g2"], tp[:n].contiguous(), trusted_subgroup=trusted_subgroup)
     out["alpha_g1"] = batch_exp(acc["alpha_g1"], scalar_powers(tau, n, dev, coeff=alpha))
     out["beta_g1"] = batch_exp(acc["beta_g1"], scalar_powers(tau, n, dev, coeff=beta))
-    out["beta_g2"] = batch_exp(acc["beta_g2"], scalar_powers(tau, 1, dev, coeff=beta))
+    out["beta_g2"] = batch_exp(acc["beta_g2"], scalar_powers(tau, 1, dev, coeff=beta), trusted_subgroup=trusted_subgroup)
     return out
 
 
-def eval_qap_polynomials(radix, at, bt, ct):
+def eval_qap_polynomials(radix, at, bt, ct, trusted_subgroup: bool = False):
     """The `eval` of MPCParameters::new (phase2/src/parameters.rs:225-300) as four sparse products over the Lagrange bases of a
     phase1radix2m file (`radix`: what read_phase1radix2m returns).  at / bt / ct: CSR triples (row_ptr int32 (n_vars + 1),
     col int32 (nnz) = Lagrange index, coeff (nnz, 4) canonical) -- the QAP polynomials of keypair_assembly.rs:15-25, one row
@@ -439,7 +449,7 @@ def eval_qap_polynomials(radix, at, bt, ct):
 
     a_g1 = eval_qap(radix["coeffs_g1"], *at)
     b_g1 = eval_qap(radix["coeffs_g1"], *bt)
-    b_g2 = eval_qap(radix["coeffs_g2"], *bt)
+    b_g2 = eval_qap(radix["coeffs_g2"], *bt, trusted_subgroup=trusted_subgroup)
     # ext: one product over the concatenated bases [beta_L | alpha_L | L] and the row-wise concatenated term lists
     m = radix["coeffs_g1"].shape[0]
     bases = torch.cat([radix["beta_coeffs_g1"], radix["alpha_coeffs_g1"], radix["coeffs_g1"]])
@@ -583,6 +593,6 @@ def contribute_parameters(params, delta: int):
     out["h"] = batch_exp(params["h"], d_inv, same_scalar=True)
     vk = dict(params["vk"])
     vk["delta_g1"] = batch_exp(params["vk"]["delta_g1"], d, same_scalar=True)
-    vk["delta_g2"] = batch_exp(params["vk"]["delta_g2"], d, same_scalar=True)
+    vk["delta_g2"] = batch_exp(params["vk"]["delta_g2"], d, same_scalar=True)   # (one point: the plain windows)
     out["vk"] = vk
     return out

@@ -46,7 +46,7 @@ int point_fft_g1(void* d_points, uint32_t log_n, const Fr& omega, bool scale, co
 int codec_decode(int group, void* d_out, const void* d_in, size_t n, int compressed, int checked, hipStream_t st, long long* err_index);
 int codec_encode(int group, void* d_out, const void* d_in, size_t n, int compressed, hipStream_t st);
 // point_fft_g2.hip
-int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st);
+int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st, bool trusted_subgroup);
 int segsum_g1_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
 int segsum_g2_device(const void* d_points, uint64_t nnz, const uint32_t* d_row_ptr, uint32_t n_rows, hipStream_t st, void* d_out);
 void msm_release_g1();
@@ -186,10 +186,25 @@ void prof_reset() {
 //       scratch array, then batch_normalize_kernel: 16 points per lane share one inversion (Montgomery's trick),
 //       which is what batch_normalization does with one inversion per CPU chunk.
 //   G2: MSB-first double-and-add on the memory-format XYZZ formulas, one inversion per point.
+// y^2 == x^3 + 3 (ec.rs:133-148): the G1 kernels below split their scalar over phi(x, y) = (beta x, y), which is multiplication by lambda on
+// E(Fq) -- a group of PRIME order r, so on every point of the curve -- and on nothing else: a record that is on no curve (`checked = 0`
+// decoding, compute_constrained.rs:16) is handed to the plain-window kernel instead (`defer`), whose doublings and additions are the
+// group law of y^2 = x^3 + (y0^2 - x0^3) -- what the reference's wNAF computes for it (wnaf.rs:4-71; no formula names b).
+ZK_HD bool g1_on_curve(const Affine<Fq>& p) {
+  const Fq one = Fq::one();
+  return sqr(p.y) == add(mul(sqr(p.x), p.x), add(add(one, one), one));
+}
+__device__ __forceinline__ bool g1_defer(const Affine<Fq>& base, uint64_t i, uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count) {
+  if (g1_on_curve(base)) return false;
+  defer_list[atomicAdd(defer_count, 1u)] = (uint32_t)i;
+  return true;
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ bases, int same_base,
                                                        const uint32_t* __restrict__ scalars, int same_scalar, uint64_t n,
-                                                       const uint32_t* __restrict__ base_index, F* __restrict__ zbuf) {
+                                                       const uint32_t* __restrict__ base_index, F* __restrict__ zbuf,
+                                                       uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -200,6 +215,7 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
   if constexpr (std::is_same<F, Fq>::value) {
     JacU<FqParams> acc = JacU<FqParams>::zero();
     if (!base.is_zero()) {
+      if (g1_defer(base, i, defer_list, defer_count)) return;
       // GLV (glv.hpp): k P = k1 P + k2 phi(P), |k1|, |k2| < 2^128, phi(x, y) = (beta x, y): 129 doublings instead of 254.  Both
       // halves in non-adjacent form (one addition per three bits each): digit j = bit_{j+1}(3m) - bit_{j+1}(m).
       const GlvSplit g = glv_split(s);
@@ -244,12 +260,16 @@ __global__ void __launch_bounds__(256) batch_exp_kernel(Affine<F>* __restrict__ 
 // each lane builds its own table {1..8} * P (Jacobian + Z^2, Z^3: JacTabU, 192 B) in a scratch array laid out
 // [entry][lane], then runs 4 doublings + one table addition per window.  254 x 1071 + 60 x 2079 + table ~ 408k mads per
 // scalar against 254 x (1071 + 1593) on the NAF path when lanes diverge.
+// SPLIT = false: the plain form for the records the split kernels defer (off the curve): 65 windows over the whole scalar, a doubling that
+// lands on Z == 0 (a point of order two: such curves have them) made the literal infinity, infinite table entries skipped.
 constexpr int EXP_TAB = 8;
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restrict__ out, const Affine<Fq>* __restrict__ bases, int same_base,
-                                                           const uint32_t* __restrict__ scalars, uint64_t i0, uint64_t n_chunk,
+                                                           const uint32_t* __restrict__ scalars, int same_scalar, uint64_t i0, uint64_t n_chunk,
                                                            const uint32_t* __restrict__ base_index, Fq* __restrict__ zbuf,
                                                            JacTabU<FqParams>* __restrict__ tab, const uint32_t* __restrict__ term_list,
-                                                           const uint32_t* __restrict__ term_count) {
+                                                           const uint32_t* __restrict__ term_count, uint32_t* __restrict__ defer_list,
+                                                           uint32_t* __restrict__ defer_count) {
   // term_list != nullptr: only the listed elements are worked on (lane t of the launch <-> term_list[i0 + t], up to *term_count)
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunk) return;
@@ -260,10 +280,16 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
   }
   uint32_t s[8];
 #pragma unroll
-  for (int l = 0; l < 8; ++l) s[l] = scalars[i * 8 + l];
+  for (int l = 0; l < 8; ++l) s[l] = scalars[(same_scalar ? 0 : i * 8) + l];
   const Affine<Fq> base = bases[same_base ? 0 : (base_index ? base_index[i] : i)];
   JacU<FqParams> acc = JacU<FqParams>::zero();
   if (!base.is_zero()) {
+    if constexpr (SPLIT)
+      if (g1_defer(base, i, defer_list, defer_count)) return;
+    auto canon = [](JacU<FqParams>& q) {                    // plain form: 2 Y Z == 0 is infinity
+      if constexpr (!SPLIT)
+        if (u_is_zero_lt2p(q.z)) q = JacU<FqParams>::zero();
+    };
     const FqU C = UPow2<FqParams, 266>::get();             // x*2^256 * 2^266 / 2^261 = x * 2^261
     const FqU x2 = u_mul(u_from_std(base.x), C);            // < 2p, N
     const FqU y2 = u_mul(u_from_std(base.y), C);
@@ -272,47 +298,54 @@ __global__ void __launch_bounds__(256) batch_exp_win_kernel(Affine<Fq>* __restri
     for (int e = 2; e <= EXP_TAB; ++e) {                    // e*P = 2 * (e/2)*P  or  (e-1)*P + P
       const JacTabU<FqParams> src = tab[(uint64_t)((e & 1) ? e - 2 : e / 2 - 1) * n_chunk + t];
       JacU<FqParams> q{src.x, src.y, src.z};
-      if (e & 1) jacu_add_mixed(q, x2, y2, false);
-      else q = jacu_double(q);
+      if (e & 1) {
+        jacu_add_mixed(q, x2, y2, false);
+      } else {
+        q = jacu_double(q);
+        canon(q);
+      }
       tab[(uint64_t)(e - 1) * n_chunk + t] = jacu_tab_entry(q);
     }
-    // GLV (glv.hpp): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128 -- 33 windows of 4 doublings instead of 64; phi of a table
-    // entry is the entry with X multiplied by beta (Y, Z, Z^2, Z^3 unchanged), one more product per addition.
-    // signed digits d_j in [-8, 8] of both halves: m = sum d_j 16^j
-    const GlvSplit g = glv_split(s);
-    uint32_t mag1[5], mag2[5], sgn1[2] = {0, 0}, sgn2[2] = {0, 0};
-    auto digits = [](const uint32_t m[5], uint32_t mag[5], uint32_t sgn[2]) {
-      uint32_t carry = 0;
-#pragma unroll
-      for (int w = 0; w < 5; ++w) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          uint32_t d = ((m[w] >> (4 * q)) & 15u) + carry;
-          carry = d > 8u ? 1u : 0u;
-          if (carry) {
-            d = 16u - d;
-            sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
-          }
-          o |= d << (4 * q);
+    if constexpr (SPLIT) {
+      // GLV (glv.hpp): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128 -- 33 windows of 4 doublings instead of 64; phi of a table
+      // entry is the entry with X multiplied by beta (Y, Z, Z^2, Z^3 unchanged), one more product per addition.
+      // signed digits d_j in [-8, 8] of both halves: m = sum d_j 16^j
+      const GlvSplit g = glv_split(s);
+      uint32_t mag1[5], mag2[5], sgn1[2], sgn2[2];
+      signed_nibbles<5, 5>(g.k1, mag1, sgn1);   // (magnitudes < 2^128: the carry out of nibble 31 lands in nibble 32, nothing beyond)
+      signed_nibbles<5, 5>(g.k2, mag2, sgn2);
+      const FqU betaU = u_mul(u_from_std(glv_beta()), C);     // beta, 2^261 domain
+#pragma unroll 1
+      for (int j = 39; j >= 0; --j) {   // all 40 nibbles of the five limbs: canonical scalars use 33, and doubling infinity returns at once
+#pragma unroll 1
+        for (int rep = 0; rep < 4; ++rep) acc = jacu_double(acc);
+        const uint32_t d1 = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
+        if (d1) jacu_add_tab(acc, tab[(uint64_t)(d1 - 1) * n_chunk + t], (((sgn1[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg1);
+        const uint32_t d2 = (mag2[j >> 3] >> (4 * (j & 7))) & 15u;
+        if (d2) {
+          JacTabU<FqParams> e = tab[(uint64_t)(d2 - 1) * n_chunk + t];
+          e.x = u_mul(e.x, betaU);                            // X < 6p: < 1.08p
+          jacu_add_tab(acc, e, (((sgn2[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg2);
         }
-        mag[w] = o;
       }
-    };
-    digits(g.k1, mag1, sgn1);   // (magnitudes < 2^128: the carry out of nibble 31 lands in nibble 32, nothing beyond)
-    digits(g.k2, mag2, sgn2);
-    const FqU betaU = u_mul(u_from_std(glv_beta()), C);     // beta, 2^261 domain
+    } else {
+      uint32_t mag[9], sgn[3];
+      signed_nibbles<9, 8>(s, mag, sgn);
 #pragma unroll 1
-    for (int j = 39; j >= 0; --j) {   // all 40 nibbles of the five limbs: canonical scalars use 33, and doubling infinity returns at once
+      for (int j = 64; j >= 0; --j) {   // the 64 nibbles and the carry out of the last
 #pragma unroll 1
-      for (int rep = 0; rep < 4; ++rep) acc = jacu_double(acc);
-      const uint32_t d1 = (mag1[j >> 3] >> (4 * (j & 7))) & 15u;
-      if (d1) jacu_add_tab(acc, tab[(uint64_t)(d1 - 1) * n_chunk + t], (((sgn1[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg1);
-      const uint32_t d2 = (mag2[j >> 3] >> (4 * (j & 7))) & 15u;
-      if (d2) {
-        JacTabU<FqParams> e = tab[(uint64_t)(d2 - 1) * n_chunk + t];
-        e.x = u_mul(e.x, betaU);                            // X < 6p: < 1.08p
-        jacu_add_tab(acc, e, (((sgn2[j >> 5] >> (j & 31)) & 1u) != 0) != g.neg2);
+        for (int rep = 0; rep < 4; ++rep) {
+          acc = jacu_double(acc);
+          canon(acc);
+        }
+        const uint32_t d = (mag[j >> 3] >> (4 * (j & 7))) & 15u;
+        if (d) {
+          const JacTabU<FqParams> e = tab[(uint64_t)(d - 1) * n_chunk + t];
+          if (!e.z.limbs_all_zero()) {
+            jacu_add_tab(acc, e, ((sgn[j >> 5] >> (j & 31)) & 1u) != 0);
+            canon(acc);                                       // (the addition doubles when acc == e)
+          }
+        }
       }
     }
   }
@@ -350,7 +383,8 @@ __global__ void batch_exp_same_digits_kernel(const uint32_t* __restrict__ scalar
 __global__ void __launch_bounds__(256) batch_exp_same_kernel(Affine<Fq>* __restrict__ out, const Affine<Fq>* __restrict__ bases, int same_base,
                                                             uint64_t i0, uint64_t n_chunk, const uint32_t* __restrict__ base_index,
                                                             Fq* __restrict__ zbuf, JacTabU<FqParams>* __restrict__ tab,
-                                                            const SameDigits* __restrict__ dig) {
+                                                            const SameDigits* __restrict__ dig, uint32_t* __restrict__ defer_list,
+                                                            uint32_t* __restrict__ defer_count) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunk) return;
   const uint64_t i = i0 + t;
@@ -358,6 +392,7 @@ __global__ void __launch_bounds__(256) batch_exp_same_kernel(Affine<Fq>* __restr
   JacU<FqParams> acc = JacU<FqParams>::zero();
   const int top = dig->top;
   if (!base.is_zero() && top >= 0) {
+    if (g1_defer(base, i, defer_list, defer_count)) return;
     const FqU C = UPow2<FqParams, 266>::get();             // x*2^256 * 2^266 / 2^261 = x * 2^261
     const FqU x2 = u_mul(u_from_std(base.x), C);            // < 2p, N
     const FqU y2 = u_mul(u_from_std(base.y), C);
@@ -414,6 +449,14 @@ __device__ __forceinline__ void tabu2_store(JacTabU2* p, const JacTabU2& v) {
   for (int i = 0; i < (int)(sizeof(JacTabU2) / 16); ++i) d[i] = s[i];
 }
 
+// SPLIT = true: the scalar goes over the twist's endomorphism psi (glv.hpp: k P = k1 P + k2 psi(P), k1, k2 < 2^128 -- 33 windows of four
+// doublings instead of 64).  psi(P) = mu P holds in the order-r subgroup ONLY, so this form runs only under the caller's promise
+// MI355ZK_G2_TRUSTED_SUBGROUP.  SPLIT = false (the default): 65 plain windows over the whole 256-bit scalar -- the group law and nothing
+// else, hence the reference's wNAF answer (pairing/src/wnaf.rs:4-71) for EVERY record its decoders admit (ec.rs:1136-1344 test the curve
+// equation at most): points of the twist outside the subgroup, and -- none of the formulas uses the curve's b -- records that are on no
+// curve at all (`checked = 0` decoding), whose multiples live on y^2 = x^3 + (y0^2 - x0^3) where small orders exist: a doubling that
+// lands on Z == 0 (a point of order two) is made the literal infinity, and an infinite table entry is skipped.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __restrict__ out, const Affine<Fq2>* __restrict__ bases, int same_base,
                                                               const uint32_t* __restrict__ scalars, int same_scalar, uint64_t i0,
                                                               uint64_t n_chunk, const uint32_t* __restrict__ base_index,
@@ -434,39 +477,27 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
   JacU2 acc = JacU2::zero();
   if (!base.is_zero()) {
     tabu2_store(tab + t, jacu2_tab_from_affine(base.x, base.y));
-    // The scalar is split by the twist's endomorphism psi (glv.hpp): k P = k1 P + k2 psi(P), k1, k2 < 2^128 -- 33 windows of four
-    // doublings instead of 64; psi of a table entry costs two Fq2 products by constants and five negations.
-    const Glv2Split g = glv2_split(s);
-    uint32_t mag1[5], mag2[5], sgn1[2] = {0, 0}, sgn2[2] = {0, 0};  // signed digits d_j in [-8, 8]: m = sum d_j 16^j
-    auto digits = [](const uint32_t m[5], uint32_t mag[5], uint32_t sgn[2]) {
-      uint32_t carry = 0;
-#pragma unroll
-      for (int w = 0; w < 5; ++w) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          uint32_t d = ((m[w] >> (4 * q)) & 15u) + carry;
-          carry = d > 8u ? 1u : 0u;
-          if (carry) {
-            d = 16u - d;
-            sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
-          }
-          o |= d << (4 * q);
-        }
-        mag[w] = o;
-      }
-    };
-    digits(g.k1, mag1, sgn1);
-    digits(g.k2, mag2, sgn2);
-    const FqU C266 = UPow2<FqParams, 266>::get();
-    const Fq2 cxs = glv2_cx(), cys = glv2_cy();
-    const Fq2U cxU{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};   // 2^261 domain, < 2p
-    const Fq2U cyU{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
+    // signed digits d_j in [-8, 8]: m = sum d_j 16^j.  SPLIT: of both halves (five words each); plain: of the scalar (eight words and the carry)
+    constexpr int NW = SPLIT ? 5 : 9;
+    uint32_t mag1[NW], mag2[SPLIT ? 5 : 1], sgn1[(NW + 3) / 4], sgn2[2];
+    Fq2U cxU, cyU;
+    if constexpr (SPLIT) {
+      const Glv2Split g = glv2_split(s);
+      signed_nibbles<5, 5>(g.k1, mag1, sgn1);
+      signed_nibbles<5, 5>(g.k2, mag2, sgn2);
+      const FqU C266 = UPow2<FqParams, 266>::get();
+      const Fq2 cxs = glv2_cx(), cys = glv2_cy();
+      cxU = Fq2U{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};   // 2^261 domain, < 2p
+      cyU = Fq2U{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
+    } else {
+      signed_nibbles<9, 8>(s, mag1, sgn1);
+    }
     // table program, one nibble per field (load, double, add, store):  2P = 2*1P, 3P = 2P + 1P, 4P = 2*2P, 5P = 4P + 1P, ...
     constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};
-    constexpr int WINDOWS = 40;   // all nibbles of the five limbs (canonical scalars use 33; doubling infinity returns at once)
+    // SPLIT: all nibbles of the five limbs (canonical scalars use 33); plain: the 64 nibbles and the carry out of the last (doubling infinity returns at once)
+    constexpr int WINDOWS = SPLIT ? 40 : 65, PER = SPLIT ? 5 : 4;
 #pragma unroll 1
-    for (int step = 0; step < 7 + 5 * WINDOWS; ++step) {
+    for (int step = 0; step < 7 + PER * WINDOWS; ++step) {
       uint32_t load = 0, dbl_it = 0, add = 0, store = 0, negate = 0, psi = 0;
       if (step < 7) {
         const uint32_t pr = PROG[step];
@@ -475,9 +506,9 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
         add = (pr >> 4) & 15u;
         store = pr & 15u;
       } else {
-        const int m = step - 7;        // per window: four doublings (the fourth adds the k1 digit), then the k2 digit through psi
+        const int m = step - 7;        // per window: four doublings (the fourth adds the k1 digit), then (SPLIT) the k2 digit through psi
         if (m == 0) acc = JacU2::zero();
-        const int win = m / 5, sub = m - 5 * win, j = WINDOWS - 1 - win;
+        const int win = m / PER, sub = m - PER * win, j = WINDOWS - 1 - win;
         if (sub < 4) {
           dbl_it = 1;
           if (sub == 3) {
@@ -494,11 +525,22 @@ __global__ void __launch_bounds__(256) batch_exp_win_u2_kernel(Affine<Fq2>* __re
         const JacTabU2 e = tabu2_load(tab + (uint64_t)(load - 1) * n_chunk + t);
         acc = JacU2{e.x, e.y, e.z};
       }
-      if (dbl_it) acc = jacu2_double(acc);
+      if (dbl_it) {
+        acc = jacu2_double(acc);
+        if constexpr (!SPLIT)
+          if (u_is_zero_lt2p(acc.z.c0) && u_is_zero_lt2p(acc.z.c1)) acc = JacU2::zero();   // 2 Y Z == 0: Y == 0, a point of order two
+      }
       if (add) {
         JacTabU2 e = tabu2_load(tab + (uint64_t)(add - 1) * n_chunk + t);
-        if (psi) e = jacu2_tab_psi(e, cxU, cyU);
-        jacu2_add_tab(acc, e, negate != 0);
+        if constexpr (SPLIT) {
+          if (psi) e = jacu2_tab_psi(e, cxU, cyU);
+          jacu2_add_tab(acc, e, negate != 0);
+        } else {
+          if (!e.z.limbs_all_zero()) {                        // (d P == infinity for a small d: only off the twist)
+            jacu2_add_tab(acc, e, negate != 0);
+            if (u_is_zero_lt2p(acc.z.c0) && u_is_zero_lt2p(acc.z.c1)) acc = JacU2::zero();   // (the addition doubles when acc == e)
+          }
+        }
       }
       if (store) tabu2_store(tab + (uint64_t)(store - 1) * n_chunk + t, jacu2_tab_entry(acc));
     }
@@ -613,13 +655,13 @@ void exp_scratch_release_all() {
   g_exp_scratch.clear();
 }
 
-// QAP coefficients are mostly +-1 (circom R1CS): a term with coefficient 1 / r - 1 / 0 is the base itself / its negative /
-// nothing, no scalar multiplication.  Those terms are written directly (Z = one resp. 0 for the normalisation pass that follows);
+// QAP coefficients are mostly +-1 (circom R1CS): a term with coefficient 1 / r - 1 / 0 is the base itself / its negative (where the
+// base is known to have order r: see allow_minus_one) / nothing, no scalar multiplication.  Those terms are written directly (Z = one resp. 0 for the normalisation pass that follows);
 // the indices of the others are appended to `list` and only they run the windowed multiplication, as full waves.
 template <class F>
 __global__ void __launch_bounds__(256) exp_classify_kernel(Affine<F>* __restrict__ out, F* __restrict__ zbuf, const Affine<F>* __restrict__ bases,
                                                           const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ base_index, uint64_t n,
-                                                          uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+                                                          uint32_t* __restrict__ list, uint32_t* __restrict__ count, int allow_minus_one) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -634,11 +676,18 @@ __global__ void __launch_bounds__(256) exp_classify_kernel(Affine<F>* __restrict
   }
   is_rm1 = is_rm1 && s[0] == FrParams::P[0] - 1u;
   const bool is_zero = hi_zero && s[0] == 0, is_one = hi_zero && s[0] == 1;
+  // (r - 1) P == -P needs r P == infinity: true in the order-r group only -- G2 under the caller's promise, G1 for a record ON the curve
+  if (!allow_minus_one) is_rm1 = false;
   if (!(is_zero || is_one || is_rm1)) {
     list[atomicAdd(count, 1u)] = (uint32_t)i;
     return;
   }
   Affine<F> p = bases[base_index ? base_index[i] : i];
+  if constexpr (std::is_same<F, Fq>::value)
+    if (is_rm1 && !p.is_zero() && !g1_on_curve(p)) {
+      list[atomicAdd(count, 1u)] = (uint32_t)i;
+      return;
+    }
   if (is_zero || p.is_zero()) {
     p = Affine<F>{F::zero(), F::zero()};
     zbuf[i] = F::zero();
@@ -656,7 +705,8 @@ static std::mutex g_exp_launch_mu;
 
 template <class F>
 int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_scalars, int same_scalar, size_t n, void* stream,
-              const uint32_t* d_base_index = nullptr, bool shortcut_unit_scalars = false) {
+              const uint32_t* d_base_index = nullptr, bool shortcut_unit_scalars = false, bool g2_trusted = false) {
+  // g2_trusted (G2 only): the caller's promise that every base lies in the order-r subgroup -- the psi-split kernel; otherwise the plain one
   if (!d_out || !d_bases || !d_scalars) return n ? ZK_ERR_BAD_ARGS : ZK_OK;
   if (n == 0) return ZK_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -667,40 +717,49 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
     const size_t z_bytes = (n * sizeof(Fq) + 255) & ~(size_t)255;
     const bool shortcut = shortcut_unit_scalars && windowed && !same_base;
     const size_t list_bytes = shortcut ? ((n + 1) * 4 + 255) & ~(size_t)255 : 0;
+    const size_t defer_bytes = ((n + 1) * 4 + 255) & ~(size_t)255;   // [0] = count, then the records that are on no curve (g1_defer)
     void* p = nullptr;
     static const bool same_naf = std::getenv("MI355ZK_EXP_SAME_NAF") != nullptr;   // (the plain-NAF kernel of rounds 2-3, for the comparison)
     const bool same_win = !windowed && !same_naf;          // one scalar for all points: the sliding-window kernel
-    const size_t tab_bytes = (windowed || same_win) ? (size_t)EXP_TAB * chunk * sizeof(JacTabU<FqParams>) : 0;
-    int rc = exp_scratch(z_bytes + list_bytes + tab_bytes + (same_win ? 512 : 0), stream, &p);
+    const size_t tab_bytes = (size_t)EXP_TAB * chunk * sizeof(JacTabU<FqParams>);
+    int rc = exp_scratch(z_bytes + list_bytes + defer_bytes + tab_bytes + (same_win ? 512 : 0), stream, &p);
     if (rc) return rc;
     Fq* zbuf = (Fq*)p;
     uint32_t* list = shortcut ? (uint32_t*)((char*)p + z_bytes) : nullptr;   // [0] = count, then the general terms
+    uint32_t* defer = (uint32_t*)((char*)p + z_bytes + list_bytes);
+    JacTabU<FqParams>* tab = (JacTabU<FqParams>*)((char*)p + z_bytes + list_bytes + defer_bytes);
+    ZK_HIP(hipMemsetAsync(defer, 0, 4, st));
     if (shortcut) {
       ZK_HIP(hipMemsetAsync(list, 0, 4, st));
       hipLaunchKernelGGL(exp_classify_kernel<Fq>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, zbuf, (const Affine<Fq>*)d_bases,
-                         (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list);
+                         (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list, /*allow_minus_one=*/1);
     }
     if (windowed) {
-      JacTabU<FqParams>* tab = (JacTabU<FqParams>*)((char*)p + z_bytes + list_bytes);
       for (size_t i0 = 0; i0 < n; i0 += chunk) {
         const size_t m = n - i0 < chunk ? n - i0 : chunk;
-        hipLaunchKernelGGL(batch_exp_win_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
-                           same_base, (const uint32_t*)d_scalars, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab,
-                           shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(batch_exp_win_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
+                           same_base, (const uint32_t*)d_scalars, 0, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab,
+                           shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr, defer + 1, defer);
       }
     } else if (same_win) {
-      JacTabU<FqParams>* tab = (JacTabU<FqParams>*)((char*)p + z_bytes + list_bytes);
-      SameDigits* dig = (SameDigits*)((char*)p + z_bytes + list_bytes + tab_bytes);
+      SameDigits* dig = (SameDigits*)((char*)p + z_bytes + list_bytes + defer_bytes + tab_bytes);
       static_assert(sizeof(SameDigits) <= 512, "digit buffer");
       hipLaunchKernelGGL(batch_exp_same_digits_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)d_scalars, dig);
       for (size_t i0 = 0; i0 < n; i0 += chunk) {
         const size_t m = n - i0 < chunk ? n - i0 : chunk;
         hipLaunchKernelGGL(batch_exp_same_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
-                           same_base, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab, (const SameDigits*)dig);
+                           same_base, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab, (const SameDigits*)dig, defer + 1, defer);
       }
     } else {
       hipLaunchKernelGGL(batch_exp_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, (const Affine<F>*)d_bases,
-                         same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n, d_base_index, zbuf);
+                         same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)n, d_base_index, zbuf, defer + 1, defer);
+    }
+    // the deferred records (none on honest data: every lane of these launches reads the count and leaves) through the plain windows
+    for (size_t i0 = 0; i0 < n; i0 += chunk) {
+      const size_t m = n - i0 < chunk ? n - i0 : chunk;
+      hipLaunchKernelGGL(batch_exp_win_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq>*)d_out, (const Affine<Fq>*)d_bases,
+                         same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index, zbuf, tab,
+                         (const uint32_t*)(defer + 1), (const uint32_t*)defer, (uint32_t*)nullptr, (uint32_t*)nullptr);
     }
     ZK_HIP(hipGetLastError());
     constexpr int K = 16;
@@ -721,14 +780,19 @@ int batch_exp(void* d_out, const void* d_bases, int same_base, const void* d_sca
     if (shortcut) {
       ZK_HIP(hipMemsetAsync(list, 0, 4, st));
       hipLaunchKernelGGL(exp_classify_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Affine<F>*)d_out, zbuf, (const Affine<F>*)d_bases,
-                         (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list);
+                         (const uint32_t*)d_scalars, d_base_index, (uint64_t)n, list + 1, list, /*allow_minus_one=*/g2_trusted ? 1 : 0);
     }
     JacTabU2* tab = (JacTabU2*)((char*)p + z_bytes + list_bytes);
     for (size_t i0 = 0; i0 < n; i0 += chunk) {
       const size_t m = n - i0 < chunk ? n - i0 : chunk;
-      hipLaunchKernelGGL(batch_exp_win_u2_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq2>*)d_out,
-                         (const Affine<Fq2>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
-                         (Fq2*)zbuf, tab, shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
+      if (g2_trusted)
+        hipLaunchKernelGGL(batch_exp_win_u2_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq2>*)d_out,
+                           (const Affine<Fq2>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
+                           (Fq2*)zbuf, tab, shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
+      else
+        hipLaunchKernelGGL(batch_exp_win_u2_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (Affine<Fq2>*)d_out,
+                           (const Affine<Fq2>*)d_bases, same_base, (const uint32_t*)d_scalars, same_scalar, (uint64_t)i0, (uint64_t)m, d_base_index,
+                           (Fq2*)zbuf, tab, shortcut ? list + 1 : (const uint32_t*)nullptr, shortcut ? list : (const uint32_t*)nullptr);
     }
     ZK_HIP(hipGetLastError());
     constexpr int K = 8;
@@ -832,7 +896,15 @@ int batch_mul(void* d_out, const uint64_t* base_raw, const void* d_scalars, size
   int rc = mul_slot(stream, &d_base);
   if (rc) return rc;
   ZK_HIP(hipMemcpyAsync(d_base, base_raw, sizeof(Affine<F>), hipMemcpyHostToDevice, (hipStream_t)stream));
-  rc = batch_exp<F>(d_out, d_base, 1, d_scalars, 0, n, stream);
+  // G2: ONE base, so its membership in the order-r subgroup is decided here, on the host (psi(P) == mu P, ~200 group operations),
+  // and the psi-split kernel runs only for a member; any other record of the twist goes through the plain windows.
+  bool member = false;
+  if constexpr (std::is_same<F, Fq2>::value) {
+    Affine<Fq2> b;
+    std::memcpy(&b, base_raw, sizeof b);
+    member = g2_in_subgroup(b);
+  }
+  rc = batch_exp<F>(d_out, d_base, 1, d_scalars, 0, n, stream, nullptr, false, member);
   if (rc != ZK_OK) return rc;
   ZK_HIP(hipStreamSynchronize((hipStream_t)stream));  // base_raw is the caller's (pageable) memory; the result is ready on return
   return ZK_OK;
@@ -1820,9 +1892,9 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
 // independent, so they shard by CONTIGUOUS POINT RANGE with no exchange at all (shard.batch_exp_sharded is the
 // one-process-per-GPU form): device d of mi355zk_init's set takes range d -- upload, the batch_exp kernels, download -- from its own
 // host thread; with one device the whole vector is one range.  Ranges are worked off in pieces of 2^22 points (a piece's buffers
-// come from the grow-only pool, so a 2^26-point vector does not allocate 10 GiB).  G2: the subgroup precondition of batch_exp_dev.
+// come from the grow-only pool, so a 2^26-point vector does not allocate 10 GiB).  g2_trusted: the promise flag of batch_exp_dev.
 template <class F>
-int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, size_t n, int same_scalar) {
+int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, size_t n, int same_scalar, bool g2_trusted) {
   if ((n && (!out || !bases)) || !scalars) return ZK_ERR_BAD_ARGS;
   if (n == 0) return ZK_OK;
   if (n >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
@@ -1879,7 +1951,7 @@ int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, 
       if ((e = hipMemcpyAsync(d_in[k], bases + p0 * rec, m * rec, hipMemcpyHostToDevice, S->copy)) != hipSuccess) return false;
       if (!same_scalar && (e = hipMemcpyAsync(d_sc[k], scalars + p0 * 4, m * 32, hipMemcpyHostToDevice, S->copy)) != hipSuccess) return false;
       if ((e = hipEventRecord(up[k], S->copy)) != hipSuccess || (e = hipStreamWaitEvent(S->compute, up[k], 0)) != hipSuccess) return false;
-      rc = batch_exp<F>(d_out[k], d_in[k], 0, same_scalar ? d_sc[0] : d_sc[k], same_scalar, m, (void*)S->compute);
+      rc = batch_exp<F>(d_out[k], d_in[k], 0, same_scalar ? d_sc[0] : d_sc[k], same_scalar, m, (void*)S->compute, nullptr, false, g2_trusted);
       if (rc) return false;
       return (e = hipEventRecord(done[k], S->compute)) == hipSuccess;
     };
@@ -2065,7 +2137,7 @@ __global__ void __launch_bounds__(256) csr_check_kernel(const uint32_t* __restri
 
 template <class F>
 static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeffs,
-                         size_t n_rows, size_t nnz, void* stream, int group) {
+                         size_t n_rows, size_t nnz, void* stream, int group, bool g2_trusted) {
   if (!d_out || !d_row_ptr || (nnz && (!d_bases || !d_col || !d_coeffs)) || n_rows >= (1ull << 31) || nnz >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   if (n_rows == 0) return ZK_OK;
   Affine<F>* d_terms = nullptr;
@@ -2088,7 +2160,7 @@ static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const
       return ZK_ERR_BAD_ARGS;
     }
   }
-  int rc = batch_exp<F>(d_terms, d_bases, 0, d_coeffs, 0, nnz, stream, d_col, /*shortcut_unit_scalars=*/true);
+  int rc = batch_exp<F>(d_terms, d_bases, 0, d_coeffs, 0, nnz, stream, d_col, /*shortcut_unit_scalars=*/true, g2_trusted);
   if (rc == ZK_OK)
     rc = group == 1 ? segsum_g1_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out)
                     : segsum_g2_device(d_terms, nnz, d_row_ptr, (uint32_t)n_rows, (hipStream_t)stream, d_out);
@@ -2103,7 +2175,7 @@ static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const
 // and monotonicity across the cuts are checked here.
 template <class F>
 static int sparse_matvec_host(uint8_t* out, const uint8_t* bases, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col, const uint64_t* coeffs,
-                              size_t n_rows, size_t nnz, int group) {
+                              size_t n_rows, size_t nnz, int group, bool g2_trusted) {
   constexpr size_t rec = sizeof(Affine<F>);
   if (!row_ptr || (n_rows && !out) || (nnz && (!bases || !col || !coeffs)) || n_rows >= (1ull << 31) || nnz >= (1ull << 31) || n_bases >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   if (n_rows == 0) return ZK_OK;
@@ -2157,7 +2229,7 @@ static int sparse_matvec_host(uint8_t* out, const uint8_t* bases, size_t n_bases
     if (e == hipSuccess) e = hipStreamSynchronize(S->compute);   // (rp is a local vector)
     if (e != hipSuccess) { rcs[d] = ZK_ERR_DEVICE; return; }
     int rc = sparse_matvec<F>(base + o_out, base + o_bases, n_bases, (const uint32_t*)(base + o_rp), (const uint32_t*)(base + o_col), base + o_cf, rows, terms,
-                              (void*)S->compute, group);
+                              (void*)S->compute, group, g2_trusted);
     if (rc != ZK_OK) { rcs[d] = rc; return; }
     e = hipMemcpyAsync(out + r0 * rec, base + o_out, rows * rec, hipMemcpyDeviceToHost, S->compute);
     if (e == hipSuccess) e = hipStreamSynchronize(S->compute);
@@ -2511,9 +2583,10 @@ int mi355zk_bn254_fr_divide_by_z_on_coset_dev(void* d_a, uint32_t log_n, void* s
 }
 
 // EvaluationDomain<Point<G1>>::{fft, ifft} on affine records (group.rs:22-51, domain.rs:154-173; prepare_phase2.rs:68-131)
-int mi355zk_bn254_g1_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {
+int mi355zk_bn254_g1_point_fft_dev(void* d_points_affine, uint32_t log_n, int mode, void* stream) {
   return abi_guard([&]() -> int {
-    if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
+    if (!d_points_affine || log_n > 28 || (mode & ~(MI355ZK_FFT_INVERSE | MI355ZK_G2_TRUSTED_SUBGROUP))) return ZK_ERR_BAD_ARGS;
+    const int inverse = mode & MI355ZK_FFT_INVERSE;
     DomainConsts D;
     int rc = domain_consts(log_n, &D);
     if (rc) return rc;
@@ -2547,13 +2620,15 @@ int mi355zk_bn254_g2_encode_dev(void* d_out_bytes, const void* d_in_affine, size
   });
 }
 
-int mi355zk_bn254_g2_point_fft_dev(void* d_points_affine, uint32_t log_n, int inverse, void* stream) {
+int mi355zk_bn254_g2_point_fft_dev(void* d_points_affine, uint32_t log_n, int mode, void* stream) {
   return abi_guard([&]() -> int {
-    if (!d_points_affine || log_n > 28) return ZK_ERR_BAD_ARGS;
+    if (!d_points_affine || log_n > 28 || (mode & ~(MI355ZK_FFT_INVERSE | MI355ZK_G2_TRUSTED_SUBGROUP))) return ZK_ERR_BAD_ARGS;
+    const int inverse = mode & MI355ZK_FFT_INVERSE;
     DomainConsts D;
     int rc = domain_consts(log_n, &D);
     if (rc) return rc;
-    return point_fft_g2(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream);
+    return point_fft_g2(d_points_affine, log_n, inverse ? D.omegainv : D.omega, inverse != 0, to_canonical(D.minv), (hipStream_t)stream,
+                        (mode & MI355ZK_G2_TRUSTED_SUBGROUP) != 0);
   });
 }
 
@@ -2579,48 +2654,57 @@ int mi355zk_bn254_g2_batch_mul_dev(void* d_out_affine, const uint64_t base_affin
   });
 }
 int mi355zk_bn254_g1_sparse_matvec(uint8_t* out_affine, const uint8_t* bases_affine, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col,
-                                   const uint64_t* coeffs, size_t n_rows, size_t nnz) {
+                                   const uint64_t* coeffs, size_t n_rows, size_t nnz, int flags) {
   return abi_guard([&]() -> int {
-    return sparse_matvec_host<Fq>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 1);
+    if (flags & ~MI355ZK_G2_TRUSTED_SUBGROUP) return ZK_ERR_BAD_ARGS;
+    return sparse_matvec_host<Fq>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 1, false);
   });
 }
 int mi355zk_bn254_g2_sparse_matvec(uint8_t* out_affine, const uint8_t* bases_affine, size_t n_bases, const uint32_t* row_ptr, const uint32_t* col,
-                                   const uint64_t* coeffs, size_t n_rows, size_t nnz) {
+                                   const uint64_t* coeffs, size_t n_rows, size_t nnz, int flags) {
   return abi_guard([&]() -> int {
-    return sparse_matvec_host<Fq2>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 2);
+    if (flags & ~MI355ZK_G2_TRUSTED_SUBGROUP) return ZK_ERR_BAD_ARGS;
+    return sparse_matvec_host<Fq2>(out_affine, bases_affine, n_bases, row_ptr, col, coeffs, n_rows, nnz, 2, (flags & MI355ZK_G2_TRUSTED_SUBGROUP) != 0);
   });
 }
 int mi355zk_bn254_g1_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
-                                       const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
+                                       const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream, int flags) {
   return abi_guard([&]() -> int {
-    return sparse_matvec<Fq>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1);
+    if (flags & ~MI355ZK_G2_TRUSTED_SUBGROUP) return ZK_ERR_BAD_ARGS;
+    return sparse_matvec<Fq>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 1, false);
   });
 }
 int mi355zk_bn254_g2_sparse_matvec_dev(void* d_out_affine, const void* d_bases_affine, size_t n_bases, const uint32_t* d_row_ptr,
-                                       const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream) {
+                                       const uint32_t* d_col, const void* d_coeffs, size_t n_rows, size_t nnz, void* stream, int flags) {
   return abi_guard([&]() -> int {
-    return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2);
+    if (flags & ~MI355ZK_G2_TRUSTED_SUBGROUP) return ZK_ERR_BAD_ARGS;
+    return sparse_matvec<Fq2>(d_out_affine, d_bases_affine, n_bases, d_row_ptr, d_col, d_coeffs, n_rows, nnz, stream, 2, (flags & MI355ZK_G2_TRUSTED_SUBGROUP) != 0);
   });
 }
 
-int mi355zk_bn254_g1_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int same_scalar) {
+int mi355zk_bn254_g1_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int mode) {
   return abi_guard([&]() -> int {
-    return batch_exp_host<Fq>(out_affine, bases_affine, scalars, n, same_scalar);
+    if (mode & ~(MI355ZK_EXP_SAME_SCALAR | MI355ZK_G2_TRUSTED_SUBGROUP)) return ZK_ERR_BAD_ARGS;
+    return batch_exp_host<Fq>(out_affine, bases_affine, scalars, n, mode & MI355ZK_EXP_SAME_SCALAR, false);
   });
 }
-int mi355zk_bn254_g2_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int same_scalar) {
+int mi355zk_bn254_g2_batch_exp(uint8_t* out_affine, const uint8_t* bases_affine, const uint64_t* scalars, size_t n, int mode) {
   return abi_guard([&]() -> int {
-    return batch_exp_host<Fq2>(out_affine, bases_affine, scalars, n, same_scalar);
+    if (mode & ~(MI355ZK_EXP_SAME_SCALAR | MI355ZK_G2_TRUSTED_SUBGROUP)) return ZK_ERR_BAD_ARGS;
+    return batch_exp_host<Fq2>(out_affine, bases_affine, scalars, n, mode & MI355ZK_EXP_SAME_SCALAR, (mode & MI355ZK_G2_TRUSTED_SUBGROUP) != 0);
   });
 }
-int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
+int mi355zk_bn254_g1_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int mode, void* stream) {
   return abi_guard([&]() -> int {
-    return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+    if (mode & ~(MI355ZK_EXP_SAME_SCALAR | MI355ZK_G2_TRUSTED_SUBGROUP)) return ZK_ERR_BAD_ARGS;
+    return batch_exp<Fq>(d_out_affine, d_bases_affine, 0, d_scalars, mode & MI355ZK_EXP_SAME_SCALAR, n, stream);
   });
 }
-int mi355zk_bn254_g2_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int same_scalar, void* stream) {
+int mi355zk_bn254_g2_batch_exp_dev(void* d_out_affine, const void* d_bases_affine, const void* d_scalars, size_t n, int mode, void* stream) {
   return abi_guard([&]() -> int {
-    return batch_exp<Fq2>(d_out_affine, d_bases_affine, 0, d_scalars, same_scalar, n, stream);
+    if (mode & ~(MI355ZK_EXP_SAME_SCALAR | MI355ZK_G2_TRUSTED_SUBGROUP)) return ZK_ERR_BAD_ARGS;
+    return batch_exp<Fq2>(d_out_affine, d_bases_affine, 0, d_scalars, mode & MI355ZK_EXP_SAME_SCALAR, n, stream, nullptr, false,
+                          (mode & MI355ZK_G2_TRUSTED_SUBGROUP) != 0);
   });
 }
 

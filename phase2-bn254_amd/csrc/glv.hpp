@@ -219,4 +219,30 @@ ZK_HD int glv_wnaf5(const uint32_t m_in[5], int8_t digits[GLV_WNAF_LEN]) {
   return top;
 }
 
+// fixed signed 4-bit windows of a magnitude given as NIN 32-bit words: m = sum_j d_j 16^j with d_j in [-8, 8] -- mag holds |d_j| one nibble
+// each (NW >= NIN words: the carry out of the last input nibble lands in nibble 8 NIN when NW > NIN; with NW == NIN the caller knows the
+// top nibble leaves room, e.g. the < 2^128 halves of a split in five words), sgn bit j = (d_j < 0).
+template <int NW, int NIN>
+ZK_HD void signed_nibbles(const uint32_t* m, uint32_t mag[NW], uint32_t sgn[(NW + 3) / 4]) {
+#pragma unroll
+  for (int w = 0; w < (NW + 3) / 4; ++w) sgn[w] = 0;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t word = w < NIN ? m[w] : 0u;
+    uint32_t o = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t d = ((word >> (4 * q)) & 15u) + carry;
+      carry = d > 8u ? 1u : 0u;
+      if (carry) {
+        d = 16u - d;
+        sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
+      }
+      o |= d << (4 * q);
+    }
+    mag[w] = o;
+  }
+}
+
 }  // namespace zk

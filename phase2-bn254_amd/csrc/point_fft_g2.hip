@@ -67,9 +67,13 @@ __global__ void __launch_bounds__(256) pfft2_load_kernel(const G2Affine* __restr
 }
 
 // The program of point_fft.hip's pfft_stage_kernel, on U-form Jacobian points:
-//   steps 0..6 table (2t .. 8t), steps 7..171 the 33 windows of the split twiddle (four doublings, the k1 digit, the k2 digit through psi),
-//   step 172 entry 1 := product, steps 173 / 174: a[i0] = u + product, a[i1] = u - product   (mode 0, domain.rs:303-309)
-//   mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173)
+//   steps 0..6 table (2t .. 8t), then the windows of the twiddle, then entry 1 := product, a[i0] = u + product, a[i1] = u - product
+//   (mode 0, domain.rs:303-309);  mode 1: every point times the scalar `c` (ifft's 1/m, domain.rs:163-173).
+// SPLIT = false (the default): 64 plain signed 4-bit windows of the canonical twiddle -- four doublings and a table addition each, the
+//   group law only, so the transform is the reference's (group.rs:38-51 over wnaf.rs:4-71) for EVERY vector of points of the twist.
+// SPLIT = true (MI355ZK_G2_TRUSTED_SUBGROUP): 33 windows of the twiddle split over psi (glv.hpp: w t = k1 t + k2 psi(t)) -- four doublings,
+//   the k1 digit, the k2 digit through psi; psi(t) = mu t holds in the order-r subgroup only, and a transform of subgroup points stays in it.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work, const uint32_t* __restrict__ tw_canon, uint32_t log_n,
                                                          uint32_t s, uint64_t b0, uint64_t n_chunk, JacTabU2* __restrict__ tab, int mode, Fr c) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,38 +97,26 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
   }
   const JacU2 u = mode == 0 ? v_load(work + i0).p : JacU2::zero();
   JacU2 acc = v_load(work + i1).p;
-  // the twiddle split by the twist's endomorphism (glv.hpp): w t = k1 t + k2 psi(t), k1, k2 < 2^128; signed 4-bit digits of both
-  const Glv2Split g = glv2_split(kk);
-  uint32_t mag1[5], mag2[5], sgn1[2] = {0, 0}, sgn2[2] = {0, 0};
-  auto digits = [](const uint32_t m[5], uint32_t mag[5], uint32_t sgn[2]) {
-    uint32_t carry = 0;
-#pragma unroll
-    for (int w = 0; w < 5; ++w) {
-      uint32_t o = 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        uint32_t d = ((m[w] >> (4 * q)) & 15u) + carry;
-        carry = d > 8u ? 1u : 0u;
-        if (carry) {
-          d = 16u - d;
-          sgn[w >> 2] |= 1u << (8 * (w & 3) + q);
-        }
-        o |= d << (4 * q);
-      }
-      mag[w] = o;
-    }
-  };
-  digits(g.k1, mag1, sgn1);
-  digits(g.k2, mag2, sgn2);
-  const FqU C266 = UPow2<FqParams, 266>::get();
-  const Fq2 cxs = glv2_cx(), cys = glv2_cy();
-  const Fq2U cxU{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};   // 2^261 domain, < 2p
-  const Fq2U cyU{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
+  // signed 4-bit digits: of both halves of the split twiddle (k1, k2 < 2^128), or of the twiddle itself (canonical, < r < 2^254: 64 nibbles, no carry out)
+  constexpr int NW = SPLIT ? 5 : 8;
+  uint32_t mag1[NW], mag2[SPLIT ? 5 : 1], sgn1[2], sgn2[2];
+  Fq2U cxU, cyU;
+  if constexpr (SPLIT) {
+    const Glv2Split g = glv2_split(kk);
+    signed_nibbles<5, 5>(g.k1, mag1, sgn1);
+    signed_nibbles<5, 5>(g.k2, mag2, sgn2);
+    const FqU C266 = UPow2<FqParams, 266>::get();
+    const Fq2 cxs = glv2_cx(), cys = glv2_cy();
+    cxU = Fq2U{u_mul(u_from_std(cxs.c0), C266), u_mul(u_from_std(cxs.c1), C266)};   // 2^261 domain, < 2p
+    cyU = Fq2U{u_mul(u_from_std(cys.c0), C266), u_mul(u_from_std(cys.c1), C266)};
+  } else {
+    signed_nibbles<8, 8>(kk, mag1, sgn1);
+  }
   const bool t_inf = acc.is_zero();
   if (t_inf && mode == 1) return;
   if (!t_inf) v_store(tab + t, jacu2_tab_entry(acc));
   constexpr uint32_t PROG[7] = {0x1102, 0x0013, 0x2104, 0x0015, 0x3106, 0x0017, 0x4108};  // nibbles: load, double, add, store
-  constexpr int MAIN0 = 7, WINDOWS = 33, STEP_STORE = MAIN0 + 5 * WINDOWS, STEP_SUM = STEP_STORE + 1, STEP_DIF = STEP_STORE + 2;
+  constexpr int MAIN0 = 7, WINDOWS = SPLIT ? 33 : 64, PER = SPLIT ? 5 : 4, STEP_STORE = MAIN0 + PER * WINDOWS, STEP_SUM = STEP_STORE + 1, STEP_DIF = STEP_STORE + 2;
   const int first = (unit || t_inf) ? STEP_SUM : 0;   // twiddle one, or t = infinity: the product is t itself (entry 1 already holds it)
   const int last = mode == 0 ? STEP_DIF : STEP_STORE - 1;
 #pragma unroll 1
@@ -137,9 +129,9 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
       add = (pr >> 4) & 15u;
       store = pr & 15u;
     } else if (step < STEP_STORE) {
-      const int m = step - MAIN0;   // per window: four doublings (the fourth adds the k1 digit), then the k2 digit through psi
+      const int m = step - MAIN0;   // per window: four doublings (the fourth adds the k1 digit), then (SPLIT) the k2 digit through psi
       if (m == 0) acc = JacU2::zero();
-      const int win = m / 5, sub = m - 5 * win, j = WINDOWS - 1 - win;
+      const int win = m / PER, sub = m - PER * win, j = WINDOWS - 1 - win;
       if (sub < 4) {
         dbl_it = 1;
         if (sub == 3) {
@@ -166,8 +158,12 @@ __global__ void __launch_bounds__(256) pfft2_stage_kernel(J2* __restrict__ work,
     if (dbl_it) acc = jacu2_double(acc);
     if (add) {
       JacTabU2 e = v_load(tab + (uint64_t)(add - 1) * n_chunk + t);
-      if (psi) e = jacu2_tab_psi(e, cxU, cyU);
-      jacu2_add_tab(acc, e, negate != 0);
+      if constexpr (SPLIT) {
+        if (psi) e = jacu2_tab_psi(e, cxU, cyU);
+        jacu2_add_tab(acc, e, negate != 0);
+      } else {
+        if (!e.z.limbs_all_zero()) jacu2_add_tab(acc, e, negate != 0);   // (an infinite multiple d t, d <= 8: never on the twist, whose order is odd and has no small factor)
+      }
     }
     if (store) v_store(tab + (uint64_t)(store - 1) * n_chunk + t, jacu2_tab_entry(acc));
     if (step == STEP_SUM) v_store(work + i0, j2_of(acc));
@@ -196,7 +192,7 @@ __global__ void pfft2_twiddle_kernel(uint32_t* tw, Fr omega, uint64_t count) {
 }  // namespace
 
 // d_points: 2^log_n affine raw G2 records (128 B), in place.  scale: every output is multiplied by scale_canon (ifft: m^-1).
-int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st) {
+int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, const Fr& scale_canon, hipStream_t st, bool trusted_subgroup) {
   const uint64_t n = 1ull << log_n;
   const uint64_t lanes_max = scale ? n : (n >= 2 ? n / 2 : 1);
   const uint64_t chunk = lanes_max < (1ull << 19) ? lanes_max : (1ull << 19);  // table: 8 x 368 B per lane
@@ -213,12 +209,18 @@ int point_fft_g2(void* d_points, uint32_t log_n, const Fr& omega, bool scale, co
   for (uint32_t s = 0; s < log_n; ++s)
     for (uint64_t b0 = 0; b0 < n / 2; b0 += chunk) {
       const uint64_t m = n / 2 - b0 < chunk ? n / 2 - b0 : chunk;
-      hipLaunchKernelGGL(pfft2_stage_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s, b0, m, tab, 0, Fr::zero());
+      if (trusted_subgroup)
+        hipLaunchKernelGGL(pfft2_stage_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s, b0, m, tab, 0, Fr::zero());
+      else
+        hipLaunchKernelGGL(pfft2_stage_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, s, b0, m, tab, 0, Fr::zero());
     }
   if (scale)
     for (uint64_t b0 = 0; b0 < n; b0 += chunk) {
       const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
-      hipLaunchKernelGGL(pfft2_stage_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, 0u, b0, m, tab, 1, scale_canon);
+      if (trusted_subgroup)
+        hipLaunchKernelGGL(pfft2_stage_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, 0u, b0, m, tab, 1, scale_canon);
+      else
+        hipLaunchKernelGGL(pfft2_stage_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, work, tw, log_n, 0u, b0, m, tab, 1, scale_canon);
     }
   hipLaunchKernelGGL(pfft2_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, (G2Affine*)d_points, zbuf, log_n);
   hipError_t e = hipGetLastError();

@@ -57,7 +57,7 @@ template <> struct Abi<G1Affine> {
   static int batch_exp(void* o, const void* b, const void* s, size_t n, int same) { return mi355zk_bn254_g1_batch_exp_dev(o, b, s, n, same, nullptr); }
   static int dense(const void* b, const void* s, size_t n, uint64_t* out) { return mi355zk_bn254_g1_dense_multiexp_dev(b, s, n, nullptr, out); }
   static int merge(const void* a, const void* b, const void* r, size_t n, uint64_t* s, uint64_t* sx) { return mi355zk_bn254_g1_merge_pairs_dev(a, b, r, n, nullptr, s, sx); }
-  static int matvec(void* o, const void* b, size_t nb, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz) { return mi355zk_bn254_g1_sparse_matvec_dev(o, b, nb, rp, c, k, rows, nnz, nullptr); }
+  static int matvec(void* o, const void* b, size_t nb, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz, int flags) { return mi355zk_bn254_g1_sparse_matvec_dev(o, b, nb, rp, c, k, rows, nnz, nullptr, flags); }
   static int fft(void* p, uint32_t log_n, int inv) { return mi355zk_bn254_g1_point_fft_dev(p, log_n, inv, nullptr); }
   static int decode(void* o, const void* in, size_t n, int c, int chk, long long* idx) { return mi355zk_bn254_g1_decode_dev(o, in, n, c, chk, nullptr, idx); }
   static int encode(void* o, const void* in, size_t n, int c) { return mi355zk_bn254_g1_encode_dev(o, in, n, c, nullptr); }
@@ -67,7 +67,7 @@ template <> struct Abi<G2Affine> {
   static int batch_exp(void* o, const void* b, const void* s, size_t n, int same) { return mi355zk_bn254_g2_batch_exp_dev(o, b, s, n, same, nullptr); }
   static int dense(const void* b, const void* s, size_t n, uint64_t* out) { return mi355zk_bn254_g2_dense_multiexp_dev(b, s, n, nullptr, out); }
   static int merge(const void* a, const void* b, const void* r, size_t n, uint64_t* s, uint64_t* sx) { return mi355zk_bn254_g2_merge_pairs_dev(a, b, r, n, nullptr, s, sx); }
-  static int matvec(void* o, const void* b, size_t nb, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz) { return mi355zk_bn254_g2_sparse_matvec_dev(o, b, nb, rp, c, k, rows, nnz, nullptr); }
+  static int matvec(void* o, const void* b, size_t nb, const uint32_t* rp, const uint32_t* c, const void* k, size_t rows, size_t nnz, int flags) { return mi355zk_bn254_g2_sparse_matvec_dev(o, b, nb, rp, c, k, rows, nnz, nullptr, flags); }
   static int fft(void* p, uint32_t log_n, int inv) { return mi355zk_bn254_g2_point_fft_dev(p, log_n, inv, nullptr); }
   static int decode(void* o, const void* in, size_t n, int c, int chk, long long* idx) { return mi355zk_bn254_g2_decode_dev(o, in, n, c, chk, nullptr, idx); }
   static int encode(void* o, const void* in, size_t n, int c) { return mi355zk_bn254_g2_encode_dev(o, in, n, c, nullptr); }
@@ -75,21 +75,24 @@ template <> struct Abi<G2Affine> {
 };
 }  // namespace detail
 
+// trusted_subgroup (batch_exp, eval_qap, point_fft): the caller's promise MI355ZK_G2_TRUSTED_SUBGROUP -- every G2 record is in the order-r
+// subgroup, the kernels may split scalars over the twist's endomorphism.  Default: plain windows, the reference's wNAF result for every
+// record its decoders admit.  Ignored for G1.
 // out[i] = exps[i] * bases[i], normalised to affine (batched_accumulator.rs:1130-1181)
 template <class G>
-std::vector<G> batch_exp(const std::vector<G>& bases, const std::vector<FrRepr>& exps) {
+std::vector<G> batch_exp(const std::vector<G>& bases, const std::vector<FrRepr>& exps, bool trusted_subgroup = false) {
   if (exps.size() != bases.size()) throw std::invalid_argument("batch_exp: one exponent per base");
   detail::DeviceArray b(bases.data(), bases.size() * sizeof(G)), e(exps.data(), exps.size() * 32), o(nullptr, bases.size() * sizeof(G));
-  detail::check(detail::Abi<G>::batch_exp(o.get(), b.get(), e.get(), bases.size(), 0));
+  detail::check(detail::Abi<G>::batch_exp(o.get(), b.get(), e.get(), bases.size(), trusted_subgroup ? MI355ZK_G2_TRUSTED_SUBGROUP : 0));
   std::vector<G> out(bases.size());
   o.download(out.data());
   return out;
 }
 // out[i] = coeff * bases[i] (parameters.rs:423-470)
 template <class G>
-std::vector<G> batch_exp(const std::vector<G>& bases, const FrRepr& coeff) {
+std::vector<G> batch_exp(const std::vector<G>& bases, const FrRepr& coeff, bool trusted_subgroup = false) {
   detail::DeviceArray b(bases.data(), bases.size() * sizeof(G)), e(coeff.data(), 32), o(nullptr, bases.size() * sizeof(G));
-  detail::check(detail::Abi<G>::batch_exp(o.get(), b.get(), e.get(), bases.size(), 1));
+  detail::check(detail::Abi<G>::batch_exp(o.get(), b.get(), e.get(), bases.size(), MI355ZK_EXP_SAME_SCALAR | (trusted_subgroup ? MI355ZK_G2_TRUSTED_SUBGROUP : 0)));
   std::vector<G> out(bases.size());
   o.download(out.data());
   return out;
@@ -120,12 +123,14 @@ std::pair<typename G::Projective, typename G::Projective> power_pairs(const std:
 
 // out[v] = sum over the terms t in [row_ptr[v], row_ptr[v+1]) of coeff[t] * bases[col[t]], affine (parameters.rs:281-294 + batch_normalization)
 template <class G>
-std::vector<G> eval_qap(const std::vector<G>& bases, const std::vector<uint32_t>& row_ptr, const std::vector<uint32_t>& col, const std::vector<FrRepr>& coeff) {
+std::vector<G> eval_qap(const std::vector<G>& bases, const std::vector<uint32_t>& row_ptr, const std::vector<uint32_t>& col, const std::vector<FrRepr>& coeff,
+                        bool trusted_subgroup = false) {
   if (row_ptr.empty() || col.size() != coeff.size() || row_ptr.back() != col.size()) throw std::invalid_argument("eval_qap: malformed CSR");
   const size_t rows = row_ptr.size() - 1;
   detail::DeviceArray b(bases.data(), bases.size() * sizeof(G)), rp(row_ptr.data(), row_ptr.size() * 4), c(col.data(), col.size() * 4),
       k(coeff.data(), coeff.size() * 32), o(nullptr, rows * sizeof(G));
-  detail::check(detail::Abi<G>::matvec(o.get(), b.get(), bases.size(), (const uint32_t*)rp.get(), (const uint32_t*)c.get(), k.get(), rows, col.size()));
+  detail::check(detail::Abi<G>::matvec(o.get(), b.get(), bases.size(), (const uint32_t*)rp.get(), (const uint32_t*)c.get(), k.get(), rows, col.size(),
+                                      trusted_subgroup ? MI355ZK_G2_TRUSTED_SUBGROUP : 0));
   std::vector<G> out(rows);
   o.download(out.data());
   return out;
@@ -133,16 +138,16 @@ std::vector<G> eval_qap(const std::vector<G>& bases, const std::vector<uint32_t>
 
 // in place on `points` (a power-of-two number of them); the ifft includes the 1/m scaling and the normalisation (prepare_phase2.rs:102-131)
 template <class G>
-void point_fft(std::vector<G>& points, bool inverse) {
+void point_fft(std::vector<G>& points, bool inverse, bool trusted_subgroup = false) {
   const size_t n = points.size();
   if (n == 0 || (n & (n - 1))) throw std::invalid_argument("point_fft: power-of-two length");
   uint32_t log_n = 0;
   while (((size_t)1 << log_n) < n) ++log_n;
   detail::DeviceArray p(points.data(), n * sizeof(G));
-  detail::check(detail::Abi<G>::fft(p.get(), log_n, inverse ? 1 : 0));
+  detail::check(detail::Abi<G>::fft(p.get(), log_n, (inverse ? MI355ZK_FFT_INVERSE : 0) | (trusted_subgroup ? MI355ZK_G2_TRUSTED_SUBGROUP : 0)));
   p.download(points.data());
 }
-template <class G> void point_ifft(std::vector<G>& points) { point_fft(points, true); }
+template <class G> void point_ifft(std::vector<G>& points, bool trusted_subgroup = false) { point_fft(points, true, trusted_subgroup); }
 
 template <class G>
 std::vector<uint8_t> encode_points(const std::vector<G>& points, bool compressed) {

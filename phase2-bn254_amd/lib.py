@@ -15,6 +15,7 @@ SO_PATH = os.environ.get("MI355ZK_SO") or os.path.join(_HERE, "libmi355zk.so")
 OK, ERR_UNEXPECTED_IDENTITY, ERR_UNEXPECTED_EOF, ERR_BAD_ARGS, ERR_DEVICE = 0, 1, 2, 3, -1
 OP_FFT, OP_IFFT, OP_COSET_FFT, OP_ICOSET_FFT = 0, 1, 2, 3
 MSM_SCALARS_MONTGOMERY = 1
+EXP_SAME_SCALAR, FFT_INVERSE, G2_TRUSTED_SUBGROUP = 1, 1, 2   # mode / flag bits of batch_exp, point_fft, sparse_matvec (include/mi355zk.h)
 
 _vp, _sz, _i, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
 _u64p, _u32p, _u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
@@ -84,10 +85,10 @@ SIGNATURES = {
     "mi355zk_selftest_g1_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
     "mi355zk_selftest_g2_scalar_mul_u": (_i, [_vp, _vp, _vp]),
     "mi355zk_selftest_g2_accumulate": (_i, [_i, _vp, _vp, _sz, _vp]),
-    "mi355zk_bn254_g1_sparse_matvec": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz]),
-    "mi355zk_bn254_g2_sparse_matvec": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz]),
-    "mi355zk_bn254_g1_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),
-    "mi355zk_bn254_g2_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "mi355zk_bn254_g1_sparse_matvec": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _i]),
+    "mi355zk_bn254_g2_sparse_matvec": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _i]),
+    "mi355zk_bn254_g1_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _i]),
+    "mi355zk_bn254_g2_sparse_matvec_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _i]),
     "mi355zk_bn254_g1_decode_dev": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     "mi355zk_bn254_g2_decode_dev": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     "mi355zk_bn254_g1_encode_dev": (_i, [_vp, _vp, _sz, _i, _vp]),

@@ -262,9 +262,11 @@ def test_full_size_device_resident_properties(zk, worker, log_n):
 
 @pytest.mark.parametrize("group", [1, 2])
 @pytest.mark.parametrize("same_scalar", [0, 1])
-def test_batch_exp_matches_oracle(zk, worker, group, same_scalar):
+@pytest.mark.parametrize("trusted", [0, 2])
+def test_batch_exp_matches_oracle(zk, worker, group, same_scalar, trusted):
     """out[i] = k[i] * P[i] (powersoftau batch_exp) / k * P[i] (phase2 contribute), affine out.
-    Bit exact against the oracle's mul_assign + into_affine, incl. scalar 0 / 1 / r-1 and an infinity base."""
+    Bit exact against the oracle's mul_assign + into_affine, incl. scalar 0 / 1 / r-1 and an infinity base.  trusted = 2
+    (MI355ZK_G2_TRUSTED_SUBGROUP): the psi-split G2 kernel (these bases are in the subgroup); accepted and ignored on G1."""
     import torch
 
     import bn254_model as M
@@ -283,16 +285,17 @@ def test_batch_exp_matches_oracle(zk, worker, group, same_scalar):
     d_k = torch.from_numpy(ks.view(np.int64)).cuda()
     d_o = torch.empty_like(d_b)
     fn = zk.lib.load().mi355zk_bn254_g1_batch_exp_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_batch_exp_dev
-    assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(d_k.data_ptr()), n, same_scalar, None) == 0
+    assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(d_k.data_ptr()), n, same_scalar | trusted, None) == 0
     torch.cuda.synchronize()
     got = d_o.cpu().numpy().view(np.uint64)
     for i in range(n):
         want = G.to_affine(G.mul(G.from_affine(bases[i]), ks[i]))
         assert np.array_equal(got[i], want), i
+    assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(d_k.data_ptr()), n, same_scalar | 4, None) == 3   # an unknown mode bit
 
 
-@pytest.mark.parametrize("group", [1, 2])
-def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group):
+@pytest.mark.parametrize("group,trusted", [(1, 0), (2, 0), (2, 2)])
+def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group, trusted):
     """The per-point scalar multiplications split the scalar by the curve's endomorphism (glv.hpp: k = k1 + k2 lambda on G1,
     k = k1 + k2 mu on G2).  Scalars on and around the eigenvalue and its multiples, around 2^128, and with one half of the split
     equal to zero, per point and as the one shared scalar, against the oracle's plain double-and-add."""
@@ -306,7 +309,7 @@ def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group
     vals = [ev, ev + 1, ev - 1, R - ev, 2 * ev % R, 3 * ev % R, (ev * ev) % R, (ev * ev + 1) % R, (1 << 128) - 1, 1 << 128, (1 << 128) + 1,
             (1 << 127), (ev << 64) % R, 7, 8, 9, 15, 16, 17, R - 2, (R - 1) // 2, (R + 1) // 2, 0x8888888888888888888888888888888888888888 % R,
             0x0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F % R,
-            R, R + 1, (1 << 256) - 1, (1 << 255) + 12345]                  # not canonical: still k * P (the split is exact for any 256-bit k)
+            R, R + 1, (1 << 256) - 1, (1 << 255) + 12345]                  # not canonical: still k * P (plain windows take all 256 bits; the split is exact for any 256-bit k)
     n = len(vals)
     bases = inputs.bases_progression_cpu(group, n, seed=190 + group)
     ks = np.array([M.to_limbs(v) for v in vals], dtype=np.uint64)
@@ -314,7 +317,7 @@ def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group
     d_b = torch.from_numpy(bases.view(np.int64)).cuda()
     d_o = torch.empty_like(d_b)
     d_k = torch.from_numpy(ks.view(np.int64)).cuda()
-    assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(d_k.data_ptr()), n, 0, None) == 0
+    assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(d_k.data_ptr()), n, trusted, None) == 0
     torch.cuda.synchronize()
     got = d_o.cpu().numpy().view(np.uint64)
     for i in range(n):
@@ -322,7 +325,7 @@ def test_batch_exp_scalars_around_the_endomorphism_eigenvalues(zk, worker, group
     # the same values as the ONE scalar of a phase2-style call (G1: the sliding-window kernel -- every value, and 0 / 1 / 2 / 3 / r - 1)
     for v in (vals + [0, 1, 2, 3, R - 1, 31, 32, 33, (1 << 127) - 1] if group == 1 else vals[:8]):
         one = torch.from_numpy(np.array([M.to_limbs(v)], dtype=np.uint64).view(np.int64)).cuda()
-        assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(one.data_ptr()), n, 1, None) == 0
+        assert fn(C.c_void_p(d_o.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_void_p(one.data_ptr()), n, 1 | trusted, None) == 0
         torch.cuda.synchronize()
         got = d_o.cpu().numpy().view(np.uint64)
         k = np.array(M.to_limbs(v % R), dtype=np.uint64)

@@ -60,32 +60,35 @@ def test_point_fft_roundtrip_and_lagrange_property(zk, worker):
 
 @pytest.mark.parametrize("log_n", [0, 1, 3, 6])
 @pytest.mark.parametrize("op", ["fft", "ifft"])
-def test_g2_point_fft_matches_oracle(zk, worker, log_n, op):
-    """The G2 leg of prepare_phase2 (coeffs_g2): bit exact against the oracle's Point<G2> FFT + batch_normalization."""
+@pytest.mark.parametrize("trusted", [0, 2])
+def test_g2_point_fft_matches_oracle(zk, worker, log_n, op, trusted):
+    """The G2 leg of prepare_phase2 (coeffs_g2): bit exact against the oracle's Point<G2> FFT + batch_normalization -- through the plain
+    windows (default) and, these points being in the subgroup, under MI355ZK_G2_TRUSTED_SUBGROUP (mode bit 1: the psi-split twiddles)."""
     n = 1 << log_n
     pts = inputs.bases_progression_cpu(2, n, seed=60 + log_n)
     if n >= 4:
         pts[2] = 0  # an infinity coefficient
     want = O.point_domain_op(2, pts, log_n, op)
-    got = _run(zk, pts, log_n, 1 if op == "ifft" else 0, group=2)
+    got = _run(zk, pts, log_n, (1 if op == "ifft" else 0) | trusted, group=2)
     assert np.array_equal(got, want)
 
 
-def test_g2_point_fft_roundtrip(zk, worker):
+@pytest.mark.parametrize("trusted", [0, 2])
+def test_g2_point_fft_roundtrip(zk, worker, trusted):
     log_n = 9
     pts = inputs.bases_progression_cpu(2, 1 << log_n, seed=71)
-    lag = _run(zk, pts, log_n, 1, group=2)
+    lag = _run(zk, pts, log_n, 1 | trusted, group=2)
     assert not np.array_equal(lag, pts)
-    assert np.array_equal(_run(zk, lag, log_n, 0, group=2), pts)
+    assert np.array_equal(_run(zk, lag, log_n, 0 | trusted, group=2), pts)
 
 
-@pytest.mark.parametrize("group", [1, 2])
-def test_point_ifft_matches_oracle_at_2e12(zk, worker, group):
+@pytest.mark.parametrize("group,trusted", [(1, 0), (2, 0), (2, 2)])
+def test_point_ifft_matches_oracle_at_2e12(zk, worker, group, trusted):
     """prepare_phase2's Lagrange conversion at 2^12 points (the REQUIRED_POWER of BASELINE config 1), G1 and G2, every record
     against the oracle's Point<G> FFT + batch_normalization; an infinity coefficient included."""
     log_n = 12
     pts = inputs.bases_progression_cpu(group, 1 << log_n, seed=90 + group)
     pts[1234] = 0
     want = O.point_domain_op(group, pts, log_n, "ifft")
-    got = _run(zk, pts, log_n, 1, group=group)
+    got = _run(zk, pts, log_n, 1 | trusted, group=group)
     assert np.array_equal(got, want)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Measurements for the SURVEY 8(f) "next" rows that are built: batch_exp (row 1), merge_pairs (row 2), the QAP sparse matvec (row 3) and the G1 point FFT (row 4)."""
+"""Measurements for the SURVEY 8(f) "next" rows that are built: batch_exp (row 1), merge_pairs (row 2), the QAP sparse matvec (row 3) and the G1 point FFT (row 4).
+G2 rows are measured twice: the default (plain windows: the reference's result for every record its decoders admit) and, keys ending in
+"_trusted_subgroup", under the promise MI355ZK_G2_TRUSTED_SUBGROUP (psi-split scalars) -- the price of the exact default on honest data."""
 import argparse, ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,12 +23,19 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     sc = bench.gen_scalars(n, 41 + g, dev)
     res = torch.empty((n, limbs), dtype=torch.int64, device=dev)
     bexp = L.mi355zk_bn254_g1_batch_exp_dev if g == 1 else L.mi355zk_bn254_g2_batch_exp_dev
+    TRUST = zk.lib.G2_TRUSTED_SUBGROUP
+    modes = ((0, ""),) if g == 1 else ((0, ""), (TRUST, "_trusted_subgroup"))
     for same in (0, 1):
-        bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same, None); torch.cuda.synchronize()
+      for tr, suffix in modes:
+        assert bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same | tr, None) == 0; torch.cuda.synchronize()
+        if tr: ref_res = res.clone()
         t = time.perf_counter()
-        for _ in range(a.iters): bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same, None)
+        for _ in range(a.iters): bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same | tr, None)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / a.iters
-        out[f"g{g}_batch_exp_{'same_scalar' if same else 'per_point'}"] = {"ms": round(dt * 1e3, 3), "Mpoint_per_s": round(n / dt / 1e6, 2)}
+        out[f"g{g}_batch_exp_{'same_scalar' if same else 'per_point'}{suffix}"] = {"ms": round(dt * 1e3, 3), "Mpoint_per_s": round(n / dt / 1e6, 2)}
+        if tr:
+            assert bexp(C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), C.c_void_p(sc.data_ptr()), n, same, None) == 0
+            out[f"g{g}_batch_exp_{'same_scalar' if same else 'per_point'}{suffix}"]["equals_default_on_subgroup_points"] = bool(torch.equal(res, ref_res))
     mp = L.mi355zk_bn254_g1_merge_pairs_dev if g == 1 else L.mi355zk_bn254_g2_merge_pairs_dev
     s, sx = np.zeros(12 * g, np.uint64), np.zeros(12 * g, np.uint64)
     args = (C.c_void_p(bases.data_ptr()), C.c_void_p(bases.data_ptr() + 64 * g), C.c_void_p(sc.data_ptr()), n, None, s.ctypes.data_as(C.c_void_p), sx.ctypes.data_as(C.c_void_p))
@@ -44,11 +53,12 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     cf = bench.gen_scalars(nnz, 61 + g, dev)
     smv = L.mi355zk_bn254_g1_sparse_matvec_dev if g == 1 else L.mi355zk_bn254_g2_sparse_matvec_dev
     sargs = (C.c_void_p(res.data_ptr()), C.c_void_p(bases.data_ptr()), n, C.c_void_p(rp32.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(cf.data_ptr()), n, nnz, None)
-    assert smv(*sargs) == 0
-    t = time.perf_counter()
-    for _ in range(a.iters): assert smv(*sargs) == 0
-    dt = (time.perf_counter() - t) / a.iters
-    out[f"g{g}_qap_sparse_matvec"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
+    for tr, suffix in modes:
+        assert smv(*sargs, tr) == 0
+        t = time.perf_counter()
+        for _ in range(a.iters): assert smv(*sargs, tr) == 0
+        dt = (time.perf_counter() - t) / a.iters
+        out[f"g{g}_qap_sparse_matvec{suffix}"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
     # the same matrix with circom-like coefficients: 90 % of the terms +-1 (no scalar multiplication), 10 % general
     kind = torch.randint(0, 20, (nnz,), device=dev, generator=g_)
     cf1 = cf.clone()
@@ -57,11 +67,12 @@ for g, limbs, gen in ((1, 8, inputs.G1_GEN_RAW), (2, 16, inputs.G2_GEN_RAW)):
     cf1[kind < 9] = one
     cf1[(kind >= 9) & (kind < 18)] = rm1
     sargs1 = sargs[:5] + (C.c_void_p(cf1.data_ptr()),) + sargs[6:]
-    assert smv(*sargs1) == 0
-    t = time.perf_counter()
-    for _ in range(a.iters): assert smv(*sargs1) == 0
-    dt = (time.perf_counter() - t) / a.iters
-    out[f"g{g}_qap_sparse_matvec_90pct_unit_coeffs"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
+    for tr, suffix in modes:   # (G2 default: a coefficient r - 1 is a full multiplication -- (r - 1) P == -P only where r P == infinity)
+        assert smv(*sargs1, tr) == 0
+        t = time.perf_counter()
+        for _ in range(a.iters): assert smv(*sargs1, tr) == 0
+        dt = (time.perf_counter() - t) / a.iters
+        out[f"g{g}_qap_sparse_matvec_90pct_unit_coeffs{suffix}"] = {"rows": n, "nnz": nnz, "ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
 # row 4: point FFT (prepare_phase2's Lagrange-basis conversion)
 for ln in (12, 16, a.log_n):
     m = 1 << ln
@@ -105,9 +116,10 @@ for ln in (12, min(a.log_n, 18)):  # G2 leg (coeffs_g2)
     assert L.mi355zk_bn254_g2_batch_mul_dev(C.c_void_p(pts.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), m, None) == 0
     torch.cuda.synchronize()
     ref = pts.clone()
-    t = time.perf_counter()
-    assert L.mi355zk_bn254_g2_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 1, None) == 0
-    dt = time.perf_counter() - t
-    assert L.mi355zk_bn254_g2_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 0, None) == 0
-    out[f"g2_point_ifft_2e{ln}"] = {"ms": round(dt * 1e3, 2), "Mbutterfly_per_s": round(m / 2 * ln / dt / 1e6, 2), "fft_of_ifft_is_identity": bool(torch.equal(pts, ref))}
+    for tr, suffix in ((0, ""), (zk.lib.G2_TRUSTED_SUBGROUP, "_trusted_subgroup")):
+        t = time.perf_counter()
+        assert L.mi355zk_bn254_g2_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 1 | tr, None) == 0
+        dt = time.perf_counter() - t
+        assert L.mi355zk_bn254_g2_point_fft_dev(C.c_void_p(pts.data_ptr()), ln, 0 | tr, None) == 0
+        out[f"g2_point_ifft_2e{ln}{suffix}"] = {"ms": round(dt * 1e3, 2), "Mbutterfly_per_s": round(m / 2 * ln / dt / 1e6, 2), "fft_of_ifft_is_identity": bool(torch.equal(pts, ref))}
 print(json.dumps(out))
