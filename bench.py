@@ -25,7 +25,9 @@ phase2 contribute at 2^20), each with its own `roofline` and `cpu_baseline`, all
 from __future__ import annotations
 
 import argparse
+import contextlib
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -80,14 +82,46 @@ def _prof(L, names):
     return res
 
 
+# The interpreter's cyclic garbage collector: with torch imported a full (generation-2) collection walks a few hundred thousand objects --
+# tens of milliseconds -- and it fires wherever the allocation counters happen to trip.  BENCH_r04's "G1 table mode 3.24 ms" was 20 calls of
+# 1.39 ms plus ONE such pause (round 5 reproduced it: ms_min_median_max = [3.69, 3.79, 38.2] in the G2 table leg of two driver-style runs,
+# none in tools/diag_table_calls.py's 200 calls).  Every timed loop of the secondary legs therefore runs like `timeit` does: collect first,
+# collector off inside.  The callback below logs each collection so the JSON line says what was seen (`host_gc`).
+_GC_LOG = []
+
+
+def _gc_cb(phase, info):
+    if phase == "start":
+        _gc_cb.t0 = time.perf_counter()
+    else:
+        _GC_LOG.append((int(info.get("generation", -1)), (time.perf_counter() - getattr(_gc_cb, "t0", time.perf_counter())) * 1e3))
+
+
+gc.callbacks.append(_gc_cb)
+
+
+@contextlib.contextmanager
+def _no_gc():
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def _timed(fn, iters):
     fn()
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(iters):
-        r = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / iters, r
+    with _no_gc():
+        t = time.perf_counter()
+        for _ in range(iters):
+            r = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / iters
+    return dt, r
 
 
 def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
@@ -183,10 +217,11 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         for _ in range(25 if group == 1 else 12):
             zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
         iters = 20 if group == 1 else 10
-        t = time.perf_counter()
-        for _ in range(iters):
-            res = zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
-        dt = (time.perf_counter() - t) / iters   # (no per-kernel events in the timed loop: ~20 event records are 1-2 % of a 2-ms call)
+        with _no_gc():
+            t = time.perf_counter()
+            for _ in range(iters):
+                res = zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
+            dt = (time.perf_counter() - t) / iters   # (no per-kernel events in the timed loop: ~20 event records are 1-2 % of a 2-ms call)
         L.mi355zk_prof_reset()
         L.mi355zk_prof_enable(1)
         for _ in range(5):
@@ -206,13 +241,14 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         # windows) -- for vectors that do not change between calls, like the Parameters a prover queries; same affine point
         tb = zk.MsmTable(b)
         torch.cuda.synchronize()
-        for _ in range(25 if group == 1 else 12):      # the plain leg's warm-up (round 4 gave this leg ONE call: BENCH_r04's 3.24 ms was a cold figure)
+        for _ in range(25 if group == 1 else 12):      # the plain leg's warm-up
             zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
         calls = []
-        for _ in range(iters):
-            t = time.perf_counter()
-            res_t = zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
-            calls.append(time.perf_counter() - t)
+        with _no_gc():
+            for _ in range(iters):
+                t = time.perf_counter()
+                res_t = zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
+                calls.append(time.perf_counter() - t)
         dt_t = sum(calls) / iters
         L.mi355zk_prof_reset()
         L.mi355zk_prof_enable(1)
@@ -453,14 +489,15 @@ def main() -> int:
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
     result = None
-    for _ in range(args.steps):
-        result = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    with _no_gc():   # (the interpreter's collector off inside the timed region, as `timeit` runs: see _GC_LOG)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            result = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     L.mi355zk_prof_enable(0)
     acc_ms_timed, acc_cnt = C.c_double(), C.c_long()
     L.mi355zk_prof_get(b"msm_accumulate", C.byref(acc_ms_timed), C.byref(acc_cnt))
@@ -683,6 +720,10 @@ def main() -> int:
         torch.cuda.empty_cache()
         out["secondary"] = secondary(zk, L, worker, dev, args.secondary_log_n, cpu=not args.no_cpu_baseline)
     if rank == 0:
+        full = [ms for g, ms in _GC_LOG if g == 2]
+        out["host_gc"] = {"collections": len(_GC_LOG), "full_collections": len(full), "longest_ms": round(max([ms for _, ms in _GC_LOG], default=0.0), 2),
+                          "note": "cyclic-GC runs of this interpreter during the whole bench (outside the timed loops, which run with the collector "
+                                  "off): a full collection with torch imported is what put single 38-64 ms calls into round 4's table-mode legs"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -162,6 +162,15 @@ ZK_HD Fq2 glv2_cy() {
   for (int i = 0; i < 8; ++i) { r.c0.l[i] = a[i]; r.c1.l[i] = b[i]; }
   return r;
 }
+// the twist's coefficient b' = 3 / (9 + u) in the memory format (pairing/src/bn256/fq.rs:18-31 B_COEFF_FQ2, the same limbs)
+ZK_HD Fq2 g2_coeff_b() {
+  const uint32_t a[8] = {0x77b802a8u, 0x3bf938e3u, 0x3633535du, 0x020b1b27u, 0x49755260u, 0x26b7edf0u, 0x4384a86du, 0x2514c632u};
+  const uint32_t b[8] = {0xd1dcff67u, 0x38e7ecccu, 0x93ce0d3eu, 0x65f0b37du, 0x22ac00aau, 0xd749d0ddu, 0x4a688d4du, 0x0141b9ceu};
+  Fq2 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { r.c0.l[i] = a[i]; r.c1.l[i] = b[i]; }
+  return r;
+}
 
 // non-adjacent form of a magnitude m < 2^159 (5 limbs): digit j = bit_{j+1}(3m) - bit_{j+1}(m);  pos / neg: 5 limbs + 1 bit (6 words)
 ZK_HD void glv_naf(const uint32_t m[5], uint32_t pos[6], uint32_t neg[6]) {

@@ -1443,14 +1443,17 @@ __global__ void __launch_bounds__(256) msm_accumulate_pair_g1_kernel(
 template <class F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) msm_accumulate_split_kernel(
     const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-    const uint32_t* __restrict__ order, uint32_t split_t, uint32_t heavy, uint32_t hb, XYZZ<F>* __restrict__ buckets, int skip_zero,
-    unsigned long long* __restrict__ err_base) {
+    const uint32_t* __restrict__ order, uint32_t split_t, uint32_t heavy, uint32_t heavy_hb, uint32_t hb, XYZZ<F>* __restrict__ buckets,
+    int skip_zero, unsigned long long* __restrict__ err_base) {
   using U = typename BucketAcc<F>::type;
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, i = gt >> 2, role = gt & 3u;
   if (i >= hb) return;                                 // (whole quads leave: i is the same for the four lanes)
   const uint32_t b = order[i];
   const uint32_t j = first[b], e = last[b];
-  if (e - j <= split_t || e - j > heavy) return;       // the lane-per-bucket launch / the segment-parallel path has it
+  // the lane-per-bucket launch has the short ones, the segment-parallel path the heavy ones AMONG order[0 .. heavy_hb): a heavy bucket
+  // past that reach (more than MSM_HEAVY_BLOCKS over-long buckets: skewed exponents) is walked here -- the main kernel skips every
+  // bucket of order[0 .. max(hb, heavy_hb)) longer than split_t, so nobody else would take it
+  if (e - j <= split_t || (e - j > heavy && i < heavy_hb)) return;
   U part = xyzzr_load(XYZZ<F>::zero());
   if (j + role < e) part = xyzzr_load(xyzzu_to_r(accumulate_run<F, false>(U::zero(), bases, vals, j + role, e, 4, skip_zero != 0, err_base)));
   // (split_t >= 4: every lane has at least one entry; the test above is for safety)
@@ -2369,7 +2372,7 @@ int msm_device(const Affine<F>* d_bases, uint64_t n_bases, uint64_t base_offset,
     const uint32_t skip_len = split ? C.split_t : C.heavy, skip_hb = split ? std::max(C.split_hb, C.hb) : C.hb;
     if (split) {
       hipLaunchKernelGGL(msm_accumulate_split_kernel<F>, dim3((4 * C.split_hb + 255) / 256), dim3(256), 0, st, bases_set, vals_b, first, last, order,
-                         C.split_t, C.heavy, C.split_hb, buckets, dense ? 1 : 0, d_err);
+                         C.split_t, C.heavy, C.hb, C.split_hb, buckets, dense ? 1 : 0, d_err);
       ZK_HIP(hipGetLastError());
     }
     bool pair_done = false;

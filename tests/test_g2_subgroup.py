@@ -56,6 +56,31 @@ def test_subgroup_points_pass_and_a_cofactor_point_fails_on_host(lib):
         assert lib.mi355zk_selftest_g2_in_subgroup(mixed.ctypes.data_as(C.c_void_p)) == 0
 
 
+def test_the_membership_test_is_sound_for_bn254():
+    """api.hip g2_in_subgroup: P in G2 <=> f(psi) P == 0 with f = (x + 1) + x X + x X^2 - 2 x X^3.  psi satisfies chi = X^2 - t X + q on all of
+    E'(Fq2), so f(psi) P == 0 implies Res(f, chi) P == 0; the order of P then divides gcd(Res, #E'(Fq2)) -- which is r: a point that passes
+    is in the subgroup, and a member passes because r | Res means f(q) == 0 mod r for psi's eigenvalue q.  The same for rounds 3-4's X - 6 x^2."""
+    import math
+
+    x = 0x44E992B44A6909F1
+    q, r, t = 36 * x**4 + 36 * x**3 + 24 * x**2 + 6 * x + 1, 36 * x**4 + 36 * x**3 + 18 * x**2 + 6 * x + 1, 6 * x**2 + 1
+    assert q == M.Q and r == M.R_ORDER
+    order = r * (2 * q - r)                                       # #E'(Fq2) of the sextic twist that carries G2
+
+    def resultant_with_chi(f):                                    # f: integer coefficients, low degree first; Res(f, chi) by reducing mod chi
+        # work in Z[X] / (chi): X^2 = t X - q.  Res(chi, f) = prod over the two roots of chi of f(root) = norm of f(X) in Z[X]/(chi) (chi monic)
+        a, b = 0, 0                                               # f(X) = a + b X mod chi
+        for c in reversed(f):
+            a, b = c - q * b, a + t * b                           # (a + b X) X + c
+        # norm of a + b X over the roots s1, s2 (s1 + s2 = t, s1 s2 = q): (a + b s1)(a + b s2) = a^2 + a b t + b^2 q
+        return a * a + a * b * t + b * b * q
+
+    for f in ([x + 1, x, x, -2 * x], [-(t - 1), 1]):
+        res = resultant_with_chi(f)
+        assert res % r == 0 and math.gcd(res, 2 * q - r) == 1 and math.gcd(res, order) == r
+        assert sum(c * pow(q, k, r) for k, c in enumerate(f)) % r == 0   # members pass: psi acts on G2 as q
+
+
 def _limbs(v):
     return np.array(M.to_limbs(v % (1 << 256)), dtype=np.uint64)
 

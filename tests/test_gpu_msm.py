@@ -429,8 +429,8 @@ def test_merge_pairs_and_dense_multiexp(zk, worker, group):
     assert np.array_equal(G.to_affine(one), ref(v[:n]))
 
 
-@pytest.mark.parametrize("group", [1, 2])
-def test_sparse_matvec_qap_evaluation(zk, worker, group):
+@pytest.mark.parametrize("group,trusted", [(1, 0), (2, 0), (2, 2)])
+def test_sparse_matvec_qap_evaluation(zk, worker, group, trusted):
     """out[v] = sum over the terms of variable v of coeff * Lagrange point (parameters.rs:281-294),
     then batch_normalization.  CSR rows of very different lengths (empty rows, one long row such as the constant-one
     variable, +-1 and zero coefficients, an infinity base), bit exact against the oracle's mul_assign / add_assign."""
@@ -457,14 +457,14 @@ def test_sparse_matvec_qap_evaluation(zk, worker, group):
     d_out = torch.zeros((len(row_len), 8 * group), dtype=torch.int64, device="cuda")
     fn = zk.lib.load().mi355zk_bn254_g1_sparse_matvec_dev if group == 1 else zk.lib.load().mi355zk_bn254_g2_sparse_matvec_dev
     assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), nb, C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_col.data_ptr()),
-              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 0
+              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None, trusted) == 0
     # the index arrays are validated: one column beyond the bases, or a non-monotone row_ptr, is "bad arguments" (3), not a wild gather
     assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), int(col.max()), C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_col.data_ptr()),
-              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 3
+              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None, trusted) == 3
     bad_rp = row_ptr.copy()
     bad_rp[2], bad_rp[3] = bad_rp[3], bad_rp[2] - 1
     assert fn(C.c_void_p(d_out.data_ptr()), C.c_void_p(d_bases.data_ptr()), nb, C.c_void_p(d(bad_rp).data_ptr()), C.c_void_p(d_col.data_ptr()),
-              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None) == 3
+              C.c_void_p(d_cf.data_ptr()), len(row_len), nnz, None, trusted) == 3
     got = d_out.cpu().numpy().view(np.uint64)
     for r in range(len(row_len)):
         acc = G.from_affine(np.zeros(G.aff, np.uint64))
