@@ -73,6 +73,29 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def ntt_sources_sha() -> str:
+    """the same lock for the NTT pass's PMC figure (profiles/latest_pmc_ntt.json)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("ntt.hip", "fieldu.hpp"):
+        with open(os.path.join(ROOT, "phase2-bn254_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _ntt_traffic(log_n: int):
+    """HBM bytes per ntt_pass_kernel launch from the committed PMC record, only while it was measured at this size on these sources"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_pmc_ntt.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload_log_n") == log_n and pmc.get("kernel_sources_sha") == ntt_sources_sha():
+            return pmc["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def _prof(L, names):
     res = {}
     for name in names:
@@ -167,9 +190,8 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
     entry = {"metric": "2^%d-element BN254 Fr NTT (EvaluationDomain fft / ifft / coset_fft), in place in HBM" % log_n, **ntt,
              "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                          # profiles/r03_ntt20_pmc_hbm.txt: WRITE_SIZE 32 MiB exactly + FETCH_SIZE 33.35 MB x 2 (the guide's correction for
-                          # coalesced streams) per pass, reported only for the size it was measured at
-                          "traffic": int((33352.8 * 2 + 32768.9) * 1024) if log_n == 20 else None,
+                          # a SEPARATE rocprofv3 --pmc pass, hash-locked to ntt.hip + fieldu.hpp (profiles/latest_pmc_ntt.json): null rather than stale
+                          "traffic": _ntt_traffic(log_n),
                           "passes_per_transform": passes, "pass_ms": round(pass_ms, 4) if pass_ms else None,
                           "note": "algorithmic 64 B per element per pass (32 B read + 32 B written); the pass is VALU-issue bound (DESIGN.md 3)"}}
     if cpu:

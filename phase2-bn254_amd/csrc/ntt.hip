@@ -155,12 +155,18 @@ __device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// Row-local LDS position of element x: the low five bits (the bank) are XOR-ed with the next five.  Any 32
-// consecutive x stay on 32 different banks (butterfly stages with m >= 32), the stride-2/4/.. pairs of the
-// first stages spread over both halves, and the bit-reversed placement at load time -- whose low five
-// index bits are constant across 32 consecutive inputs -- becomes conflict-free as well.  Measured before:
-// 59 % of the kernel's LDS cycles were bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
-__device__ __forceinline__ uint32_t swz(uint32_t x) { return x ^ ((x >> 5) & 31u); }
+// Row-local LDS position of element x: the low five bits (the bank, up to the odd element stride 9) are XOR-ed with a mix of the bits
+// above them.  Round 4 XOR-ed bits 5..9 in unchanged and padded the rows to np + 1 elements: tools/ntt_lds_model.py (a bank model of every
+// access site of this kernel; it reproduces the counter) showed where its 20 % conflict cycles on the 2^20 pass came from -- the stage pair
+// with m = 16 (lanes 16 apart hold x and x + 64, and "+ 64" moved the position by 2, inside the same 16 banks) and the closing read of a
+// G >= 2 tile (neighbouring lanes alternate rows at +9 banks per row against +9 per element) -- and 33 - 58 % on the tiles of 2^21 .. 2^26.
+// Now: bits 5..9 times 25 (so that x + 32, + 64, + 128 ... each land in another part of the 32 banks), bits 10, 11 of the long rows folded
+// in, rows at the plain pitch np and told apart by a row term (lds_pos).  Modelled conflict cycles: 2^20 pass 20 % -> 0, 2^21 .. 2^23
+// 26 - 33 % -> 0, 2^24 58 % -> 20 %, 2^25 / 2^26 45 % -> 1 %; measured: profiles/r05_ntt20_pass_sq_pmc.txt.
+__device__ __forceinline__ uint32_t swz(uint32_t x) { return x ^ ((((x >> 5) * 25u) ^ (x >> 10)) & 31u); }
+// position of element x of row g in a tile of rows of np >= 32 elements: `rowx` = (g * a) & 31 with a = 21 (a = 20 for eight-row tiles)
+// moves neighbouring rows to other banks where lanes alternate rows (tile load and store); shorter rows are not permuted (swz is the identity there)
+__device__ __forceinline__ uint32_t row_term(uint32_t g, uint32_t G, uint32_t np) { return np >= 32 ? (g * (G == 8 ? 20u : 21u)) & 31u : 0u; }
 
 // One pass over one tile.  roots[x] = w_p^x for x < N_p/2 (w_p = omega^(N/N_p)).
 template <uint32_t LOG_NP, bool R4>
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   // twiddle-one products are skipped in stages 0 .. SKIP_MAX: rows longer than 2^10 give up stage 2 (a skipped stage doubles the
   // value bound instead of adding 2p: 16p + 2 (LOG_NP - 3) p would pass the 32p the closing reduction allows; 10p + 2 (LOG_NP - 3) p does not)
   constexpr uint32_t SKIP_MAX = LOG_NP > 10 ? 1 : 2;
-  constexpr uint32_t pitch = np >= 32 ? np + 1 : np;  // break the power-of-two row stride
+  constexpr uint32_t pitch = np;
   const uint32_t plane = P.g * pitch;
   const uint32_t elems = P.g * np;
   // One- and two-row tiles move 32- / 64-byte runs at a large stride: a fraction of every DRAM burst and page, the rest belonging to
@@ -198,7 +204,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));                    // g^i = A[i >> h] * B[i & mask]: two products by constants
       v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));     // < 2p, N
     }
-    lds_store(lds, plane, g * pitch + swz(bitrev(x, LOG_NP)), v);
+    lds_store(lds, plane, g * pitch + (swz(bitrev(x, LOG_NP)) ^ row_term(g, P.g, np)), v);
   }
   __syncthreads();
 
@@ -230,7 +236,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     const uint32_t half = elems >> 1;
     for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
       const uint32_t g = b >> (LOG_NP - 1), x0 = (b & ((np >> 1) - 1)) << 1;
-      const uint32_t i0 = g * pitch + swz(x0), i1 = g * pitch + swz(x0 + 1);
+      const uint32_t rx = row_term(g, P.g, np);
+      const uint32_t i0 = g * pitch + (swz(x0) ^ rx), i1 = g * pitch + (swz(x0 + 1) ^ rx);
       FrU u = lds_load(lds, plane, i0), t = lds_load(lds, plane, i1);
       bf(std::integral_constant<int, 0>{}, u, t, TwU{u, u}, true);
       lds_store(lds, plane, i0, u);
@@ -259,8 +266,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
         j = qf & (m - 1);
         x0 = ((qf >> s) << (s + 2)) + j;
       }
-      const uint32_t row = g * pitch;
-      const uint32_t ia = row + swz(x0), ib = row + swz(x0 + m), ic = row + swz(x0 + 2 * m), id = row + swz(x0 + 3 * m);
+      const uint32_t row = g * pitch, rx = row_term(g, P.g, np);
+      const uint32_t ia = row + (swz(x0) ^ rx), ib = row + (swz(x0 + m) ^ rx), ic = row + (swz(x0 + 2 * m) ^ rx), id = row + (swz(x0 + 3 * m) ^ rx);
       FrU a = lds_load(lds, plane, ia), b = lds_load(lds, plane, ib), c = lds_load(lds, plane, ic), d = lds_load(lds, plane, id);
       const bool one = s <= SKIP_MAX && j == 0;                            // stage s (s == 0: j == 0 always)
       {
@@ -315,8 +322,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
         j = bf & (m - 1);
         x0 = ((bf >> s) << (s + 1)) + j;
       }
-      uint32_t i0 = g * pitch + swz(x0);
-      uint32_t i1 = g * pitch + swz(x0 + m);
+      const uint32_t rx = row_term(g, P.g, np);
+      uint32_t i0 = g * pitch + (swz(x0) ^ rx);
+      uint32_t i1 = g * pitch + (swz(x0 + m) ^ rx);
       FrU u = lds_load(lds, plane, i0);
       FrU t = lds_load(lds, plane, i1);
       // (t < 24p with limbs < 4*2^29 either way: the skipped product only leaves t as large as u may be)
@@ -337,7 +345,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   // store: one more product brings the value below 2p (inter-pass twiddle, or the post scale / one on the last pass)
   for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
     uint32_t g = e % P.g, k = e / P.g;
-    FrU v = lds_load(lds, plane, g * pitch + swz(k));                     // < 30p, limbs < 4*2^29
+    FrU v = lds_load(lds, plane, g * pitch + (swz(k) ^ row_term(g, P.g, np)));   // < 30p, limbs < 4*2^29
     const uint64_t go = out_base + k * P.out_xs + g * P.out_gs;
     TwU w;
     if (P.tw_full) {
@@ -521,7 +529,7 @@ std::map<int, int> g_cfg;  // device -> rc of its one-time kernel configuration
 
 }  // namespace
 
-// the tile kernel stages up to 4 x 1025 x 36 B = 144 KiB in dynamic LDS (gfx950: 160 KiB per CU)
+// the tile kernel stages up to 4096 x 36 B = 144 KiB in dynamic LDS (gfx950: 160 KiB per CU)
 int ntt_configure() {
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
@@ -728,7 +736,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     P.xcd_pair = ((P.g <= 2 || pair_all) && tiles % 256 == 0 && !no_pair) ? (pair_env ? (uint32_t)std::atoi(pair_env) : 5u) : 0u;
     if (p == 0 && Tpre) { P.pre = 1; P.pre_h = Tpre->h; }
     if (p == R - 1) { P.post = Tpost ? 2 : (post_c ? 1 : 3); P.post_h = Tpost ? Tpost->h : 0; }
-    uint32_t pitch = np >= 32 ? (uint32_t)np + 1 : (uint32_t)np;
+    uint32_t pitch = (uint32_t)np;
     size_t lds_bytes = (size_t)P.g * pitch * 36;
     uint32_t threads = (uint32_t)((P.g * np) / 2);
     if (threads > NTT_THREADS) threads = NTT_THREADS;

@@ -48,6 +48,24 @@ json.dump({"round": int(tag[1:3]), "workload_log_n": 26, "n_gpus": 1, "kernel": 
           open(os.path.join(DST, "latest_pmc.json"), "w"), indent=1)
 print(open(os.path.join(DST, "latest_pmc.json")).read())
 
+# ---- the NTT pass's HBM counters, locked to ntt.hip + fieldu.hpp like the MSM figure is to its sources (round 5: bench.py carried a literal from round 3)
+if os.path.exists(os.path.join(SRC, "ntt20_pmc_fetch.txt")):
+    with open(os.path.join(DST, f"{tag}_ntt20_pmc_hbm.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/bench_ntt.py --log-n 20  (MI355X), KB per dispatch, averaged over\n"
+                "# BOTH passes of the transforms (pass 1 also streams the 72-MiB table of inter-pass twiddles, pass 2 the 36-KiB root table).  The pass reads its data\n"
+                "# as 16 B / lane coalesced streams: FETCH_SIZE tallies 64 B per 128-byte request there (the guide's x2); the table entries are read as 8-byte words of\n"
+                "# consecutive lanes, the same streaming pattern.  Infinity-Cache hits are counted (32 MiB of data + the table fit its 256 MiB).\n")
+        f.write(open(os.path.join(SRC, "ntt20_pmc_fetch.txt")).read())
+        f.write("".join(l for l in open(os.path.join(SRC, "ntt20_pmc_write.txt")) if not l.startswith("kernel ")))
+    nf = counter("ntt20_pmc_fetch.txt", "zk::ntt_pass_kernel"); nw = counter("ntt20_pmc_write.txt", "zk::ntt_pass_kernel")
+    json.dump({"round": int(tag[1:3]), "workload_log_n": 20, "kernel": "ntt_pass_kernel<10, radix-4>", "FETCH_SIZE_KB_per_launch": nf, "WRITE_SIZE_KB_per_launch": nw,
+               "hbm_bytes_per_launch": int((2 * nf + nw) * 1024), "kernel_sources_sha": bench.ntt_sources_sha(),
+               "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/bench_ntt.py --log-n 20 (profiles/{tag}_ntt20_pmc_hbm.txt), average of the "
+                      "two passes of a transform; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the reads are coalesced streams, which gfx950's FETCH_SIZE tallies at half "
+                      "their bytes (guide); algorithmic 64 B x 2^20 = 67.1 MB per pass, the rest is the twiddle table of pass 1 (72 B per element)"},
+              open(os.path.join(DST, "latest_pmc_ntt.json"), "w"), indent=1)
+    print(open(os.path.join(DST, "latest_pmc_ntt.json")).read())
+
 # ---- round 4 additions
 for src, dst, hdr in (("ab_quad.txt", "ab_quad.txt", "# bash tools/ab_quad.sh: the reduce tails on quad additions (default) against one lane per addition (MI355ZK_MSM_QUAD=0), same box, same process order;\n# bench.py --log-n L --steps 30 --warmup 10 (ms per call, msm_reduce / msm_accumulate by HIP events, result limb) and tools/bench_g2.py\n"),
                       ("multi_device_2e26.json", "multi_device_2e26.json", None),
