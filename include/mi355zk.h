@@ -110,7 +110,9 @@ int mi355zk_bases_cache_pin(const void *host_bases, size_t n_bases, int group);
  * table mode from the second call on -- what a prover wants for the h / l / a / b vectors of its Parameters. */
 int mi355zk_bases_cache_pin_tables(const void *host_bases, size_t n_bases, int group);
 void mi355zk_bases_cache_invalidate(const void *host_bases);
-/* diagnostics: 1 when a device copy of the vector at host_bases is cached (its size, and the size of its window table or 0), else 0 */
+/* diagnostics: 1 when device copies of (parts of) the vector at host_bases are cached, else 0; *device_bytes = their total over all devices -- the whole
+ * vector on the one device that runs the calls over it, or, after multi-GPU calls (mi355zk_init with n_devices > 1), one slice per device: n / N
+ * records each -- and *table_bytes = the size of its window table or 0 */
 int mi355zk_bases_cache_info(const void *host_bases, size_t *device_bytes, size_t *table_bytes);
 /* Same for G = G2Affine (prover.rs:297-298). */
 int mi355zk_bn254_g2_msm(const uint8_t *bases, size_t n_bases, size_t base_offset,

@@ -1249,7 +1249,8 @@ int msm_dev_entry(const void* d_bases, size_t n_bases, size_t base_offset, const
 //     PCIe and the kernels overlap; the first call is bound by the link (96 B per exponent), later calls by the kernels.
 
 struct BasesEntry {
-  const void* host = nullptr;
+  const void* host = nullptr;   // first record of what is cached: the pinned vector itself, or the SLICE of it a multi-GPU cell consumes
+  const void* owner = nullptr;  // the pinned vector the records belong to (== host unless a slice): what invalidate / info are asked about
   size_t n = 0;
   int group = 0, dev = 0;
   uint64_t fp = 0;
@@ -1321,11 +1322,22 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
   const size_t cap = bases_cache_cap();
   if (cap == 0 || bytes > cap) return nullptr;
   bool want_table = false;
+  const void* owner = host;
   {
     std::lock_guard<std::mutex> lk(g_bc_mu);
+    // pinned: the vector itself, or a record range INSIDE a pinned vector (the single-process multi-GPU mode caches on each device only
+    // the slice its cell consumes: SURVEY 8e "the tau-table slice stays resident on its GPU")
     bool pinned = false;
-    for (auto& p : g_bc_pins)
-      if (p.host == host && p.n == n && p.group == group) { pinned = true; want_table = want_table || p.tables; }
+    const size_t rec = group == 1 ? 64 : 128;
+    for (auto& p : g_bc_pins) {
+      if (p.group != group) continue;
+      const char* lo = (const char*)p.host;
+      if ((const char*)host >= lo && (const char*)host + n * rec <= lo + p.n * rec) {
+        pinned = true;
+        owner = p.host;
+        want_table = want_table || (p.tables && p.host == host && p.n == n);   // (tables for whole vectors only: a slice's calls are cells)
+      }
+    }
     if (!pinned && !bases_cache_implicit()) return nullptr;
   }
   const uint64_t fp = bases_fingerprint((const uint8_t*)host, bytes, group == 1 ? 64 : 128);
@@ -1342,7 +1354,7 @@ std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, 
     return nullptr;                                       // its upload failed: go uncached
   }
   auto e = std::make_shared<BasesEntry>();
-  e->host = host; e->n = n; e->group = group; e->dev = dev; e->fp = fp; e->bytes = bytes; e->want_table = want_table;
+  e->host = host; e->owner = owner; e->n = n; e->group = group; e->dev = dev; e->fp = fp; e->bytes = bytes; e->want_table = want_table;
   {
     std::lock_guard<std::mutex> lk(g_bc_mu);
     // the capacity is PER DEVICE (a process may drive several: mi355zk_init with n_devices > 1 keeps a copy of a pinned vector on
@@ -1449,13 +1461,13 @@ void bases_cache_invalidate(const void* host) {
     else ++i;
   }
   for (size_t i = 0; i < g_bc.size();) {
-    if ((host == nullptr || g_bc[i]->host == host) && g_bc[i]->ready && g_bc[i].use_count() == 1) {
+    if ((host == nullptr || g_bc[i]->host == host || g_bc[i]->owner == host) && g_bc[i]->ready && g_bc[i].use_count() == 1) {
       (void)hipSetDevice(g_bc[i]->dev);
       (void)hipFree(g_bc[i]->d);
       (void)hipFree(g_bc[i]->table);
       g_bc.erase(g_bc.begin() + (long)i);
     } else {
-      if (host == nullptr || g_bc[i]->host == host) g_bc[i]->fp ^= 0x9e3779b97f4a7c15ull;  // in use: never matched again
+      if (host == nullptr || g_bc[i]->host == host || g_bc[i]->owner == host) g_bc[i]->fp ^= 0x9e3779b97f4a7c15ull;  // in use: never matched again
       ++i;
     }
   }
@@ -1867,8 +1879,14 @@ int msm_host_multi(const std::vector<int>& devs, const uint8_t* bases, size_t n_
   const auto t0 = std::chrono::steady_clock::now();
   auto run_cell = [&](Cell& c) {
     if (hipSetDevice(c.dev) != hipSuccess) { c.rc = ZK_ERR_DEVICE; return; }
+    // The cell sees only the SLICE of the base vector its exponents consume -- [boff, boff + used) -- as a vector of its own: that is what
+    // its device allocates, uploads and (inside a pinned vector) keeps: 2^26 G1 points on 8 devices are 512 MiB per device, not 4 GiB
+    // (SURVEY 8e).  The ranges end before the first exponent without a base (the Eof is planned above for the whole call), so the slice
+    // holds every base the cell asks for.
+    constexpr size_t bsz = GROUP == 1 ? 64 : 128;
     const uint64_t boff = base_offset + density_rank(P, density, c.lo);
-    c.rc = msm_host_run<GROUP>(bases, n_bases, boff, scalars + c.lo * 4, c.hi - c.lo, density ? density + (c.lo >> 5) : nullptr,
+    const uint64_t used = density_rank(P, density, c.hi) - density_rank(P, density, c.lo);
+    c.rc = msm_host_run<GROUP>(bases + boff * bsz, used, 0, scalars + c.lo * 4, c.hi - c.lo, density ? density + (c.lo >> 5) : nullptr,
                                density ? c.hi - c.lo : 0, reinterpret_cast<uint64_t*>(&c.part), wg, c.wgi);
     c.err = t_last_err_index;
     if (trace)
@@ -1928,8 +1946,18 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
   const int min_log = env ? std::atoi(env) : 20;
   if (n_scalars >= (1ull << (min_log < 0 ? 0 : min_log > 30 ? 30 : min_log)) && n_scalars >= 64)
     return msm_host_multi<GROUP>(devs, bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
+  // A short call runs whole on ONE device: the one that already holds the (pinned) vector if there is one -- the device copy of a
+  // parameter vector is then made once per process, not once per device of the set (8 x 4 GiB for a 2^26-point CRS) -- else the next in
+  // turn, so that the prover's concurrent multiexps over its different vectors spread over the node on first touch.
+  int pick = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_bc_mu);
+    for (auto& e : g_bc)
+      if (e->host == bases && e->n == n_bases && e->group == GROUP && std::find(devs.begin(), devs.end(), e->dev) != devs.end()) { pick = e->dev; break; }
+  }
+  if (pick < 0) pick = devs[g_devset_turn.fetch_add(1) % devs.size()];
   DeviceGuard guard;
-  ZK_HIP(hipSetDevice(devs[g_devset_turn.fetch_add(1) % devs.size()]));
+  ZK_HIP(hipSetDevice(pick));
   return msm_host_run<GROUP>(bases, n_bases, base_offset, scalars, n_scalars, density, density_bits, out_xyz);
 }
 
@@ -2398,7 +2426,7 @@ int mi355zk_bases_cache_info(const void* host_bases, size_t* device_bytes, size_
     {
       std::lock_guard<std::mutex> lk(g_bc_mu);
       for (auto& e : g_bc)
-        if (e->host == host_bases && e->ready) { d += e->bytes; t += e->table_bytes; found = 1; }
+        if ((e->host == host_bases || e->owner == host_bases) && e->ready) { d += e->bytes; t += e->table_bytes; found = 1; }
     }
     if (device_bytes) *device_bytes = d;
     if (table_bytes) *table_bytes = t;

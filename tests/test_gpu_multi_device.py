@@ -332,3 +332,39 @@ def test_qap_evaluation_on_host_buffers_over_the_device_set(zk, worker, group, k
         for t in range(row_ptr[r], row_ptr[r + 1]):
             acc = G.add(acc, G.mul(G.from_affine(bases[col[t]]), coeff[t]))
         assert np.array_equal(got[r], G.to_affine(acc)), r
+
+
+def test_each_device_keeps_only_the_slice_its_cell_consumes(zk, multi):
+    """"the tau-table slice stays resident on its GPU".  A pinned vector that multi-GPU calls run over is cached as one slice per
+    (logical) device -- n / N records each, together the vector once -- not as a whole copy per device (round 4: N x the vector); with a
+    density map the slices are the prefix-popcount ranges.  A short call (below the cutting threshold) runs whole on ONE device and the
+    next short calls over the same vector go to the device that holds it."""
+    lib = zk.lib.load()
+    n = 4096
+    bases = inputs.bases_progression_cpu(1, n, seed=4601)
+    scalars = inputs.random_scalars(n, seed=4602)
+    rc, want = O.G1.multiexp(bases, scalars, threads=4)
+    assert rc == 0
+    d, t = C.c_size_t(0), C.c_size_t(0)
+    for k in (2, 4, 8):
+        w = multi(k)
+        zk.pin_bases(bases)
+        for _ in range(2):
+            assert np.array_equal(O.G1.to_affine(zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars).wait()), O.G1.to_affine(want))
+        assert lib.mi355zk_bases_cache_info(bases.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 1
+        assert d.value == n * 64, (k, d.value)                               # the vector ONCE over all devices, in k slices
+        zk.unpin_bases(bases)
+        assert lib.mi355zk_bases_cache_info(bases.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 0
+    # density map: the cells' slices follow the prefix popcounts and add up to the consumed bases
+    rng = np.random.default_rng(4603)
+    bits = rng.random(n) < 0.5
+    m = int(bits.sum())
+    dm = zk.DensityTracker.from_bools(bits)
+    rc, want = O.G1.multiexp(bases[:m], scalars, density=GU.density_words(bits), density_bits=n, threads=4)
+    assert rc == 0
+    w = multi(4)
+    b = np.ascontiguousarray(bases[:m])
+    zk.pin_bases(b)
+    assert np.array_equal(O.G1.to_affine(zk.multiexp(w, (b, 0), dm, scalars).wait()), O.G1.to_affine(want))
+    assert lib.mi355zk_bases_cache_info(b.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 1 and d.value == m * 64
+    zk.unpin_bases(None)
