@@ -291,7 +291,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       lds_store(lds, plane, ic, c);
       lds_store(lds, plane, id, d);
     }
+#ifdef ZK_NTT_X_NOBAR   // TIMING EXPERIMENT ONLY (wrong results): what would the pass cost without the barriers behind the first three stage pairs?
+    if constexpr (s >= 6) __syncthreads();
+#else
     __syncthreads();
+#endif
   });
   } else {
   // radix-2 stages (short transforms run narrow tiles, at least 256 of them: a pass is latency-bound there, and two independent
@@ -367,6 +371,172 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     const FrU prod = tw_mul(v, w);                                         // v < 30p, limbs < 4*2^29: < 2p
     gstore(out + go, u_to_std_lt2p(prod));
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the radix-4 pass with WAVE-LOCAL stage pairs (full tiles: G * np = 2048 or 4096 elements, a lane per group of four).
+// Same arithmetic per element as ntt_pass_kernel<LOG_NP, true> above (same butterflies, same skipped twiddle-one products, hence the
+// same value bounds and the same bytes); what changes is WHICH lane runs which group and how the lanes wait for one another:
+//   * lane q takes row g = q mod G and group index qf = q / G in EVERY stage pair (twiddle index j = qf mod m fastest).  A wave
+//     therefore owns 64 / G consecutive groups of every row, i.e. an aligned block of 256 / G elements per row, for as long as the
+//     groups of a stage pair span no more than that block: the hand-over from pair s to pair s + 2 then stays inside the wave -- the
+//     LDS executes a wave's writes and reads in order -- and needs NO workgroup barrier.  For the 2 x 1024 tiles of a 2^20 transform
+//     that removes the barriers behind pairs 0 and 2; with the two below, 2 barriers are left of 6.  (Measured before the rewrite, by
+//     deleting those barriers from the old kernel -- wrong results, right cost: 61.0 -> 58.6 us per pass.)
+//   * column passes load every lane's first group straight into registers: the elements of a group of pair 0 sit at bit-reversed
+//     positions 4 qf + k, i.e. they are the elements brev(k) * np / 4 + brev(qf) of the row -- rows of a column pass are strided in
+//     memory anyway, so these loads coalesce exactly like the old tile load (G adjacent 32-byte records per element index) -- and
+//     the tile's first LDS round trip and the barrier behind the load disappear.  The last pass (rows contiguous in memory) keeps
+//     the coalesced tile load through LDS.
+//   * the last stage pair leaves the lane with the elements j + r * np / 4 of its row in natural order: they are multiplied by the
+//     inter-pass twiddle / scale and stored from registers (G adjacent records per element index, as before): no closing LDS round
+//     trip and barrier either.
+// The twiddle-one skip of the old kernel's pair 1 / 2 relied on dealing the groups j-slowest; here a lane whose j is 0 still takes
+// the skipping branch (same arithmetic), its wave just does not save the time.
+// LDS positions: swizzle multiplier 13 and per-G row terms chosen with the bank model for THIS lane order (tools/ntt_lds_model.py).
+__device__ __forceinline__ uint32_t swz_wl(uint32_t x) { return x ^ ((((x >> 5) * 13u) ^ (x >> 10)) & 31u); }
+__device__ __forceinline__ uint32_t row_term_wl(uint32_t g, uint32_t G) { return (g * (G == 2 ? 26u : G == 4 ? 21u : 25u)) & 31u; }
+__device__ __forceinline__ void wave_handover() {
+  // the wave's LDS writes of this stage pair before its reads of the next: nothing for the hardware (in order per wave), an order for the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <uint32_t LOG_NP>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, NttPassParams P,
+                                                                 const UTab* __restrict__ roots, const UTab* __restrict__ twA,
+                                                                 const UTab* __restrict__ twB, const UTab* __restrict__ preA,
+                                                                 const UTab* __restrict__ preB, const UTab* __restrict__ postA,
+                                                                 const UTab* __restrict__ postB, TwU post_c, const UTab* __restrict__ twF) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  static_assert(LOG_NP >= 8, "full tiles of rows of at least 256 elements");
+  constexpr uint32_t np = 1u << LOG_NP;
+  constexpr uint32_t SKIP_MAX = LOG_NP > 10 ? 1 : 2;   // as in ntt_pass_kernel
+  constexpr uint32_t pitch = np;
+  constexpr uint32_t plane = 0;                         // (element-major tiles only)
+  const uint32_t G = P.g, log_g = 31u - (uint32_t)__clz(G);
+  const uint32_t elems = G * np;                        // == 4 * blockDim.x
+  uint64_t tile = blockIdx.x;
+  if (P.xcd_pair == 1) tile = (tile & ~15ull) | ((tile & 7ull) << 1) | ((tile >> 3) & 1ull);
+  else if (P.xcd_pair == 5) tile = (tile & ~255ull) | ((tile & 7ull) << 5) | ((tile >> 3) & 31ull);
+  const uint64_t hi = tile / P.tiles_lo, lo = tile % P.tiles_lo;
+  const uint64_t in_base = hi * P.in_hi_stride + lo * P.in_lo_stride;
+  const uint64_t out_base = hi * P.out_hi_stride + lo * P.out_lo_stride;
+  const uint32_t q = threadIdx.x;
+  // (a wave whose lanes share ONE row would own 256 elements of it and need one barrier less -- but its loads and stores are then lone
+  // 32-byte records, the neighbour column's record going to another wave: measured 0.117 -> 0.139 ms at 2^20, 1.96 -> 2.66 ms at 2^24)
+  const uint32_t g = q & (G - 1u), qf = q >> log_g;    // row, group index (qf < np / 4)
+  const uint32_t own = 256u / G;                        // elements of a row a wave owns
+  const uint32_t row = g * pitch, rx = row_term_wl(g, G);
+  auto at = [&](uint32_t x) __attribute__((always_inline)) { return row + (swz_wl(x) ^ rx); };
+
+  auto fetch = [&](uint64_t gi) __attribute__((always_inline)) {                       // one element of the tile from memory: < 2p, N
+    FrU v = u_from_std(gload(in + gi));
+    if (P.pre) {                                        // distribute_powers (domain.rs:176-189)
+      v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));
+      v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));
+    }
+    return v;
+  };
+  // (the butterfly of ntt_pass_kernel, bounds noted there)
+  auto bf = [&](auto stc, FrU& u, FrU& t, const TwU& w, bool skip) __attribute__((always_inline)) {
+    constexpr uint32_t ST = (uint32_t) decltype(stc)::value;
+    if (!skip) t = tw_mul(t, w);
+    else t = u_carry(t);
+    FrU sum = u_add(u, t);
+    if constexpr ((ST & 3) == 3) sum = u_carry(sum);
+    FrU dif;
+    if constexpr (ST == 1) dif = skip ? u_sub<4, 1>(u, t) : u_sub<2, 1>(u, t);
+    else if constexpr (ST == 2) dif = skip ? u_sub<8, 1>(u, t) : u_sub<2, 1>(u, t);
+    else dif = u_sub<2, 1>(u, t);
+    u = sum;
+    t = dif;
+  };
+  // element k of row g leaves the tile: the closing product (inter-pass twiddle, or the post scale) and the store
+  auto emit = [&](uint32_t k, const FrU& v_in) __attribute__((always_inline)) {
+    FrU v = v_in;                                       // < 30p, limbs < 4*2^29
+    const uint64_t go = out_base + k * P.out_xs + g * P.out_gs;
+    TwU w;
+    if (P.tw_full) {
+      w = tab_load(twF + go);
+    } else if (P.tw_mul != 0) {
+      const uint64_t ex = P.tw_mul * k * (lo * G + g);
+      v = tw_mul(v, tab_load(twA + (ex >> P.tw_h)));
+      w = tab_load(twB + (ex & ((1ull << P.tw_h) - 1)));
+    } else if (P.post == 2) {
+      v = tw_mul(v, tab_load(postA + (go >> P.post_h)));
+      v = tw_mul(v, tab_load(postB + (go & ((1ull << P.post_h) - 1))));
+      w = post_c;
+    } else if (P.post == 3) {
+      gstore(out + go, u_to_std_lt32p(u_carry(v)));
+      return;
+    } else {
+      w = post_c;
+    }
+    gstore(out + go, u_to_std_lt2p(tw_mul(v, w)));
+  };
+
+  constexpr uint32_t S0 = LOG_NP & 1;
+  FrU a, b, c, d;
+  const bool direct = S0 == 0 && !P.load_x_fastest;    // (uniform)
+  if (direct) {
+    const uint32_t xr = bitrev(qf, LOG_NP - 2);         // element index = brev2(k) * np / 4 + brev(qf)
+    a = fetch(in_base + (uint64_t)(xr) * P.in_xs + g * P.in_gs);
+    b = fetch(in_base + (uint64_t)(xr + 2u * (np >> 2)) * P.in_xs + g * P.in_gs);   // k = 1 -> brev2 = 2
+    c = fetch(in_base + (uint64_t)(xr + 1u * (np >> 2)) * P.in_xs + g * P.in_gs);   // k = 2 -> brev2 = 1
+    d = fetch(in_base + (uint64_t)(xr + 3u * (np >> 2)) * P.in_xs + g * P.in_gs);
+  } else {
+    for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
+      uint32_t x, gg;
+      if (P.load_x_fastest) { x = e & (np - 1); gg = e >> LOG_NP; }
+      else { gg = e & (G - 1u); x = e >> log_g; }
+      const uint64_t gi = in_base + x * P.in_xs + gg * P.in_gs;
+      lds_store(lds, plane, gg * pitch + (swz_wl(bitrev(x, LOG_NP)) ^ row_term_wl(gg, G)), fetch(gi));
+    }
+    __syncthreads();
+    if constexpr (S0 == 1) {                           // stage 0 alone (all twiddles one): two butterflies per lane, neighbours in the row
+      const uint32_t x0 = qf << 2;
+      a = lds_load(lds, plane, at(x0)); b = lds_load(lds, plane, at(x0 + 1)); c = lds_load(lds, plane, at(x0 + 2)); d = lds_load(lds, plane, at(x0 + 3));
+      bf(std::integral_constant<int, 0>{}, a, b, TwU{a, a}, true);
+      bf(std::integral_constant<int, 0>{}, c, d, TwU{a, a}, true);
+      lds_store(lds, plane, at(x0), a); lds_store(lds, plane, at(x0 + 1), b); lds_store(lds, plane, at(x0 + 2), c); lds_store(lds, plane, at(x0 + 3), d);
+      // pair 1 takes groups of 8 elements = two of these lanes' quadruples: inside the wave while it owns >= 8 elements per row
+      if (8u <= own) wave_handover(); else __syncthreads();
+    }
+  }
+  for_limbs<(int)(LOG_NP / 2)>([&](auto pc) {
+    constexpr uint32_t s = S0 + 2u * (uint32_t) decltype(pc)::value;
+    constexpr uint32_t m = 1u << s;
+    constexpr bool first = decltype(pc)::value == 0, last = s + 2 == LOG_NP;
+    const uint32_t j = qf & (m - 1), x0 = ((qf >> s) << (s + 2)) + j;
+    const uint32_t ia = at(x0), ib = at(x0 + m), ic = at(x0 + 2 * m), id = at(x0 + 3 * m);
+    if (!(first && direct)) { a = lds_load(lds, plane, ia); b = lds_load(lds, plane, ib); c = lds_load(lds, plane, ic); d = lds_load(lds, plane, id); }
+    const bool one = s <= SKIP_MAX && j == 0;
+    {
+      TwU w1{a, a};
+      if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));
+      bf(std::integral_constant<int, (int)s>{}, a, b, w1, one);
+      bf(std::integral_constant<int, (int)s>{}, c, d, w1, one);
+    }
+    const bool one2 = s + 1 <= SKIP_MAX && j == 0;
+    {
+      TwU w2{a, a};
+      if (!one2) w2 = tab_load(roots + ((uint64_t)j << (LOG_NP - 2 - s)));
+      bf(std::integral_constant<int, (int)s + 1>{}, a, c, w2, one2);
+    }
+    {
+      const TwU w3 = tab_load(roots + ((uint64_t)(j + m) << (LOG_NP - 2 - s)));
+      bf(std::integral_constant<int, (int)s + 1>{}, b, d, w3, false);
+    }
+    if constexpr (!last) {
+      lds_store(lds, plane, ia, a); lds_store(lds, plane, ib, b); lds_store(lds, plane, ic, c); lds_store(lds, plane, id, d);
+      // the next pair's groups span 16 m elements of a row; the wave owns 256 / G of them
+      if (16u * m <= own) wave_handover(); else __syncthreads();
+    } else {
+      emit(x0, a); emit(x0 + m, b); emit(x0 + 2 * m, c); emit(x0 + 3 * m, d);   // (last pair: x0 == j == qf)
+    }
+  });
 }
 
 // tab[j] = base^(j * step): the plain integer and its quotient (UTab)
@@ -542,6 +712,11 @@ int ntt_configure() {
   ZK_NTT_FN(1) ZK_NTT_FN(2) ZK_NTT_FN(3) ZK_NTT_FN(4) ZK_NTT_FN(5) ZK_NTT_FN(6) ZK_NTT_FN(7) ZK_NTT_FN(8) ZK_NTT_FN(9) ZK_NTT_FN(10)
   ZK_NTT_FN(11) ZK_NTT_FN(12)
 #undef ZK_NTT_FN
+  const void* wl[5] = {reinterpret_cast<const void*>(ntt_pass_wl_kernel<8>), reinterpret_cast<const void*>(ntt_pass_wl_kernel<9>),
+                       reinterpret_cast<const void*>(ntt_pass_wl_kernel<10>), reinterpret_cast<const void*>(ntt_pass_wl_kernel<11>),
+                       reinterpret_cast<const void*>(ntt_pass_wl_kernel<12>)};
+  for (const void* f : wl)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) rc = ZK_ERR_DEVICE;
   for (int l = 1; l <= 2 * NTT_MAX_LOG_NP; ++l) {
     hipError_t e = hipFuncSetAttribute(fns[l], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -753,6 +928,21 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       if (threads > NTT_THREADS) threads = NTT_THREADS;
       if (threads < 64) threads = 64;
     }
+    // full tiles of rows of >= 256 elements: the wave-local kernel (round 5; env MI355ZK_NTT_WAVELOCAL=0: the barrier-per-pair kernel, for the A/B)
+    static const bool no_wl = std::getenv("MI355ZK_NTT_WAVELOCAL") != nullptr && std::getenv("MI355ZK_NTT_WAVELOCAL")[0] == '0';
+    const bool wl_kernel = r4 && !no_wl && b[p] >= 8 && (uint64_t)P.g * np == 4ull * threads;
+#define ZK_NTT_LAUNCH_WL(L)                                                                                                                \
+  case L:                                                                                                                                  \
+    hipLaunchKernelGGL((ntt_pass_wl_kernel<L>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A,      \
+                       T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,    \
+                       post_cu, T->full);                                                                                                  \
+    break;
+    if (wl_kernel) {
+      switch (b[p]) {
+        ZK_NTT_LAUNCH_WL(8) ZK_NTT_LAUNCH_WL(9) ZK_NTT_LAUNCH_WL(10) ZK_NTT_LAUNCH_WL(11) ZK_NTT_LAUNCH_WL(12)
+        default: return ZK_ERR_BAD_ARGS;
+      }
+    } else {
 #define ZK_NTT_LAUNCH(L)                                                                                                                   \
   case L:                                                                                                                                  \
     if (r4)                                                                                                                                \
@@ -769,7 +959,9 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       ZK_NTT_LAUNCH(9) ZK_NTT_LAUNCH(10) ZK_NTT_LAUNCH(11) ZK_NTT_LAUNCH(12)
       default: return ZK_ERR_BAD_ARGS;
     }
+    }
 #undef ZK_NTT_LAUNCH
+#undef ZK_NTT_LAUNCH_WL
     ZK_HIP(hipGetLastError());
     prof_end(slot_pass, st);
   }

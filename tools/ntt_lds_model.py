@@ -14,7 +14,12 @@ group of 32 lane-dwords takes as many cycles as its most loaded bank has DISTINC
                row term separates neighbouring rows where lanes alternate rows; found by searching multipliers and row terms over every tile shape
                the planner uses (table below: what is left is the eight-row tile of 2^24 and the short radix-2 rows)
 
-usage: python tools/ntt_lds_model.py            (all tile shapes, both layouts)"""
+  round 5, wave-local kernel (ntt_pass_wl_kernel: full tiles, lane q = row q mod G, group q / G in every stage pair):
+            position(g, x) = g * np + ((x ^ ((((x >> 5) * 13) ^ (x >> 10)) & 31)) ^ ((g * a_G) & 31)),  a_2 = 26, a_4 = 21, a_8 = 25
+            -- chosen by the same search for THAT lane order: in a wave's 32-lane group the varying index bits are (row, a few bits of the group
+               index); multiplier and row term must make them independent modulo 32 banks in every stage pair (second table below)
+
+usage: python tools/ntt_lds_model.py            (all tile shapes, both layouts; then the wave-local kernel's shapes)"""
 import sys
 
 def brev(x, bits): return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
@@ -108,3 +113,50 @@ for name, log_np, G, threads, r4, lxf in SHAPES:
     if "-v" in sys.argv:
         for layout in LAYOUTS:
             print(f"   {layout}:"); model(log_np, G, threads, r4, layout, lxf, verbose=True)
+
+
+# ---- the wave-local kernel (ntt_pass_wl_kernel)
+def model_wl(log_np, G, column_pass):
+    np_ = 1 << log_np
+    threads = G * np_ // 4
+    a = {1: 0, 2: 26, 4: 21, 8: 25}[G]
+    pos = lambda g, x: g * np_ + ((x ^ ((((x >> 5) * 13) ^ (x >> 10)) & 31)) ^ ((g * a) & 31))
+    def cost(idx, l):
+        c = 0
+        for half in range(0, len(idx), 32):
+            banks = {}
+            for lane in range(half, half + 32):
+                ad = 9 * idx[lane] + l
+                banks.setdefault(ad & 31, set()).add(ad)
+            c += max(len(v) for v in banks.values())
+        return c
+    ideal = cyc = 0
+    def site(idx_fn, count, weight):
+        nonlocal ideal, cyc
+        for w0 in range(0, count, 64):
+            idx = [idx_fn(w0 + i) for i in range(64)]
+            for l in range(9):
+                cyc += weight * cost(idx, l); ideal += weight * 2
+    s0 = log_np & 1
+    direct = column_pass and not s0
+    if not direct:   # tile load through LDS (last pass: x fastest; odd row lengths)
+        site((lambda e: pos(e >> log_np, brev(e & (np_ - 1), log_np))) if not column_pass else (lambda e: pos(e % G, brev(e // G, log_np))), G * np_, 1)
+    if s0:
+        for r in range(4): site(lambda q, r=r: pos(q % G, 4 * (q // G) + r), threads, 2)
+    rounds = list(range(s0, log_np, 2))
+    for s in rounds:
+        m = 1 << s
+        w = 2
+        if s == rounds[0] and direct: w -= 1    # first pair: operands come from memory
+        if s == rounds[-1]: w -= 1              # last pair: results go to memory
+        for r in range(4):
+            site(lambda q, r=r, s=s, m=m: pos(q % G, (((q // G) >> s) << (s + 2)) + ((q // G) & (m - 1)) + r * m), threads, w)
+    return ideal, cyc
+print()
+for name, log_np, G in (("2^20: 2 x 2^10", 10, 2), ("2^16 .. 2^19: 4 x 2^10", 10, 4), ("2^21 / 2^22: 2^11 rows", 11, 1), ("2^23: 2^12 rows", 12, 1), ("2^24: 8 x 2^8", 8, 8),
+                        ("2^25 / 2^26: 4 x 2^9", 9, 4)):
+    out = []
+    for col in (1, 0):
+        ti, tc = model_wl(log_np, G, col)
+        out.append(f"{'column pass' if col else 'last pass'}: {100 * (tc - ti) / tc:5.1f} %")
+    print(f"{name:28s} wave-local kernel   " + "   ".join(out))
