@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
     const bool one = s <= SKIP_MAX && j == 0;
     {
       TwU w1{a, a};
-      if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));
+      if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));   // (requesting it before the hand-over, to run under the wait: measured, nothing)
       bf(std::integral_constant<int, (int)s>{}, a, b, w1, one);
       bf(std::integral_constant<int, (int)s>{}, c, d, w1, one);
     }
