@@ -67,8 +67,15 @@ struct ProfSlot {
     hipEvent_t a, b;
   };
   std::vector<Pair> pending;
-  hipEvent_t open = nullptr;
-  int open_dev = -1;
+  // the begin events waiting for their end, keyed by the STREAM they were recorded on: several host threads run msm_device at once (the
+  // cells of the multi-GPU mode, the prover's eight multiexps), each on its own stream -- one `open` per slot paired thread A's end with
+  // thread B's begin
+  struct Open {
+    hipStream_t st;
+    hipEvent_t e;
+    int dev;
+  };
+  std::vector<Open> open;
 };
 std::mutex g_prof_mu;
 std::vector<ProfSlot> g_prof;
@@ -109,24 +116,32 @@ void prof_begin(int slot, hipStream_t st) {
   hipEvent_t e = prof_event(&dev);
   if (e == nullptr) return;
   (void)hipEventRecord(e, st);
-  if (g_prof[slot].open) g_prof_free[g_prof[slot].open_dev].push_back(g_prof[slot].open);   // (a begin without its end: several host threads on one slot)
-  g_prof[slot].open = e;
-  g_prof[slot].open_dev = dev;
+  for (auto& o : g_prof[slot].open)
+    if (o.st == st) {                     // (a begin without its end on this stream: an error path)
+      g_prof_free[o.dev].push_back(o.e);
+      o.e = e;
+      o.dev = dev;
+      return;
+    }
+  g_prof[slot].open.push_back(ProfSlot::Open{st, e, dev});
 }
 void prof_end(int slot, hipStream_t st) {
   if (g_prof_on == 0 || (g_prof_on == 2 && slot != g_prof_only)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof[slot].open) return;
+  auto& open = g_prof[slot].open;
+  size_t k = 0;
+  while (k < open.size() && open[k].st != st) ++k;
+  if (k == open.size()) return;
   int dev = 0;
   hipEvent_t e = prof_event(&dev);
   if (e == nullptr) return;
-  if (dev != g_prof[slot].open_dev) {   // the pair must be on one device
+  if (dev != open[k].dev) {             // the pair must be on one device
     g_prof_free[dev].push_back(e);
     return;
   }
   (void)hipEventRecord(e, st);
-  g_prof[slot].pending.push_back(ProfSlot::Pair{dev, g_prof[slot].open, e});
-  g_prof[slot].open = nullptr;
+  g_prof[slot].pending.push_back(ProfSlot::Pair{dev, open[k].e, e});
+  open.erase(open.begin() + (long)k);
 }
 void prof_collect() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -1966,7 +1981,7 @@ int msm_host_entry(const uint8_t* bases, size_t n_bases, size_t base_offset, con
 // and H times delta^-1) and powersoftau's `batch_exp` (batched_accumulator.rs:1130-1181) are to a single-process caller.  The points are
 // independent, so they shard by CONTIGUOUS POINT RANGE with no exchange at all (shard.batch_exp_sharded is the
 // one-process-per-GPU form): device d of mi355zk_init's set takes range d -- upload, the batch_exp kernels, download -- from its own
-// host thread; with one device the whole vector is one range.  Ranges are worked off in pieces of 2^22 points (a piece's buffers
+// host thread; with one device the whole vector is one range.  Ranges are worked off in pieces of 2^18 points (a piece's buffers
 // come from the grow-only pool, so a 2^26-point vector does not allocate 10 GiB).  g2_trusted: the promise flag of batch_exp_dev.
 template <class F>
 int batch_exp_host(uint8_t* out, const uint8_t* bases, const uint64_t* scalars, size_t n, int same_scalar, bool g2_trusted) {
@@ -2111,7 +2126,10 @@ int dense_host(const uint8_t* v1, const uint8_t* v2, const uint64_t* rho, size_t
       // power_pairs (utils.rs:133-135) is merge_pairs(v[0 .. n-1], v[1 .. n]): the two vectors are ONE array seen at two offsets, and
       // uploading it twice would double the PCIe traffic of a call the link already bounds -- a v2 that starts `shift` (<= 16)
       // records into v1 shares v1's upload
-      const size_t shift = (v2 && v2 >= v1 && (size_t)(v2 - v1) % rec == 0 && (size_t)(v2 - v1) / rec <= 16) ? (size_t)(v2 - v1) / rec : (size_t)-1;
+      // (the addresses are compared as integers -- the two pointers need not belong to one array -- and the vectors must really overlap:
+      // shift <= n; two separate short arrays that happen to sit within 16 records of each other are uploaded separately: ADVICE r4)
+      const uintptr_t a1 = (uintptr_t)v1, a2 = (uintptr_t)v2;
+      const size_t shift = (v2 && a2 >= a1 && (a2 - a1) % rec == 0 && (a2 - a1) / rec <= 16 && (a2 - a1) / rec <= n) ? (size_t)((a2 - a1) / rec) : (size_t)-1;
       const bool shared = shift != (size_t)-1;
       char* d_v2 = v2 ? (shared ? d_v1 + shift * rec : d_v1 + vb) : nullptr;
       char* d_rho = d_v1 + (v2 ? 2 : 1) * vb;

@@ -291,11 +291,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
       lds_store(lds, plane, ic, c);
       lds_store(lds, plane, id, d);
     }
-#ifdef ZK_NTT_X_NOBAR   // TIMING EXPERIMENT ONLY (wrong results): what would the pass cost without the barriers behind the first three stage pairs?
-    if constexpr (s >= 6) __syncthreads();
-#else
     __syncthreads();
-#endif
   });
   } else {
   // radix-2 stages (short transforms run narrow tiles, at least 256 of them: a pass is latency-bound there, and two independent
