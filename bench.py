@@ -732,8 +732,23 @@ def main() -> int:
         # parity of the GPU path on the same sample (affine-normalised, bit exact)
         got = zk.multiexp(worker, (bases[:ns], 0), zk.FullDensity(), scalars[:ns]).wait()
         ok = bool(np.array_equal(O.G1.to_affine(got), O.G1.to_affine(ref)))
+        # the same sample at the window width bellman picks at the HEADLINE size (c = ceil(ln 2^26) = 19, 14 windows = 14 busy threads,
+        # multiexp.rs:341-345,75): the reference's shape at the metric's size, on a sample the oracle finishes in seconds
+        at_metric = None
+        c_metric = O.multiexp_window_bits(n_total) if n_total < (1 << 32) else 19
+        if c_metric != c_ref:
+            O.multiexp_set_window_bits(c_metric)
+            try:
+                w_m = (254 + c_metric - 1) // c_metric
+                t2 = time.perf_counter()
+                rc_m, ref_m = O.G1.multiexp(hb, hs, threads=min(cores, w_m))
+                dt_m = time.perf_counter() - t2
+            finally:
+                O.multiexp_set_window_bits(0)
+            at_metric = {"window_bits": c_metric, "windows": w_m, "threads": min(cores, w_m), "Mscalar_mul_per_s": round(ns / dt_m / 1e6, 4),
+                         "seconds": round(dt_m, 2), "same_point": bool(rc_m == 0 and np.array_equal(O.G1.to_affine(ref_m), O.G1.to_affine(ref)))}
         out["cpu_baseline"] = {"value": round(ns / dt / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "threads": threads, "host_cores": cores,
-                               "kind": "port",
+                               "kind": "port", "at_the_metric_size_window": at_metric,
                                "sample": "first 2^%d points of the same input, oracle restatement of bellman_ce multiexp "
                                          "(c=%d, one thread per window, %d windows), %.2f s" % (int(np.log2(ns)), c_ref, windows, dt),
                                "gpu_matches_oracle_on_sample": ok}

@@ -84,6 +84,8 @@
 #undef F_SQR
 #undef F_INV
 
+/* bench-only window width override for the BN254 multiexp instances (0 = the reference's rule) */
+static uint32_t oracle_window_override = 0;
 /* ------------------------------------------------------------------ multiexp: G1, G2 */
 #define MNAME(x) g1m_##x
 #define M_AFFINE g1_affine_t
@@ -95,7 +97,9 @@
 #define M_DOUBLE(p) g1_double(p)
 #define M_SCALAR_LIMBS 4
 #define M_NUM_BITS 254
+#define ORACLE_WINDOW_OVERRIDE oracle_window_override
 #include "tmpl_multiexp.h"
+#undef ORACLE_WINDOW_OVERRIDE
 #undef MNAME
 #undef M_AFFINE
 #undef M_PROJ
@@ -117,7 +121,9 @@
 #define M_DOUBLE(p) g2_double(p)
 #define M_SCALAR_LIMBS 4
 #define M_NUM_BITS 254
+#define ORACLE_WINDOW_OVERRIDE oracle_window_override
 #include "tmpl_multiexp.h"
+#undef ORACLE_WINDOW_OVERRIDE
 #undef MNAME
 #undef M_AFFINE
 #undef M_PROJ
@@ -346,6 +352,8 @@ EXPORT int oracle_g2_multiexp(const uint64_t *bases, size_t n_bases, size_t base
   return rc;
 }
 EXPORT uint32_t oracle_multiexp_window_bits(size_t n_scalars) { return g1m_choose_c(n_scalars); }
+/* BENCH ONLY: force the window width of the BN254 multiexps (0 = back to the reference's rule ceil(ln n), multiexp.rs:341-345) */
+EXPORT void oracle_multiexp_set_window_bits(uint32_t c) { oracle_window_override = c; }
 
 /* powersoftau::utils::dense_multiexp (powersoftau/src/utils.rs:189-292); `cpus` = num_cpus::get() */
 EXPORT void oracle_g1_dense_multiexp(const uint64_t *bases, const uint64_t *scalars, size_t n, int cpus, uint64_t out_xyz[12]) {

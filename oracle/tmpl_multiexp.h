@@ -100,6 +100,11 @@ static int MNAME(window)(const M_AFFINE *bases, size_t n_bases, size_t base_offs
 
 /* multiexp.rs:341-345 */
 static inline uint32_t MNAME(choose_c)(size_t n) {
+#ifdef ORACLE_WINDOW_OVERRIDE
+  /* BENCH ONLY (oracle_multiexp_set_window_bits): the width the reference would pick at ANOTHER size -- the 2^26 headline's c = 19 timed
+   * on a 2^22 sample; 0 = the reference's rule below */
+  if (ORACLE_WINDOW_OVERRIDE) return ORACLE_WINDOW_OVERRIDE;
+#endif
   if (n < 32) return 3;
   return (uint32_t)ceil(log((double)(uint32_t)n));
 }

@@ -253,6 +253,11 @@ def point_domain_op(group: int, affine_pts, log_n: int, op: str, log_cpus: int =
     return np.stack([G.to_affine(p) for p in jac.reshape(-1, G.jac)])
 
 
+def multiexp_set_window_bits(c: int):
+    """BENCH ONLY: force the window width of the BN254 multiexps (0: the reference's rule) -- the 2^26 headline's c = 19 on a 2^22 sample"""
+    lib().oracle_multiexp_set_window_bits(C.c_uint32(c))
+
+
 def multiexp_window_bits(n):
     return int(lib().oracle_multiexp_window_bits(C.c_size_t(n)))
 

@@ -931,3 +931,59 @@ def test_pair_and_lane_kernels_agree(group):
     for k in res["0"]:
         assert res["0"][k] == res["1"][k], k
     assert "123" in res["0"]["identity"]
+
+
+_HEAVY_PAST_REACH = r'''
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import phase2_bn254_amd as zk, inputs, bench, bn254_model as M, oracle_lib as O
+L = zk.lib.load(); w = zk.Worker(0); dev = torch.device("cuda", 0)
+n = 1 << 20
+g = np.zeros(5 + 128, np.uint32)
+assert L.mi355zk_selftest_msm_digits(n, 1, None, 0, 0, 0, None, g.ctypes.data) == 0
+c, W, nb, rmul = (int(x) for x in g[:4])
+assert c == 14 and rmul == 1 and W * nb <= (1 << 18), (c, W, nb, rmul)      # the split launch is on: <= 2^18 buckets over all windows
+width = [int(x) for x in g[5:5 + W]]; shift = [int(x) for x in g[5 + W:5 + 2 * W]]
+rng = np.random.default_rng(9101)
+HOT = 3686                                   # 45 % of a window's 8192 buckets; 19 x 3686 = 70 034 hot buckets of 2^20 / 3686 = 284 entries each
+limbs = np.zeros((n, 4), np.uint64)
+for wd, sh in zip(width, shift):
+    hot = rng.choice(np.arange(1, (1 << (wd - 1)) - 1, dtype=np.uint64), size=min(HOT, (1 << (wd - 1)) - 2), replace=False)   # positive digits below the sign boundary: no carries
+    d = hot[rng.permutation(n) % len(hot)]     # every hot digit exactly n / 3686 = 284 or 285 times: all of them over the threshold
+    li, off = sh // 64, sh % 64
+    limbs[:, li] |= d << np.uint64(off)
+    if off + wd > 64: limbs[:, li + 1] |= d >> np.uint64(64 - off)
+scalars = torch.from_numpy(limbs.view(np.int64)).to(dev)
+k = bench.gen_scalars(n, 9102, dev)
+bases = torch.empty((n, 8), dtype=torch.int64, device=dev)
+gen = np.ascontiguousarray(inputs.G1_GEN_RAW)
+assert L.mi355zk_bn254_g1_batch_mul_dev(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+torch.cuda.synchronize()
+got = zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars).wait()
+os.environ["MI355ZK_MSM_SPLIT"] = "0"        # (read per call) the lane-per-bucket launch alone
+plain = zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars).wait()
+to_int = lambda a: sum(a[:, i].astype(object) << (64 * i) for i in range(4))
+dot = int(sum(s * kk for s, kk in zip(to_int(limbs), to_int(k.cpu().numpy().view(np.uint64)))) % M.R_ORDER)
+want = O.G1.to_affine(O.G1.mul(O.G1.from_affine(inputs.G1_GEN_RAW), M.to_limbs(dot)))
+print(json.dumps({"split": bool(np.array_equal(O.G1.to_affine(got), want)), "plain": bool(np.array_equal(O.G1.to_affine(plain), want))}))
+'''
+
+
+def test_more_over_long_buckets_than_the_heavy_path_reaches(zk, worker):
+    """ADVICE r4: with the quad-per-bucket launch active the lane-per-bucket launch skips EVERY bucket of order[0 .. max(split_hb, hb)) that is
+    longer than split_t; the segment-parallel path takes the over-long ones of order[0 .. hb) only, hb <= 65 536 -- an over-long bucket past
+    that reach was accumulated by nobody (round 4's library returns a wrong point for this input).  2^20 exponents at c = 14 (19 windows x 8192
+    buckets <= 2^18: the split launch is on) whose digits take 3686 values per window: 70 034 buckets of 284 entries against a heavy threshold of
+    274.  Closed form (bases k_i * G), with and without the split launch; a process of its own because MI355ZK_MSM_C is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MI355ZK_MSM_C="14")
+    env.pop("MI355ZK_MSM_SPLIT", None)
+    r = subprocess.run([sys.executable, "-c", _HEAVY_PAST_REACH], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and line, r.stderr[-800:]
+    assert json.loads(line[-1]) == {"split": True, "plain": True}
