@@ -124,8 +124,9 @@ gc.callbacks.append(_gc_cb)
 
 
 @contextlib.contextmanager
-def _no_gc():
-    gc.collect()
+def _no_gc(collect: bool = True):
+    if collect:
+        gc.collect()
     was = gc.isenabled()
     gc.disable()
     try:
@@ -135,10 +136,13 @@ def _no_gc():
             gc.enable()
 
 
-def _timed(fn, iters):
-    fn()
-    torch.cuda.synchronize()
-    with _no_gc():
+def _timed(fn, iters, collect: bool = True):
+    # (the collection -- tens of milliseconds with the GPU idle -- comes BEFORE the warm-up: a 0.12-ms transform timed right after it
+    # runs on clocks that have dropped; the first refresh of round 5 read the NTT 8 % slow that way)
+    with _no_gc(collect):
+        fn()
+        fn()
+        torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(iters):
             r = fn()
@@ -173,9 +177,11 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         # timed loop (~5 us each on a 60-us kernel) and timed `fft` first, on clocks that had just idled through the input
         # generation -- together 10-15 % on this 0.12-ms operation (tools/bench_ntt.py shows both effects).  The per-pass kernel time
         # for the roofline comes from a second, instrumented loop.
-        for _ in range(40):
+        gc.collect()
+        t_warm = time.perf_counter() + 0.04   # (40 ms of back-to-back transforms: the collection above left the GPU idle for ~50 ms, and 40 calls
+        while time.perf_counter() < t_warm:   #  = 5 ms did not bring the clocks back: ifft / coset_fft read 5-8 % slow behind it)
             getattr(dom, op)(worker)
-        dt, _ = _timed(lambda: getattr(dom, op)(worker), 40)
+        dt, _ = _timed(lambda: getattr(dom, op)(worker), 40, collect=False)
         ntt[op] = {"ms": round(dt * 1e3, 4), "Melem_per_s": round(n / dt / 1e6, 1)}
         if op == "fft":
             L.mi355zk_prof_reset()
@@ -236,10 +242,11 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         # spinning for a while after their last parallel region): a 2-ms call is ~27 kernel launches, and launches issued beside spinning
         # threads measured 0.2 ms per call slower with IDENTICAL kernel times (profiles/r04_final_bench_n1.json against bench_2e20.json)
         time.sleep(0.3)
+        gc.collect()   # (before the warm-up, not between it and the timed loop: see _timed)
         for _ in range(25 if group == 1 else 12):
             zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
         iters = 20 if group == 1 else 10
-        with _no_gc():
+        with _no_gc(collect=False):
             t = time.perf_counter()
             for _ in range(iters):
                 res = zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
@@ -263,10 +270,11 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         # windows) -- for vectors that do not change between calls, like the Parameters a prover queries; same affine point
         tb = zk.MsmTable(b)
         torch.cuda.synchronize()
+        gc.collect()
         for _ in range(25 if group == 1 else 12):      # the plain leg's warm-up
             zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
         calls = []
-        with _no_gc():
+        with _no_gc(collect=False):
             for _ in range(iters):
                 t = time.perf_counter()
                 res_t = zk.multiexp(worker, (tb, 0), zk.FullDensity(), sc).wait()
@@ -485,6 +493,7 @@ def main() -> int:
     # after 50).  Steps shorter than 20 ms therefore get extra UNTIMED settle steps worth 0.2 s (reported as "settle_steps");
     # the 2^26 headline (67 ms per step) gets none.
     settle_steps = 0
+    gc.collect()
     if args.warmup > 0 or args.steps > 0:
         t_probe = time.perf_counter()
         step()
@@ -512,7 +521,7 @@ def main() -> int:
         dist.barrier()
     torch.cuda.synchronize()
     result = None
-    with _no_gc():   # (the interpreter's collector off inside the timed region, as `timeit` runs: see _GC_LOG)
+    with _no_gc(collect=False):   # (the interpreter's collector off inside the timed region, as `timeit` runs: see _GC_LOG; collected before the warm-up)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             result = step()

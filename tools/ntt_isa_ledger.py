@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction ledger of ntt_pass_kernel<10, radix-4> (the pass of a 2^20 transform) from the gfx950 ISA hipcc emits:
+"""Static instruction ledger of ntt_pass_wl_kernel<10> (the pass of a 2^20 transform) from the gfx950 ISA hipcc emits:
    python tools/ntt_isa_ledger.py [-DZK_NTT_LDS_PLANES]
 Classes: products (v_mad_u64_u32 and the Montgomery glue that only products contain: v_mul_lo_u32, v_lshrrev_b64), limb masks / carries / packing
 (v_and, v_lshrrev_b32, v_lshl*, v_alignbit, v_or*), additions and subtractions (v_add*, v_sub*: butterflies, borrow constants AND address arithmetic -- the
@@ -13,7 +13,7 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
                        os.path.join(ROOT, "phase2-bn254_amd", "csrc", "ntt.hip")] + sys.argv[1:], stderr=subprocess.DEVNULL)
 body, on = [], False
 for line in open(out):
-    if re.match(r"^_ZN2zk12_GLOBAL__N_115ntt_pass_kernelILj10ELb1E.*:", line): on = True
+    if re.match(r"^_ZN2zk12_GLOBAL__N_118ntt_pass_wl_kernelILj10E.*:", line): on = True
     if on and ".amdhsa_kernel" in line: break
     if on: body.append(line)
 ops = collections.Counter(m.group(1) for l in body for m in [re.match(r"^\s+((?:v|s|ds|global|buffer|scratch)_[a-z0-9_]+)", l)] if m)
@@ -29,8 +29,8 @@ def cls(op):
     return "other VALU"
 led = collections.Counter()
 for op, c in ops.items(): led[cls(op)] += c
-vgpr = next((l.split(",")[-1].strip() for l in open(out) if "ntt_pass_kernelILj10ELb1E" in l and ".num_vgpr" in l), "?")
-print(f"# ntt_pass_kernel<10, radix-4>, gfx950, flags {sys.argv[1:] or '(default: element-major LDS tiles)'}: {vgpr} VGPRs, {sum(ops.values())} instructions (static)")
+vgpr = next((l.split(",")[-1].strip() for l in open(out) if "ntt_pass_wl_kernelILj10E" in l and ".num_vgpr" in l), "?")
+print(f"# ntt_pass_wl_kernel<10>, gfx950, flags {sys.argv[1:] or '(default: element-major LDS tiles)'}: {vgpr} VGPRs, {sum(ops.values())} instructions (static)")
 for k, v in led.most_common(): print(f"{v:7d}  {k}")
 print("# by opcode:")
 for op, c in ops.most_common(28): print(f"{c:7d}  {op}")

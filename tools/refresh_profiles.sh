@@ -30,7 +30,7 @@ for ln in 16 20 24; do timeout 300 python $R/tools/bench_ntt.py --log-n $ln; don
 for ln in 12 14 18 19 21 22 23 25 26 28; do timeout 300 python $R/tools/bench_ntt.py --log-n $ln; done > $O/ntt_other_sizes.json 2>/dev/null
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAIT_ANY -d /tmp/p_ns1 -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d /tmp/p_ns2 -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
-{ python $R/tools/pmc_kernel.py $(find /tmp/p_ns1 -name "*.db" | head -1) ntt_pass_kernel; python $R/tools/pmc_kernel.py $(find /tmp/p_ns2 -name "*.db" | head -1) ntt_pass_kernel; } > $O/ntt20_pass_sq_pmc.txt 2>&1
+{ python $R/tools/pmc_kernel.py $(find /tmp/p_ns1 -name "*.db" | head -1) ntt_pass_; python $R/tools/pmc_kernel.py $(find /tmp/p_ns2 -name "*.db" | head -1) ntt_pass_; } > $O/ntt20_pass_sq_pmc.txt 2>&1
 rm -rf /tmp/p_nf /tmp/p_nw
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_nf -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_nw -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1

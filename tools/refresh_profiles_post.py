@@ -20,7 +20,7 @@ put("msm26_kernel_stats.txt", "msm26_kernel_stats.txt",
     "# summarised from the rocpd database with tools/rocpd_summary.py (ROCm 7.2 rocprofv3 writes rocpd; same numbers as --stats)\n"
     "# batch_exp_kernel = synthetic-input generation (outside the timed region); every msm_* launch is a full-size step\n"
     "# (1 warm-up + 3 timed + 2 of the linearity check); msm_accumulate_kernel is the dominant kernel of a step\n")
-put("ntt20_pass_sq_pmc.txt", "ntt20_pass_sq_pmc.txt", "# ntt_pass_kernel, 2^20 elements (2 passes of 1024-point rows, 512 tiles of 2 x 1024, two 512-lane workgroups per CU), per dispatch,\n# rocprofv3 --pmc (two passes of 8 / 7 counters), tools/bench_ntt.py --log-n 20; SQ cycle counters tick once per 4 clocks\n")
+put("ntt20_pass_sq_pmc.txt", "ntt20_pass_sq_pmc.txt", "# ntt_pass_wl_kernel<10> (round 5: the wave-local radix-4 pass), 2^20 elements (2 passes of 1024-point rows, 512 tiles of 2 x 1024, two 512-lane workgroups per CU), per dispatch,\n# rocprofv3 --pmc (two passes of 8 / 7 counters), tools/bench_ntt.py --log-n 20; SQ cycle counters tick once per 4 clocks\n")
 put("msm20_timeline.txt", "msm20_timeline.txt", "# rocprofv3 --kernel-trace -- python tools/trace_one_msm.py: the launches of ONE 2^20-point G1 multiexp in order (start offset, duration incl. the\n# profiler's serialisation, gap to the previous kernel); the host join (~0.09 ms) follows the last copy\n")
 put("ntt20_kernel_stats.txt", "ntt20_kernel_stats.txt", "# rocprofv3 --kernel-trace -- python tools/bench_ntt.py --check   (MI355X, 2^20 Fr NTT, 20 iterations x 4 ops)\n")
 put("msm26_accumulate_sq_pmc.txt", "msm26_accumulate_sq_pmc.txt", "# rocprofv3 --pmc SQ_* (one pass, 8 counters) on msm_accumulate_kernel<Fq>, 2^26 points, MI355X\n")
@@ -57,8 +57,8 @@ if os.path.exists(os.path.join(SRC, "ntt20_pmc_fetch.txt")):
                 "# consecutive lanes, the same streaming pattern.  Infinity-Cache hits are counted (32 MiB of data + the table fit its 256 MiB).\n")
         f.write(open(os.path.join(SRC, "ntt20_pmc_fetch.txt")).read())
         f.write("".join(l for l in open(os.path.join(SRC, "ntt20_pmc_write.txt")) if not l.startswith("kernel ")))
-    nf = counter("ntt20_pmc_fetch.txt", "zk::ntt_pass_kernel"); nw = counter("ntt20_pmc_write.txt", "zk::ntt_pass_kernel")
-    json.dump({"round": int(tag[1:3]), "workload_log_n": 20, "kernel": "ntt_pass_kernel<10, radix-4>", "FETCH_SIZE_KB_per_launch": nf, "WRITE_SIZE_KB_per_launch": nw,
+    nf = counter("ntt20_pmc_fetch.txt", "zk::ntt_pass_wl_kernel"); nw = counter("ntt20_pmc_write.txt", "zk::ntt_pass_wl_kernel")
+    json.dump({"round": int(tag[1:3]), "workload_log_n": 20, "kernel": "ntt_pass_wl_kernel<10>", "FETCH_SIZE_KB_per_launch": nf, "WRITE_SIZE_KB_per_launch": nw,
                "hbm_bytes_per_launch": int((2 * nf + nw) * 1024), "kernel_sources_sha": bench.ntt_sources_sha(),
                "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/bench_ntt.py --log-n 20 (profiles/{tag}_ntt20_pmc_hbm.txt), average of the "
                       "two passes of a transform; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the reads are coalesced streams, which gfx950's FETCH_SIZE tallies at half "
