@@ -290,3 +290,35 @@ def test_table_mode_is_exact_for_a_g2_point_outside_the_subgroup(zk, worker):
         assert np.array_equal(recs[w, 123], O.G2.to_affine(O.G2.mul(O.G2.from_affine(bad), k))), w
         if w < W - 1:
             shift += widths[w]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("same_scalar", [False, True])
+def test_plain_and_split_kernels_agree_on_subgroup_points_at_size(zk, worker, same_scalar):
+    """2^15 subgroup points (k_i * G2): the default (plain windows) and the promised (psi split) kernels return the same records, and both the
+    closed form (s_i k_i mod r) * G2 -- checked on every record through batch_mul of the generator, and on a sample against the oracle's mul."""
+    import torch
+
+    n = 1 << 15
+    import bench
+
+    dev = torch.device("cuda", 0)
+    k = bench.gen_scalars(n, 4801, dev)
+    s = bench.gen_scalars(1 if same_scalar else n, 4802, dev)
+    L = zk.lib.load()
+    gen = np.ascontiguousarray(inputs.G2_GEN_RAW)
+    pts = torch.empty((n, 16), dtype=torch.int64, device=dev)
+    assert L.mi355zk_bn254_g2_batch_mul_dev(C.c_void_p(pts.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n, None) == 0
+    plain = zk.ceremony.batch_exp(pts, s, same_scalar=same_scalar)
+    split = zk.ceremony.batch_exp(pts, s, same_scalar=same_scalar, trusted_subgroup=True)
+    assert torch.equal(plain, split)
+    to_int = lambda a: sum(a[:, i].astype(object) << (64 * i) for i in range(4))  # noqa: E731
+    hk, hs = to_int(k.cpu().numpy().view(np.uint64)), to_int(s.cpu().numpy().view(np.uint64))
+    prod = np.array([M.to_limbs(int(kk) * int(hs[0 if same_scalar else i]) % M.R_ORDER) for i, kk in enumerate(hk)], dtype=np.uint64)
+    want = torch.empty_like(pts)
+    d_prod = torch.from_numpy(prod.view(np.int64)).to(dev)
+    assert L.mi355zk_bn254_g2_batch_mul_dev(C.c_void_p(want.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(d_prod.data_ptr()), n, None) == 0
+    assert torch.equal(plain, want)
+    got = plain.cpu().numpy().view(np.uint64)
+    for i in (0, 1, n // 3, n - 1):
+        assert np.array_equal(got[i], O.G2.to_affine(O.G2.mul(O.G2.from_affine(inputs.G2_GEN_RAW), prod[i]))), i
