@@ -138,11 +138,22 @@ hand = [("`r04_exp_cu_mask.txt`", "`tools/exp_cu_mask.py`", "CU-masked side stre
         ("`r04_ab_split_pair.txt`", "`tools/ab_split.sh` on the final sources", "the quad-per-long-bucket launch on top of the pair kernels: still 1 - 4 % for G1 2^13 .. 2^15"),
         ("`r04_final_bench_n1_driver_style.json`", "`python bench.py` on a fresh box after the re-lock", "the line as the driver takes it: `roofline.traffic` filled from `latest_pmc.json` (same kernel sources), 1015 Mscalar-mul/s on that box"),
         ("`r04_host_entry_timeline.txt`, `r04_multi_device_2e26.json`", "mid-round copies of the files above", "kept: DESIGN cites them")]
+hand5 = [("`r05_g2_exact_cost.json`", "`tools/bench_next_rows.py` (from `r05_final_next_rows_2e20.json`)", "the price of the exact G2 defaults on honest data: default vs `MI355ZK_G2_TRUSTED_SUBGROUP`, batch_exp 1.38-1.45 x, sparse matvec 1.14 / 1.78 x, point ifft 1.05 x"),
+         ("`r05_table_mode_gc.txt`", "`python3 bench.py --gpus 1 --steps 20 --warmup 5` x 3, `tools/diag_table_calls.py`", "BENCH_r04's 3.24-ms G1 table-mode leg = one pause of the interpreter's cyclic GC inside 20 calls of 1.39 ms; per-call times, `host_gc`"),
+         ("`r05_ubench_fieldmul.txt`", "`tools/bin/ubench_fieldmul`", "field products: memory format 125, U-form 167, f64 (5 x 52-bit, `v_fma_f64`, parity-checked) 110-117 G products/s = 0.66-0.70 x the U-form: not ported"),
+         ("`r05_snop_ab.txt`", "`tools/build_nop_stripped.sh ntt msm_g1` + `tools/ab_snop.sh`", "the `s_nop 0` hipcc pads after every ZK_CHAIN_MAD pin, deleted from the assembly: accumulate 54.24 -> 53.83 ms, NTT 2^24 2.102 -> 2.090: < 1 %"),
+         ("`r05_ntt_lds_model.txt`, `r05_ntt_lds_layout_ab.txt`", "`tools/ntt_lds_model.py`; `tools/ab_ntt_layout.sh`", "bank model of every LDS access site of the NTT pass (reproduces round 4's 20 % conflict cycles) and the measured counters: SQ_LDS_BANK_CONFLICT 884 736 -> 0; the pass time did not move"),
+         ("`r05_ntt_warmup_ab.txt`", "`tools/bench_ntt.py --warm-ms 0 / 50`, `MI355ZK_NTT_WAVELOCAL=0 / 1`", "2^20 fft: barrier-per-pair kernel 0.124 / 0.1115 ms, wave-local kernel 0.1177 / 0.104 ms (5 ms / 50 ms of warm-up): the kernel change is 5-7 %, the rest was lukewarm clocks"),
+         ("`r05_short_calls.txt`", "`tools/diag_short_calls.py`", "short multiexps: wall, kernel groups, host join before / after the branch-free host field arithmetic (G2 join 241 -> 184 us)"),
+         ("`r05_multi_device_2e26.json`", "`tools/bench_multi_device.py --log-n 26 --devices 1 2 4 8`", "per-device cached base bytes = vector / N (slice residency), first call vs steady call, on one physical GPU"),
+         ("`r05_heavy_past_reach.txt`", "`tests/test_gpu_msm.py::test_more_over_long_buckets_than_the_heavy_path_reaches` on the round-4 and round-5 libraries", "the dropped over-long bucket of ADVICE r4: wrong point before, right now"),
+         ("`r05_fuzz_seed61.txt`", "`SEED=61 CASES=30 tools/fuzz_msm.sh`, `tools/fuzz_ntt.py --max-log 22`, `tools/fuzz_rows.py`", "1020 MSM + 150 NTT + 120 row-operation differential cases on the final sources: 0 mismatches"),
+         ("`HISTORY_design_r1_r4.md`", "-", "DESIGN.md as it stood at the end of round 4 (the lab notebook of rounds 1-4)")]
 with open(os.path.join(DST, "README.md"), "w") as f:
     f.write("# profiles/ — rocprofv3 evidence (MI355X, gfx950, ROCm 7.2)\n\n"
             "GENERATED by `tools/refresh_profiles_post.py` from the files it lists (after `gpurun -- bash tools/refresh_profiles.sh`): every number below is read\n"
             "from the file in the first column.  rocprofv3 in this image writes a rocpd SQLite database; the text files are per-kernel summaries made with\n"
             "`tools/rocpd_summary.py` / `tools/pmc_kernel.py`; PMC passes are separate runs, one counter group per pass (`/opt/skills/guides/MI355X_MICROARCH.md`).\n"
             "Rounds 1-3: `HISTORY.md`.\n\n| file | command | what it shows |\n|---|---|---|\n")
-    for r in rows + hand: f.write("| " + " | ".join(r) + " |\n")
+    for r in rows + hand5 + hand: f.write("| " + " | ".join(r) + " |\n")
 print(open(os.path.join(DST, "README.md")).read()[:3000])
