@@ -340,8 +340,8 @@ int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affin
 int mi355zk_bn254_g1_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int mode);
 int mi355zk_bn254_g2_batch_exp(uint8_t *out_affine, const uint8_t *bases_affine, const uint64_t *scalars, size_t n, int mode);
 /* The test that lets a caller give the promise MI355ZK_G2_TRUSTED_SUBGROUP for data it did not produce: *bad_index = the lowest index of a G2 record that is on the twist but NOT in
- * the order-r subgroup (-1: all n records are; the all-zero record is the identity).  psi(P) == mu P, mu P by a plain
- * double-and-add (no split).  The reference has no counterpart -- its bn256 decoders do not test membership either -- so this
+ * the order-r subgroup (-1: all n records are; the all-zero record is the identity).  [x + 1] P + psi([x] P) + psi^2([x] P) == psi^3([2 x] P)
+ * with x the 63-bit BN parameter -- one plain double-and-add (no split), sound and complete for BN254; a record that is not on the twist is not a member.  The reference has no counterpart -- its bn256 decoders do not test membership either -- so this
  * is an addition for callers that handle untrusted G2 data, not a drop-in for anything.  Synchronises `stream`. */
 int mi355zk_bn254_g2_subgroup_check_dev(const void *d_points_affine, size_t n, void *stream, long long *bad_index);
 int mi355zk_selftest_g2_in_subgroup(const uint64_t affine_pt[16]);   /* host run of the same test: 1 / 0 */

@@ -2232,7 +2232,7 @@ template <class F>
 static int sparse_matvec(void* d_out, const void* d_bases, size_t n_bases, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeffs,
                          size_t n_rows, size_t nnz, void* stream, int group, bool g2_trusted, void* d_scratch = nullptr, size_t scratch_bytes = 0) {
   // d_scratch: the caller's buffer for the term products (the host-buffer form leases it with its other buffers: hipMalloc / hipFree per
-  // call synchronise the whole device, i.e. every other thread's multiexp); sparse_matvec_scratch_bytes says how much
+  // call synchronise the whole device, i.e. every other thread's multiexp): room for the terms, 256 B of flags and one byte per base
   if (!d_out || !d_row_ptr || (nnz && (!d_bases || !d_col || !d_coeffs)) || n_rows >= (1ull << 31) || nnz >= (1ull << 31)) return ZK_ERR_BAD_ARGS;
   if (n_rows == 0) return ZK_OK;
   // G2 without the caller's promise: when the bases are reused (nnz >= 2 n_bases: a circuit has ~3 terms per Lagrange coefficient), ONE
