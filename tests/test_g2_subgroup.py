@@ -168,24 +168,30 @@ def test_g2_point_fft_is_exact_for_points_outside_the_subgroup(zk, worker, op):
 
 
 @pytest.mark.gpu
-def test_g2_sparse_matvec_is_exact_for_points_outside_the_subgroup(zk, worker):
+@pytest.mark.parametrize("rows", [9, 40])
+def test_g2_sparse_matvec_is_exact_for_points_outside_the_subgroup(zk, worker, rows):
     """The QAP sums of MPCParameters::new (phase2/src/parameters.rs:281-294: `coeffs_g2[lag].mul(coeff)` added up) over bases with a cofactor
     component; coefficients 0 / 1 / r - 1 (a full multiplication here: (r - 1) P != -P) / general.  Device and host-buffer forms."""
     import torch
 
     n = 24
     pts = _g2_vector_with_cofactor_points(n, seed=4740)
-    rng = np.random.default_rng(4741)
-    rows = 9
+    # rows = 9: fewer than 2 terms per base -- every term through the plain windows; rows = 40: the bases are reused (nnz >= 2 n_bases), so the
+    # membership test runs over the bases and the terms split by it (members: psi split and the r - 1 shortcut; the others: plain windows)
+    rng = np.random.default_rng(4741 + rows)
     lens = rng.integers(0, 6, rows)
     lens[2] = 0
     row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     nnz = int(row_ptr[-1])
     col = rng.integers(0, n, nnz).astype(np.int32)
     col[:4] = [1, n // 2, n - 2, 3]                               # the records outside the subgroup (and the infinity) are used
+    assert rows == 9 or nnz >= 2 * n
     coeff = inputs.random_scalars(nnz, seed=4742)
     for t, v in enumerate([M.R_ORDER - 1, 1, M.R_ORDER - 1, 7, 0]):
         coeff[t] = _limbs(v)
+    if nnz > 8:                                                   # r - 1 and 1 on a MEMBER base too (the shortcut -P / P where it is allowed)
+        col[5], col[6] = 0, 4
+        coeff[5], coeff[6] = _limbs(M.R_ORDER - 1), _limbs(1)
     want = np.zeros((rows, 16), np.uint64)
     for r in range(rows):
         acc = O.G2.from_affine(np.zeros(16, np.uint64))
