@@ -18,13 +18,38 @@ zk.Worker(devices=[0] * a.devices) if a.devices > 1 else zk.Worker(0)
 rng = np.random.default_rng(a.seed)
 R = M.R_ORDER
 pools = {g: inputs.bases_cpu(g, 40, seed=4100 + g) for g in (1, 2)}
+
+def twist_points(count):
+    """on-twist G2 records that are NOT in the order-r subgroup (x = (c0, 1) with a square root of x^3 + b'; r * P != infinity), and their sums with
+    subgroup points: what the reference's decoders admit and its wNAF multiplies exactly (round 5: so do the default paths here)"""
+    b = O.g2_coeff_b(); out = []
+    mont = lambda v: np.array(M.to_limbs(M.to_mont(v, M.Q)), dtype=np.uint64)
+    c0 = 5
+    while len(out) < count:
+        c0 += 1
+        x = np.concatenate([mont(c0), mont(1)])
+        rhs = O.fq2_mul(O.fq2_sqr(x), x)
+        rhs = np.concatenate([O.fe_add(0, rhs[:4], b[:4]), O.fe_add(0, rhs[4:], b[4:])])
+        y = O.fq2_sqrt(rhs)
+        if y is None: continue
+        pt = np.concatenate([x, y])
+        if not O.G2.to_affine(O.G2.mul(O.G2.from_affine(pt), np.array(M.to_limbs(R), dtype=np.uint64))).any(): continue
+        out.append(pt)
+        out.append(O.G2.to_affine(O.G2.add_mixed(O.G2.from_affine(pools[2][len(out) % 40]), pt)))
+    return np.stack(out[:count])
+outside = twist_points(8)
 dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).cuda()
 host = lambda t: t.cpu().numpy().view(np.uint64)
 
-def points(g, n):
+def points(g, n, allow_outside=False):
     p = pools[g][rng.integers(0, 40, n)].copy()
     if n > 2 and rng.random() < 0.5: p[rng.integers(0, n, max(1, n // 10))] = 0      # infinity records
-    return p
+    members = True
+    if g == 2 and allow_outside and rng.random() < 0.5:                              # G2 records outside the order-r subgroup
+        k = max(1, n // 6)
+        p[rng.integers(0, n, k)] = outside[rng.integers(0, len(outside), k)]
+        members = False
+    return (p, members) if allow_outside else p
 
 def scalars(n):
     s = inputs.random_scalars(n, seed=int(rng.integers(1 << 30)))
@@ -51,11 +76,14 @@ for case in range(a.cases):
     if which == 0:      # batch_exp
         n = int(rng.choice([1, 2, 3, 17, 64, 65, 200, 257])) if g == 1 else int(rng.choice([1, 2, 3, 17, 40]))
         same = bool(rng.integers(0, 2))
-        p, s = points(g, n), scalars(1 if same else n)
+        (p, members), s = points(g, n, True), scalars(1 if same else n)
         got = host(zk.ceremony.batch_exp(dev(p), dev(s), same_scalar=same))
         got_h = zk.ceremony.batch_exp_host(p, s, same_scalar=same)
         want = np.stack([G.to_affine(G.mul(G.from_affine(p[i]), s[0 if same else i])) for i in range(n)])
-        check(np.array_equal(got, want) and np.array_equal(got_h, want), f"batch_exp g{g} n={n} same={same} (case {case})")
+        ok = np.array_equal(got, want) and np.array_equal(got_h, want)
+        if members:   # every record in the subgroup: the promise may be given, and the split kernels return the same records
+            ok = ok and np.array_equal(host(zk.ceremony.batch_exp(dev(p), dev(s), same_scalar=same, trusted_subgroup=True)), want)
+        check(ok, f"batch_exp g{g} n={n} same={same} members={members} (case {case})")
     elif which == 1:    # dense_multiexp
         n = int(rng.choice([1, 2, 5, 33, 100, 1000, 2500])) if g == 1 else int(rng.choice([1, 2, 5, 33, 300]))
         p, s = points(g, n), scalars(n)
@@ -72,7 +100,7 @@ for case in range(a.cases):
               f"merge_pairs g{g} n={n} (case {case})")
     elif which == 3:    # QAP sparse matvec
         nb = int(rng.integers(1, 40)); rows = int(rng.integers(1, 60))
-        p = points(g, nb)
+        p, members = points(g, nb, True)
         lens = rng.integers(0, 5, rows); lens[rng.integers(0, rows)] = int(rng.integers(0, 120 if g == 1 else 30))
         rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32); nnz = int(rp[-1])
         col = rng.integers(0, nb, nnz).astype(np.uint32); cf = scalars(max(nnz, 1))[:nnz]
@@ -85,7 +113,9 @@ for case in range(a.cases):
             acc = G.from_affine(np.zeros(G.aff, np.uint64))
             for t in range(rp[r], rp[r + 1]): acc = G.add(acc, G.mul(G.from_affine(p[col[t]]), cf[t]))
             want[r] = G.to_affine(acc)
-        check(np.array_equal(got, want) and np.array_equal(got_h, want), f"sparse_matvec g{g} rows={rows} nnz={nnz} (case {case})")
+        ok = np.array_equal(got, want) and np.array_equal(got_h, want)
+        if members: ok = ok and np.array_equal(host(zk.ceremony.eval_qap(dev(p), d32(rp), d32(col), dev(cf), trusted_subgroup=True)), want)
+        check(ok, f"sparse_matvec g{g} rows={rows} nnz={nnz} members={members} (case {case})")
     elif which == 4:    # codecs
         n = int(rng.choice([1, 2, 31, 100])); comp = bool(rng.integers(0, 2))
         p = points(g, n)
@@ -95,8 +125,16 @@ for case in range(a.cases):
         dec = host(zk.ceremony.decode_points(torch.from_numpy(want_enc).cuda(), g, comp, True))
         check(np.array_equal(enc, want_enc) and rc == 0 and np.array_equal(back, p) and np.array_equal(dec, p), f"codec g{g} n={n} compressed={comp} (case {case})")
     else:               # point FFT round trip + linearity: ifft(fft(v)) == v, and fft(v)[0] == sum v
-        log_n = int(rng.integers(0, 7 if g == 1 else 5)); n = 1 << log_n
+        log_n = int(rng.integers(0, 7 if g == 1 else 7)); n = 1 << log_n
         p = pools[g][rng.integers(0, 40, n)].copy()
+        if g == 2 and n >= 4 and rng.random() < 0.5:
+            # records outside the subgroup: omega^n == 1 holds mod r only, so ifft(fft(v)) == v is NOT an identity for them (nor in the reference);
+            # the transform itself is still the group law applied in the reference's order: compare with the oracle's Point<G2> FFT directly
+            p[rng.integers(0, n, max(1, n // 8))] = outside[rng.integers(0, len(outside), max(1, n // 8))]
+            op = ("fft", "ifft")[int(rng.integers(2))]
+            got = host((zk.ceremony.point_fft if op == "fft" else zk.ceremony.point_ifft)(dev(p)))
+            check(np.array_equal(got, O.point_domain_op(2, p, log_n, op)), f"point_{op} g2 n={n} with records outside the subgroup (case {case})")
+            continue
         d = dev(p)
         f = host(zk.ceremony.point_fft(d.clone()))
         back = host(zk.ceremony.point_ifft(dev(f)))
