@@ -61,9 +61,9 @@ struct NttPassParams {
   uint64_t tw_mul;
   uint32_t tw_h;            // two-level split: w^e = A[e >> h] * B[e & (2^h - 1)]
   uint32_t tw_full;         // 1: the first pass of a two-pass transform reads its twiddle w^(k * col) from a table indexed by the OUTPUT position
-  uint32_t pre;             // first pass of coset_fft: element i *= g^i   (preA/preB, split pre_h)
+  uint32_t pre;             // first pass of coset_fft: element i *= g^i   (1: preA/preB, split pre_h; 2 (round 5, folded tables): row position x *= preA[x])
   uint32_t pre_h;
-  uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h)
+  uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h); 3 = by nothing; 4 = row output k *= postA[k]
   uint32_t post_h;
   uint32_t xcd_pair;        // 1: tiles 2j and 2j + 1 run on the same XCD, one dispatch round apart (see the kernel)
 };
@@ -200,9 +200,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     else { g = e % P.g; x = e / P.g; }
     const uint64_t gi = in_base + x * P.in_xs + g * P.in_gs;
     FrU v = u_from_std(gload(in + gi));                                   // < p, N
-    if (P.pre) {                                                          // distribute_powers (domain.rs:176-189)
+    if (P.pre == 1) {                                                     // distribute_powers (domain.rs:176-189)
       v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));                    // g^i = A[i >> h] * B[i & mask]: two products by constants
       v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));     // < 2p, N
+    } else if (P.pre == 2) {
+      v = tw_mul(v, tab_load(preA + x));                                  // (g^S)^x: the column's g^col sits in the folded inter-pass table
     }
     lds_store(lds, plane, g * pitch + (swz(bitrev(x, LOG_NP)) ^ row_term(g, P.g, np)), v);
   }
@@ -361,6 +363,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
     } else if (P.post == 3) {                                             // plain fft / coset_fft: nothing to multiply by --
       gstore(out + go, u_to_std_lt32p(u_carry(v)));                       // reduce the < 24p value directly
       continue;
+    } else if (P.post == 4) {
+      w = tab_load(postA + k);                                            // (ginv^N1)^k; minv * ginv^k1 sits in the folded inter-pass table
     } else {
       w = post_c;                                                         // minv (ifft, domain.rs:163-173)
     }
@@ -425,13 +429,19 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
   const uint32_t g = q & (G - 1u), qf = q >> log_g;    // row, group index (qf < np / 4)
   const uint32_t own = 256u / G;                        // elements of a row a wave owns
   const uint32_t row = g * pitch, rx = row_term_wl(g, G);
+  // P.pre == 3 (folded tables): the row twist of a coset transform sits in the butterfly twiddles -- a stage-major table (ntt_stage_table_kernel)
+  // in preA instead of `roots`, and no twiddle is one
+  const bool twisted = P.pre == 3;
+  const UTab* stage_tab = twisted ? preA : roots;
   auto at = [&](uint32_t x) __attribute__((always_inline)) { return row + (swz_wl(x) ^ rx); };
 
-  auto fetch = [&](uint64_t gi) __attribute__((always_inline)) {                       // one element of the tile from memory: < 2p, N
+  auto fetch = [&](uint64_t gi, uint32_t x) __attribute__((always_inline)) {           // element x of a row from memory: < 2p, N
     FrU v = u_from_std(gload(in + gi));
-    if (P.pre) {                                        // distribute_powers (domain.rs:176-189)
+    if (P.pre == 1) {                                   // distribute_powers (domain.rs:176-189)
       v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));
       v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));
+    } else if (P.pre == 2) {
+      v = tw_mul(v, tab_load(preA + x));                // folded tables: (g^S)^x here, g^col in the inter-pass table
     }
     return v;
   };
@@ -467,6 +477,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
     } else if (P.post == 3) {
       gstore(out + go, u_to_std_lt32p(u_carry(v)));
       return;
+    } else if (P.post == 4) {
+      w = tab_load(postA + k);
     } else {
       w = post_c;
     }
@@ -478,24 +490,26 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
   const bool direct = S0 == 0 && !P.load_x_fastest;    // (uniform)
   if (direct) {
     const uint32_t xr = bitrev(qf, LOG_NP - 2);         // element index = brev2(k) * np / 4 + brev(qf)
-    a = fetch(in_base + (uint64_t)(xr) * P.in_xs + g * P.in_gs);
-    b = fetch(in_base + (uint64_t)(xr + 2u * (np >> 2)) * P.in_xs + g * P.in_gs);   // k = 1 -> brev2 = 2
-    c = fetch(in_base + (uint64_t)(xr + 1u * (np >> 2)) * P.in_xs + g * P.in_gs);   // k = 2 -> brev2 = 1
-    d = fetch(in_base + (uint64_t)(xr + 3u * (np >> 2)) * P.in_xs + g * P.in_gs);
+    a = fetch(in_base + (uint64_t)(xr) * P.in_xs + g * P.in_gs, xr);
+    b = fetch(in_base + (uint64_t)(xr + 2u * (np >> 2)) * P.in_xs + g * P.in_gs, xr + 2u * (np >> 2));   // k = 1 -> brev2 = 2
+    c = fetch(in_base + (uint64_t)(xr + 1u * (np >> 2)) * P.in_xs + g * P.in_gs, xr + 1u * (np >> 2));   // k = 2 -> brev2 = 1
+    d = fetch(in_base + (uint64_t)(xr + 3u * (np >> 2)) * P.in_xs + g * P.in_gs, xr + 3u * (np >> 2));
   } else {
     for (uint32_t e = threadIdx.x; e < elems; e += blockDim.x) {
       uint32_t x, gg;
       if (P.load_x_fastest) { x = e & (np - 1); gg = e >> LOG_NP; }
       else { gg = e & (G - 1u); x = e >> log_g; }
       const uint64_t gi = in_base + x * P.in_xs + gg * P.in_gs;
-      lds_store(lds, plane, gg * pitch + (swz_wl(bitrev(x, LOG_NP)) ^ row_term_wl(gg, G)), fetch(gi));
+      lds_store(lds, plane, gg * pitch + (swz_wl(bitrev(x, LOG_NP)) ^ row_term_wl(gg, G)), fetch(gi, x));
     }
     __syncthreads();
     if constexpr (S0 == 1) {                           // stage 0 alone (all twiddles one): two butterflies per lane, neighbours in the row
       const uint32_t x0 = qf << 2;
       a = lds_load(lds, plane, at(x0)); b = lds_load(lds, plane, at(x0 + 1)); c = lds_load(lds, plane, at(x0 + 2)); d = lds_load(lds, plane, at(x0 + 3));
-      bf(std::integral_constant<int, 0>{}, a, b, TwU{a, a}, true);
-      bf(std::integral_constant<int, 0>{}, c, d, TwU{a, a}, true);
+      TwU w0{a, a};
+      if (twisted) w0 = tab_load(stage_tab + 1);
+      bf(std::integral_constant<int, 0>{}, a, b, w0, !twisted);
+      bf(std::integral_constant<int, 0>{}, c, d, w0, !twisted);
       lds_store(lds, plane, at(x0), a); lds_store(lds, plane, at(x0 + 1), b); lds_store(lds, plane, at(x0 + 2), c); lds_store(lds, plane, at(x0 + 3), d);
       // pair 1 takes groups of 8 elements = two of these lanes' quadruples: inside the wave while it owns >= 8 elements per row
       if (8u <= own) wave_handover(); else __syncthreads();
@@ -508,21 +522,21 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
     const uint32_t j = qf & (m - 1), x0 = ((qf >> s) << (s + 2)) + j;
     const uint32_t ia = at(x0), ib = at(x0 + m), ic = at(x0 + 2 * m), id = at(x0 + 3 * m);
     if (!(first && direct)) { a = lds_load(lds, plane, ia); b = lds_load(lds, plane, ib); c = lds_load(lds, plane, ic); d = lds_load(lds, plane, id); }
-    const bool one = s <= SKIP_MAX && j == 0;
+    const bool one = !twisted && s <= SKIP_MAX && j == 0;
     {
       TwU w1{a, a};
-      if (!one) w1 = tab_load(roots + ((uint64_t)j << (LOG_NP - 1 - s)));   // (requesting it before the hand-over, to run under the wait: measured, nothing)
+      if (!one) w1 = tab_load(stage_tab + (twisted ? m + j : j << (LOG_NP - 1 - s)));   // (requesting it before the hand-over, to run under the wait: measured, nothing)
       bf(std::integral_constant<int, (int)s>{}, a, b, w1, one);
       bf(std::integral_constant<int, (int)s>{}, c, d, w1, one);
     }
-    const bool one2 = s + 1 <= SKIP_MAX && j == 0;
+    const bool one2 = !twisted && s + 1 <= SKIP_MAX && j == 0;
     {
       TwU w2{a, a};
-      if (!one2) w2 = tab_load(roots + ((uint64_t)j << (LOG_NP - 2 - s)));
+      if (!one2) w2 = tab_load(stage_tab + (twisted ? 2u * m + j : j << (LOG_NP - 2 - s)));
       bf(std::integral_constant<int, (int)s + 1>{}, a, c, w2, one2);
     }
     {
-      const TwU w3 = tab_load(roots + ((uint64_t)(j + m) << (LOG_NP - 2 - s)));
+      const TwU w3 = tab_load(stage_tab + (twisted ? 3u * m + j : (j + m) << (LOG_NP - 2 - s)));
       bf(std::integral_constant<int, (int)s + 1>{}, b, d, w3, false);
     }
     if constexpr (!last) {
@@ -551,6 +565,41 @@ __global__ void ntt_full_twiddle_kernel(UTab* __restrict__ full, const UTab* __r
   const uint64_t k = i >> log_s, col = i & ((1ull << log_s) - 1), ex = k * col;
   const FrU w = tw_mul(tab_load(A + (ex >> h)).w, tab_load(B + (ex & ((1ull << h) - 1))));  // < 2p, N
   tab_store(full + i, tw_make(u_to_std_lt2p(w)));                                           // canonical, and its quotient
+}
+
+// (round 5) The same table with the scale factors of a coset / inverse transform FOLDED in:
+//   full[k * S + col] = w^(k * col) * pre^col * post_c * post^k
+// The input twist pre^i of coset_fft (i = x * S + col: domain.rs:176-189) splits into pre^col -- constant over the first pass's
+// sub-transform of column col, so it commutes with it and lands here -- and (pre^S)^x, ONE product by a table of N_1 entries at the
+// load.  The output scale post_c * post^K of ifft / icoset_fft (K = k + N_1 * k2: domain.rs:163-173, 197-203) splits into
+// post_c * post^k -- constant over the second pass's sub-transform of row k: here -- and (post^N_1)^k2, ONE product by a table of S
+// entries at the last store.  coset_fft's first pass: two products less one; ifft's last pass: one less; icoset_fft's: three less one.
+__global__ void ntt_full_folded_kernel(UTab* __restrict__ full, const UTab* __restrict__ A, const UTab* __restrict__ B, uint32_t h,
+                                       uint32_t log_s, uint64_t count, const UTab* __restrict__ preA, const UTab* __restrict__ preB,
+                                       uint32_t pre_h, const UTab* __restrict__ postA, const UTab* __restrict__ postB, uint32_t post_h,
+                                       TwU post_c, int has_post_c) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t k = i >> log_s, col = i & ((1ull << log_s) - 1), ex = k * col;
+  FrU w = tw_mul(tab_load(A + (ex >> h)).w, tab_load(B + (ex & ((1ull << h) - 1))));        // < 2p, N (and so after every product below)
+  if (preA != nullptr) w = tw_mul(tw_mul(w, tab_load(preA + (col >> pre_h))), tab_load(preB + (col & ((1ull << pre_h) - 1))));
+  if (postA != nullptr) w = tw_mul(tw_mul(w, tab_load(postA + (k >> post_h))), tab_load(postB + (k & ((1ull << post_h) - 1))));
+  if (has_post_c) w = tw_mul(w, post_c);
+  tab_store(full + i, tw_make(u_to_std_lt2p(w)));
+}
+
+// (round 5) The row twist (pre^S)^x of a coset transform's first pass folded into the butterflies: a DIT block of 2m = 2^(s+1) outputs at
+// stage s is the transform of the row's samples at stride sigma = N_p / 2m, and  sum_t x_t h^(sigma t) w_2m^(t k)  =  E(k) + h^sigma w_2m^k O(k)
+// with E, O the same sums over the even / odd samples (stride 2 sigma) -- so the twisted transform is the plain one with stage s's twiddle
+// w_2m^j replaced by h^sigma w_2m^j, and no product at the load at all.  Stage-major table: tab[m + j] = h^sigma * w_p^(j sigma), j < m = 2^s
+// (tab[0] unused).  The twiddle-one products of the early stages are no longer skipped (h^sigma != 1).
+__global__ void ntt_stage_table_kernel(UTab* tab, Fr pre, uint64_t s_cols, Fr omega, uint64_t step0, uint32_t log_np) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_np)) return;
+  if (i == 0) { tab_store(tab, tw_make(to_canonical(Fr::one()))); return; }
+  const uint32_t s = 31u - (uint32_t)__clz(i), m = 1u << s, j = i - m;
+  const uint64_t sigma = (1ull << log_np) >> (s + 1);
+  tab_store(tab + i, tw_make(to_canonical(mul(pow_u64(pre, s_cols * sigma), pow_u64(omega, step0 * j * sigma)))));
 }
 
 // a[i] *= c * gA[i >> h] * gB[i & mask]   (gA == nullptr: a[i] *= c);  c in the memory format
@@ -585,7 +634,28 @@ struct PowTables {
   UTab* roots[NTT_MAX_LOG_NP + 1] = {};  // roots[b][x] = (w^(N/2^b))^x, x < 2^(b-1)
   UTab* full = nullptr;    // two-pass transforms up to NTT_FULL_TW_MAX_LOG: w^(k * col) at the first pass's output position (72 B per element)
   uint32_t full_log_s = 0;
+  // (round 5) `full` with a transform's scale factors folded in (ntt_full_folded_kernel), one per (pre_g, post_c, post_g) this root has
+  // been used with -- a domain uses two roots with two each: (fft, coset_fft) and (ifft, icoset_fft)
+  struct Folded {
+    bool has_pre = false, has_post_c = false, has_post_g = false;
+    Fr pre{}, post_c{}, post_g{};
+    uint32_t log_s = 0;
+    UTab* full = nullptr;
+    UTab* pre_rows = nullptr;   // (pre^S)^x, x < N_1
+    UTab* pre_stages = nullptr; // the first pass's butterfly twiddles times the row twist (ntt_stage_table_kernel), N_1 entries
+    UTab* post_rows = nullptr;  // (post^N_1)^k2, k2 < S
+  };
+  std::vector<Folded> folded;
+  void free_all() {
+    (void)hipFree(A);
+    (void)hipFree(B);
+    (void)hipFree(full);
+    for (auto* r : roots) (void)hipFree(r);
+    for (auto& f : folded) { (void)hipFree(f.full); (void)hipFree(f.pre_rows); (void)hipFree(f.pre_stages); (void)hipFree(f.post_rows); }
+    folded.clear();
+  }
 };
+constexpr size_t NTT_FOLDED_MAX = 4;   // per root: a caller cycling through coset generators must not grow device memory without limit
 // Measured (round 3): 2^20 fft 0.1507 -> 0.1456 ms with the table (one product less per element of the first pass, 50 MB more to
 // stream); at 2^22 the 192 MiB table makes the transform SLOWER (0.564 -> 0.580 ms): the pass is VALU-bound only while its streams stay
 // inside the L2 / Infinity Cache.  Hence two-pass transforms up to 2^20 only.
@@ -609,10 +679,7 @@ int tables_make_room(size_t need) {
   ZK_HIP(hipDeviceSynchronize());
   for (auto it = g_tables.begin(); it != g_tables.end();) {
     if (it->first.dev != dev) { ++it; continue; }
-    (void)hipFree(it->second.A);
-    (void)hipFree(it->second.B);
-    (void)hipFree(it->second.full);
-    for (auto* r : it->second.roots) (void)hipFree(r);
+    it->second.free_all();
     it = g_tables.erase(it);
   }
   return ZK_OK;
@@ -634,10 +701,7 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
   auto fail = [&](hipError_t e, const char* what) {
     std::fprintf(stderr, "[mi355zk] NTT table build failed (%s): %s\n", what, hipGetErrorString(e));
     (void)hipStreamSynchronize(st);
-    (void)hipFree(T.A);
-    (void)hipFree(T.B);
-    (void)hipFree(T.full);
-    for (auto* r : T.roots) (void)hipFree(r);
+    T.free_all();
     g_tables.erase(key);
     return (int)ZK_ERR_DEVICE;
   };
@@ -678,6 +742,59 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
   }
   if (built && (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");  // one-time: tables may be used from other streams later
   *out = &T;
+  return 0;
+}
+
+// the folded variant of T's full table for (pre_g, post_c, post_g) (any of them may be null, not all): found or built.  Called under
+// g_run_mu; the device pointers are copied out before anybody can evict the entry.
+int build_folded(hipStream_t st, uint32_t log_n, const Fr& omega, PowTables* T, const PowTables* Tpre, const PowTables* Tpost, const Fr* pre_g, const Fr* post_c,
+                 const TwU& post_cu, const Fr* post_g, uint32_t log_n1, uint32_t log_s, PowTables::Folded* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (const auto& f : T->folded) {
+    if (f.log_s != log_s || f.has_pre != (pre_g != nullptr) || f.has_post_c != (post_c != nullptr) || f.has_post_g != (post_g != nullptr)) continue;
+    if (pre_g && std::memcmp(&f.pre, pre_g, sizeof(Fr)) != 0) continue;
+    if (post_c && std::memcmp(&f.post_c, post_c, sizeof(Fr)) != 0) continue;
+    if (post_g && std::memcmp(&f.post_g, post_g, sizeof(Fr)) != 0) continue;
+    *out = f;
+    return 0;
+  }
+  if (T->folded.size() >= NTT_FOLDED_MAX) {   // the oldest goes, once nothing on the device can still be reading it
+    ZK_HIP(hipDeviceSynchronize());
+    auto& f = T->folded.front();
+    (void)hipFree(f.full); (void)hipFree(f.pre_rows); (void)hipFree(f.pre_stages); (void)hipFree(f.post_rows);
+    T->folded.erase(T->folded.begin());
+  }
+  PowTables::Folded f;
+  f.log_s = log_s;
+  if (pre_g) { f.has_pre = true; f.pre = *pre_g; }
+  if (post_c) { f.has_post_c = true; f.post_c = *post_c; }
+  if (post_g) { f.has_post_g = true; f.post_g = *post_g; }
+  const uint64_t cnt = 1ull << log_n, n1 = 1ull << log_n1, ns = 1ull << log_s;
+  hipError_t e = hipSuccess;
+  auto fail = [&](hipError_t err, const char* what) {
+    std::fprintf(stderr, "[mi355zk] NTT folded-table build failed (%s): %s\n", what, hipGetErrorString(err));
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(f.full); (void)hipFree(f.pre_rows); (void)hipFree(f.pre_stages); (void)hipFree(f.post_rows);
+    return (int)ZK_ERR_DEVICE;
+  };
+  if ((e = hipMalloc(&f.full, cnt * sizeof(UTab))) != hipSuccess) return fail(e, "full");
+  if (pre_g) {
+    if ((e = hipMalloc(&f.pre_rows, n1 * sizeof(UTab))) != hipSuccess) return fail(e, "pre rows");
+    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, f.pre_rows, *pre_g, ns, n1);
+    if ((e = hipMalloc(&f.pre_stages, n1 * sizeof(UTab))) != hipSuccess) return fail(e, "pre stages");
+    hipLaunchKernelGGL(ntt_stage_table_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, f.pre_stages, *pre_g, ns, omega, ns, log_n1);
+  }
+  if (post_g) {
+    if ((e = hipMalloc(&f.post_rows, ns * sizeof(UTab))) != hipSuccess) return fail(e, "post rows");
+    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, f.post_rows, *post_g, n1, ns);
+  }
+  hipLaunchKernelGGL(ntt_full_folded_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, f.full, T->A, T->B, T->h, log_s, cnt,
+                     Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpre ? Tpre->h : 0u, Tpost ? Tpost->A : nullptr,
+                     Tpost ? Tpost->B : nullptr, Tpost ? Tpost->h : 0u, post_cu, post_c != nullptr ? 1 : 0);
+  if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");   // one-time: the table may be used from other streams later
+  T->folded.push_back(f);
+  *out = f;
   return 0;
 }
 
@@ -729,10 +846,7 @@ void ntt_release_all() {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_tables) {
     (void)hipSetDevice(kv.first.dev);
-    (void)hipFree(kv.second.A);
-    (void)hipFree(kv.second.B);
-    (void)hipFree(kv.second.full);
-    for (auto* r : kv.second.roots) (void)hipFree(r);
+    kv.second.free_all();
   }
   g_tables.clear();
   for (auto& kv : g_scratch) {
@@ -790,13 +904,24 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   PowTables* T = nullptr;
   static const bool no_full = std::getenv("MI355ZK_NTT_NO_FULL_TW") != nullptr;  // (the two-level product, kept for the comparison in DESIGN.md)
   const bool full_tw = R == 2 && log_n <= NTT_FULL_TW_MAX_LOG && !no_full;
-  rc = build_pow_tables(st, log_n, omega, true, b, R, &T, full_tw ? b[1] : 0);
+  // (round 5) a scaled two-pass transform with a full table takes that table with its scale factors folded in (ntt_full_folded_kernel);
+  // env MI355ZK_NTT_NO_FOLD: the separate products of rounds 1-4, for the A/B
+  static const bool no_fold = std::getenv("MI355ZK_NTT_NO_FOLD") != nullptr;
+  const bool fold = full_tw && !no_fold && (pre_g || post_c || post_g);
+  rc = build_pow_tables(st, log_n, omega, true, b, R, &T, (full_tw && !fold) ? b[1] : 0);
   if (rc) return rc;
   PowTables* Tpre = nullptr;
   PowTables* Tpost = nullptr;
   if (pre_g) { rc = build_pow_tables(st, log_n, *pre_g, false, nullptr, 0, &Tpre); if (rc) return rc; }
   if (post_g) { rc = build_pow_tables(st, log_n, *post_g, false, nullptr, 0, &Tpost); if (rc) return rc; }
   const TwU post_cu = post_c ? to_tw(*post_c) : (post_g ? to_tw(Fr::one()) : TwU{FrU::zero(), FrU::zero()});   // (neither: post == 3 multiplies by nothing)
+  PowTables::Folded F;
+  if (fold) { rc = build_folded(st, log_n, omega, T, Tpre, Tpost, pre_g, post_c, post_cu, post_g, b[0], b[1], &F); if (rc) return rc; }
+  const UTab* k_full = fold ? F.full : T->full;
+  const UTab* k_preA = fold ? F.pre_rows : (Tpre ? Tpre->A : nullptr);
+  const UTab* k_preB = (!fold && Tpre) ? Tpre->B : nullptr;
+  const UTab* k_postA = fold ? F.post_rows : (Tpost ? Tpost->A : nullptr);
+  const UTab* k_postB = (!fold && Tpost) ? Tpost->B : nullptr;
   static const int slot_pass = prof_slot("ntt_pass");
 
   Fr* scratch = nullptr;
@@ -905,8 +1030,12 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     static const bool pair_all = std::getenv("MI355ZK_NTT_PAIR_ALL") != nullptr;
     // (narrow tiles only: with 128-byte runs and more the grouping is neutral -- measured with MI355ZK_NTT_PAIR_ALL)
     P.xcd_pair = ((P.g <= 2 || pair_all) && tiles % 256 == 0 && !no_pair) ? (pair_env ? (uint32_t)std::atoi(pair_env) : 5u) : 0u;
-    if (p == 0 && Tpre) { P.pre = 1; P.pre_h = Tpre->h; }
-    if (p == R - 1) { P.post = Tpost ? 2 : (post_c ? 1 : 3); P.post_h = Tpost ? Tpost->h : 0; }
+    if (p == 0 && Tpre) { P.pre = fold ? 2 : 1; P.pre_h = Tpre->h; }   // (fold + the wave-local kernel: 3, below)
+    if (p == R - 1) {
+      if (fold) P.post = Tpost ? 4 : 3;    // post_c (and post_g^k1) sit in the folded table
+      else P.post = Tpost ? 2 : (post_c ? 1 : 3);
+      P.post_h = Tpost ? Tpost->h : 0;
+    }
     uint32_t pitch = (uint32_t)np;
     size_t lds_bytes = (size_t)P.g * pitch * 36;
     uint32_t threads = (uint32_t)((P.g * np) / 2);
@@ -927,11 +1056,14 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     // full tiles of rows of >= 256 elements: the wave-local kernel (round 5; env MI355ZK_NTT_WAVELOCAL=0: the barrier-per-pair kernel, for the A/B)
     static const bool no_wl = std::getenv("MI355ZK_NTT_WAVELOCAL") != nullptr && std::getenv("MI355ZK_NTT_WAVELOCAL")[0] == '0';
     const bool wl_kernel = r4 && !no_wl && b[p] >= 8 && (uint64_t)P.g * np == 4ull * threads;
+    static const bool no_stage_fold = std::getenv("MI355ZK_NTT_NO_STAGE_FOLD") != nullptr;
+    const UTab* k_preA_p = k_preA;
+    if (p == 0 && Tpre && fold && wl_kernel && !no_stage_fold) { P.pre = 3; k_preA_p = F.pre_stages; }
 #define ZK_NTT_LAUNCH_WL(L)                                                                                                                \
   case L:                                                                                                                                  \
     hipLaunchKernelGGL((ntt_pass_wl_kernel<L>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A,      \
-                       T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,    \
-                       post_cu, T->full);                                                                                                  \
+                       T->B, k_preA_p, k_preB, k_postA, k_postB,    \
+                       post_cu, k_full);                                                                                                  \
     break;
     if (wl_kernel) {
       switch (b[p]) {
@@ -943,12 +1075,12 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   case L:                                                                                                                                  \
     if (r4)                                                                                                                                \
       hipLaunchKernelGGL((ntt_pass_kernel<L, true>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
-                         T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,  \
-                         post_cu, T->full);                                                                                                \
+                         T->B, k_preA, k_preB, k_postA, k_postB,  \
+                         post_cu, k_full);                                                                                                \
     else                                                                                                                                   \
       hipLaunchKernelGGL((ntt_pass_kernel<L, false>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
-                         T->B, Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpost ? Tpost->A : nullptr, Tpost ? Tpost->B : nullptr,  \
-                         post_cu, T->full);                                                                                                \
+                         T->B, k_preA, k_preB, k_postA, k_postB,  \
+                         post_cu, k_full);                                                                                                \
     break;
     switch (b[p]) {
       ZK_NTT_LAUNCH(1) ZK_NTT_LAUNCH(2) ZK_NTT_LAUNCH(3) ZK_NTT_LAUNCH(4) ZK_NTT_LAUNCH(5) ZK_NTT_LAUNCH(6) ZK_NTT_LAUNCH(7) ZK_NTT_LAUNCH(8)

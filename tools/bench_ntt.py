@@ -7,14 +7,14 @@ import numpy as np, torch
 import phase2_bn254_amd as zk, inputs
 
 ap = argparse.ArgumentParser(); ap.add_argument("--log-n", type=int, default=20); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--check", action="store_true"); ap.add_argument("--warm", type=int, default=40); ap.add_argument("--warm-ms", type=float, default=50.0)
+ap.add_argument("--check", action="store_true"); ap.add_argument("--warm", type=int, default=40); ap.add_argument("--warm-ms", type=float, default=50.0); ap.add_argument("--ops", default="fft,ifft,coset_fft,icoset_fft")
 a = ap.parse_args()
 L = zk.lib.load(); w = zk.Worker(0)
 n = 1 << a.log_n
 host = inputs.random_fr_mont(n, seed=5)
 d = torch.from_numpy(host.view(np.int64)).cuda()
 res = {}
-for op in ("fft", "ifft", "coset_fft", "icoset_fft"):
+for op in a.ops.split(","):
     dom = zk.EvaluationDomain(d.clone(), a.log_n)
     for _ in range(1 + a.warm): getattr(dom, op)(w)   # (tables built, clocks up: the first op timed used to read 5-10 % slow)
     t_warm = time.perf_counter() + a.warm_ms * 1e-3   # (round 5: and for warm_ms more -- 41 calls of a 2^20 transform are 5 ms, and the clocks of an idle MI355X take
