@@ -61,9 +61,10 @@ struct NttPassParams {
   uint64_t tw_mul;
   uint32_t tw_h;            // two-level split: w^e = A[e >> h] * B[e & (2^h - 1)]
   uint32_t tw_full;         // 1: the first pass of a two-pass transform reads its twiddle w^(k * col) from a table indexed by the OUTPUT position
-  uint32_t pre;             // first pass of coset_fft: element i *= g^i   (1: preA/preB, split pre_h; 2 (round 5, folded tables): row position x *= preA[x])
+  uint32_t pre;             // first pass of coset_fft: element i *= g^i   (1: preA/preB, split pre_h; round 5, folded tables: 2: row position x *= preA[x];
+                            // 3: butterfly twiddles from the stage table preA (wave-local kernel); 4: that, and *= preB[col])
   uint32_t pre_h;
-  uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h); 3 = by nothing; 4 = row output k *= postA[k]
+  uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h); 3 = by nothing; 4 = row output k *= postA[k]; 5 = that, and *= postB[first output index of the row]
   uint32_t post_h;
   uint32_t xcd_pair;        // 1: tiles 2j and 2j + 1 run on the same XCD, one dispatch round apart (see the kernel)
 };
@@ -431,12 +432,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
   const uint32_t row = g * pitch, rx = row_term_wl(g, G);
   // P.pre == 3 (folded tables): the row twist of a coset transform sits in the butterfly twiddles -- a stage-major table (ntt_stage_table_kernel)
   // in preA instead of `roots`, and no twiddle is one
-  const bool twisted = P.pre == 3;
+  const bool twisted = P.pre >= 3;
   const UTab* stage_tab = twisted ? preA : roots;
   auto at = [&](uint32_t x) __attribute__((always_inline)) { return row + (swz_wl(x) ^ rx); };
 
   auto fetch = [&](uint64_t gi, uint32_t x) __attribute__((always_inline)) {           // element x of a row from memory: < 2p, N
     FrU v = u_from_std(gload(in + gi));
+    if (P.pre == 4) v = tw_mul(v, tab_load(preB + (gi - (uint64_t)x * P.in_xs)));     // transforms without a full table: g^col (a first pass: gi = x * S + col)
     if (P.pre == 1) {                                   // distribute_powers (domain.rs:176-189)
       v = tw_mul(v, tab_load(preA + (gi >> P.pre_h)));
       v = tw_mul(v, tab_load(preB + (gi & ((1ull << P.pre_h) - 1))));
@@ -478,6 +480,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
       gstore(out + go, u_to_std_lt32p(u_carry(v)));
       return;
     } else if (P.post == 4) {
+      w = tab_load(postA + k);
+    } else if (P.post == 5) {                           // transforms without a full table: (minv * ginv^(row's first output index)) * (ginv^stride)^k
+      v = tw_mul(v, tab_load(postB + (go - (uint64_t)k * P.out_xs)));
       w = tab_load(postA + k);
     } else {
       w = post_c;
@@ -554,6 +559,13 @@ __global__ void ntt_pow_table_kernel(UTab* tab, Fr base, uint64_t step, uint64_t
   uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   tab_store(tab + j, tw_make(to_canonical(pow_u64(base, j * step))));
+}
+
+// tab[j] = c * base^j (c a Montgomery form)
+__global__ void ntt_pow_scaled_table_kernel(UTab* tab, Fr base, Fr c, uint64_t count) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  tab_store(tab + j, tw_make(to_canonical(mul(pow_u64(base, j), c))));
 }
 
 // The inter-pass twiddles of a two-pass transform N = N_1 * S, laid out like the first pass's OUTPUT: full[k * S + col] = w^(k * col)
@@ -643,7 +655,16 @@ struct PowTables {
     UTab* full = nullptr;
     UTab* pre_rows = nullptr;   // (pre^S)^x, x < N_1
     UTab* pre_stages = nullptr; // the first pass's butterfly twiddles times the row twist (ntt_stage_table_kernel), N_1 entries
-    UTab* post_rows = nullptr;  // (post^N_1)^k2, k2 < S
+    UTab* post_rows = nullptr;  // (post^N_1)^k2, k2 < S  (in general: (post^(N / N_last))^k, k < N_last)
+    // transforms without a full table (2^21 and up):
+    bool big = false;
+    UTab* pre_cols = nullptr;    // pre^col, col < N / N_first
+    UTab* post_rowc = nullptr;   // post_c * post^rb, rb < N / N_last: the factor shared by the outputs of one row of the last pass
+    UTab* tw_b_scaled = nullptr; // ifft: the low table B of the two-level twiddle times post_c -- the pass before the last multiplies it in
+    void free_tabs() {
+      (void)hipFree(full); (void)hipFree(pre_rows); (void)hipFree(pre_stages); (void)hipFree(post_rows);
+      (void)hipFree(pre_cols); (void)hipFree(post_rowc); (void)hipFree(tw_b_scaled);
+    }
   };
   std::vector<Folded> folded;
   void free_all() {
@@ -651,7 +672,7 @@ struct PowTables {
     (void)hipFree(B);
     (void)hipFree(full);
     for (auto* r : roots) (void)hipFree(r);
-    for (auto& f : folded) { (void)hipFree(f.full); (void)hipFree(f.pre_rows); (void)hipFree(f.pre_stages); (void)hipFree(f.post_rows); }
+    for (auto& f : folded) f.free_tabs();
     folded.clear();
   }
 };
@@ -745,13 +766,19 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
   return 0;
 }
 
-// the folded variant of T's full table for (pre_g, post_c, post_g) (any of them may be null, not all): found or built.  Called under
-// g_run_mu; the device pointers are copied out before anybody can evict the entry.
+// The folded tables of (T's root, pre_g, post_c, post_g) (any of the three may be null, not all): found or built.  Called under g_run_mu;
+// the device pointers are copied out before anybody can evict the entry.  with_full: the two-pass transform's full inter-pass table with
+// everything that is constant per column / per row folded in (ntt_full_folded_kernel); otherwise (2^21 and up, no full table) the small
+// tables of the same split: the first pass's stage table and pre^col, the last pass's (post^stride)^k and post_c * post^(row's first index),
+// and for a transform scaled by post_c alone the low table of the two-level twiddle times post_c.
+// bits[0 .. R): the passes' row lengths (log2), first pass first.
 int build_folded(hipStream_t st, uint32_t log_n, const Fr& omega, PowTables* T, const PowTables* Tpre, const PowTables* Tpost, const Fr* pre_g, const Fr* post_c,
-                 const TwU& post_cu, const Fr* post_g, uint32_t log_n1, uint32_t log_s, PowTables::Folded* out) {
+                 const TwU& post_cu, const Fr* post_g, const uint32_t* bits, int R, bool with_full, PowTables::Folded* out) {
   std::lock_guard<std::mutex> lk(g_mu);
+  const uint32_t log_first = bits[0], log_last = bits[R - 1];
+  const uint32_t log_s = log_n - log_first;             // columns of the first pass
   for (const auto& f : T->folded) {
-    if (f.log_s != log_s || f.has_pre != (pre_g != nullptr) || f.has_post_c != (post_c != nullptr) || f.has_post_g != (post_g != nullptr)) continue;
+    if (f.log_s != log_s || f.big != !with_full || f.has_pre != (pre_g != nullptr) || f.has_post_c != (post_c != nullptr) || f.has_post_g != (post_g != nullptr)) continue;
     if (pre_g && std::memcmp(&f.pre, pre_g, sizeof(Fr)) != 0) continue;
     if (post_c && std::memcmp(&f.post_c, post_c, sizeof(Fr)) != 0) continue;
     if (post_g && std::memcmp(&f.post_g, post_g, sizeof(Fr)) != 0) continue;
@@ -760,39 +787,56 @@ int build_folded(hipStream_t st, uint32_t log_n, const Fr& omega, PowTables* T, 
   }
   if (T->folded.size() >= NTT_FOLDED_MAX) {   // the oldest goes, once nothing on the device can still be reading it
     ZK_HIP(hipDeviceSynchronize());
-    auto& f = T->folded.front();
-    (void)hipFree(f.full); (void)hipFree(f.pre_rows); (void)hipFree(f.pre_stages); (void)hipFree(f.post_rows);
+    T->folded.front().free_tabs();
     T->folded.erase(T->folded.begin());
   }
   PowTables::Folded f;
   f.log_s = log_s;
+  f.big = !with_full;
   if (pre_g) { f.has_pre = true; f.pre = *pre_g; }
   if (post_c) { f.has_post_c = true; f.post_c = *post_c; }
   if (post_g) { f.has_post_g = true; f.post_g = *post_g; }
-  const uint64_t cnt = 1ull << log_n, n1 = 1ull << log_n1, ns = 1ull << log_s;
+  const uint64_t cnt = 1ull << log_n, n_first = 1ull << log_first, n_cols = 1ull << log_s, n_last = 1ull << log_last, n_rows_last = cnt >> log_last;
   hipError_t e = hipSuccess;
   auto fail = [&](hipError_t err, const char* what) {
     std::fprintf(stderr, "[mi355zk] NTT folded-table build failed (%s): %s\n", what, hipGetErrorString(err));
     (void)hipStreamSynchronize(st);
-    (void)hipFree(f.full); (void)hipFree(f.pre_rows); (void)hipFree(f.pre_stages); (void)hipFree(f.post_rows);
+    f.free_tabs();
     return (int)ZK_ERR_DEVICE;
   };
-  if ((e = hipMalloc(&f.full, cnt * sizeof(UTab))) != hipSuccess) return fail(e, "full");
+  auto grid = [](uint64_t c) { return dim3((unsigned)((c + 255) / 256)); };
   if (pre_g) {
-    if ((e = hipMalloc(&f.pre_rows, n1 * sizeof(UTab))) != hipSuccess) return fail(e, "pre rows");
-    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, f.pre_rows, *pre_g, ns, n1);
-    if ((e = hipMalloc(&f.pre_stages, n1 * sizeof(UTab))) != hipSuccess) return fail(e, "pre stages");
-    hipLaunchKernelGGL(ntt_stage_table_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, f.pre_stages, *pre_g, ns, omega, ns, log_n1);
+    // i = x * n_cols + col:  pre^i = (pre^n_cols)^x * pre^col
+    if ((e = hipMalloc(&f.pre_rows, n_first * sizeof(UTab))) != hipSuccess) return fail(e, "pre rows");
+    hipLaunchKernelGGL(ntt_pow_table_kernel, grid(n_first), dim3(256), 0, st, f.pre_rows, *pre_g, n_cols, n_first);
+    if ((e = hipMalloc(&f.pre_stages, n_first * sizeof(UTab))) != hipSuccess) return fail(e, "pre stages");
+    hipLaunchKernelGGL(ntt_stage_table_kernel, grid(n_first), dim3(256), 0, st, f.pre_stages, *pre_g, n_cols, omega, n_cols, log_first);
+    if (!with_full) {
+      if ((e = hipMalloc(&f.pre_cols, n_cols * sizeof(UTab))) != hipSuccess) return fail(e, "pre cols");
+      hipLaunchKernelGGL(ntt_pow_table_kernel, grid(n_cols), dim3(256), 0, st, f.pre_cols, *pre_g, 1ull, n_cols);
+    }
   }
   if (post_g) {
-    if ((e = hipMalloc(&f.post_rows, ns * sizeof(UTab))) != hipSuccess) return fail(e, "post rows");
-    hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, f.post_rows, *post_g, n1, ns);
+    // K = rb + n_rows_last * k (rb < n_rows_last the row's first output index):  post^K = post^rb * (post^n_rows_last)^k
+    if ((e = hipMalloc(&f.post_rows, n_last * sizeof(UTab))) != hipSuccess) return fail(e, "post rows");
+    hipLaunchKernelGGL(ntt_pow_table_kernel, grid(n_last), dim3(256), 0, st, f.post_rows, *post_g, n_rows_last, n_last);
+    if (!with_full) {
+      if ((e = hipMalloc(&f.post_rowc, n_rows_last * sizeof(UTab))) != hipSuccess) return fail(e, "post row constants");
+      hipLaunchKernelGGL(ntt_pow_scaled_table_kernel, grid(n_rows_last), dim3(256), 0, st, f.post_rowc, *post_g, post_c ? *post_c : Fr::one(), n_rows_last);
+    }
+  } else if (post_c && !with_full) {
+    const uint64_t nB = 1ull << T->h;
+    if ((e = hipMalloc(&f.tw_b_scaled, nB * sizeof(UTab))) != hipSuccess) return fail(e, "scaled twiddles");
+    hipLaunchKernelGGL(ntt_pow_scaled_table_kernel, grid(nB), dim3(256), 0, st, f.tw_b_scaled, omega, *post_c, nB);
   }
-  hipLaunchKernelGGL(ntt_full_folded_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, f.full, T->A, T->B, T->h, log_s, cnt,
-                     Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpre ? Tpre->h : 0u, Tpost ? Tpost->A : nullptr,
-                     Tpost ? Tpost->B : nullptr, Tpost ? Tpost->h : 0u, post_cu, post_c != nullptr ? 1 : 0);
+  if (with_full) {
+    if ((e = hipMalloc(&f.full, cnt * sizeof(UTab))) != hipSuccess) return fail(e, "full");
+    hipLaunchKernelGGL(ntt_full_folded_kernel, grid(cnt), dim3(256), 0, st, f.full, T->A, T->B, T->h, log_s, cnt,
+                       Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpre ? Tpre->h : 0u, Tpost ? Tpost->A : nullptr,
+                       Tpost ? Tpost->B : nullptr, Tpost ? Tpost->h : 0u, post_cu, post_c != nullptr ? 1 : 0);
+  }
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");   // one-time: the table may be used from other streams later
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");   // one-time: the tables may be used from other streams later
   T->folded.push_back(f);
   *out = f;
   return 0;
@@ -908,6 +952,8 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   // env MI355ZK_NTT_NO_FOLD: the separate products of rounds 1-4, for the A/B
   static const bool no_fold = std::getenv("MI355ZK_NTT_NO_FOLD") != nullptr;
   const bool fold = full_tw && !no_fold && (pre_g || post_c || post_g);
+  // ... and from 2^21 on (no full table; every pass a full tile of the wave-local kernel) the small tables of the same split
+  const bool fold_big = !full_tw && R >= 2 && log_n >= 21 && !no_fold && (pre_g || post_c || post_g);
   rc = build_pow_tables(st, log_n, omega, true, b, R, &T, (full_tw && !fold) ? b[1] : 0);
   if (rc) return rc;
   PowTables* Tpre = nullptr;
@@ -916,7 +962,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   if (post_g) { rc = build_pow_tables(st, log_n, *post_g, false, nullptr, 0, &Tpost); if (rc) return rc; }
   const TwU post_cu = post_c ? to_tw(*post_c) : (post_g ? to_tw(Fr::one()) : TwU{FrU::zero(), FrU::zero()});   // (neither: post == 3 multiplies by nothing)
   PowTables::Folded F;
-  if (fold) { rc = build_folded(st, log_n, omega, T, Tpre, Tpost, pre_g, post_c, post_cu, post_g, b[0], b[1], &F); if (rc) return rc; }
+  if (fold || fold_big) { rc = build_folded(st, log_n, omega, T, Tpre, Tpost, pre_g, post_c, post_cu, post_g, b, R, fold, &F); if (rc) return rc; }
   const UTab* k_full = fold ? F.full : T->full;
   const UTab* k_preA = fold ? F.pre_rows : (Tpre ? Tpre->A : nullptr);
   const UTab* k_preB = (!fold && Tpre) ? Tpre->B : nullptr;
@@ -1058,11 +1104,25 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     const bool wl_kernel = r4 && !no_wl && b[p] >= 8 && (uint64_t)P.g * np == 4ull * threads;
     static const bool no_stage_fold = std::getenv("MI355ZK_NTT_NO_STAGE_FOLD") != nullptr;
     const UTab* k_preA_p = k_preA;
+    const UTab* k_preB_p = k_preB;
+    const UTab* k_postA_p = k_postA;
+    const UTab* k_postB_p = k_postB;
+    const UTab* k_twB_p = T->B;
     if (p == 0 && Tpre && fold && wl_kernel && !no_stage_fold) { P.pre = 3; k_preA_p = F.pre_stages; }
+    if (fold_big && wl_kernel) {
+      if (p == 0 && Tpre) { P.pre = 4; k_preA_p = F.pre_stages; k_preB_p = F.pre_cols; }
+      if (p == R - 1 && Tpost) { P.post = 5; k_postA_p = F.post_rows; k_postB_p = F.post_rowc; }
+    }
+    // a transform scaled by post_c alone: the pass before the last multiplies it in with its twiddle, the last pass by nothing
+    // (decided for both passes together: the last pass must be able to drop the product whichever kernel runs it -- post == 3 is in both)
+    if (fold_big && post_c && !Tpost) {
+      if (p == R - 2) k_twB_p = F.tw_b_scaled;
+      if (p == R - 1) P.post = 3;
+    }
 #define ZK_NTT_LAUNCH_WL(L)                                                                                                                \
   case L:                                                                                                                                  \
     hipLaunchKernelGGL((ntt_pass_wl_kernel<L>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A,      \
-                       T->B, k_preA_p, k_preB, k_postA, k_postB,    \
+                       k_twB_p, k_preA_p, k_preB_p, k_postA_p, k_postB_p,    \
                        post_cu, k_full);                                                                                                  \
     break;
     if (wl_kernel) {
@@ -1075,11 +1135,11 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
   case L:                                                                                                                                  \
     if (r4)                                                                                                                                \
       hipLaunchKernelGGL((ntt_pass_kernel<L, true>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
-                         T->B, k_preA, k_preB, k_postA, k_postB,  \
+                         k_twB_p, k_preA, k_preB, k_postA, k_postB,  \
                          post_cu, k_full);                                                                                                \
     else                                                                                                                                   \
       hipLaunchKernelGGL((ntt_pass_kernel<L, false>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
-                         T->B, k_preA, k_preB, k_postA, k_postB,  \
+                         k_twB_p, k_preA, k_preB, k_postA, k_postB,  \
                          post_cu, k_full);                                                                                                \
     break;
     switch (b[p]) {

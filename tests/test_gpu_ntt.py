@@ -111,6 +111,20 @@ def test_large_transforms_roundtrip_and_halve(zk, worker, log_n):
     assert torch.equal(half.coeffs, f[0::2].contiguous())
 
 
+@pytest.mark.parametrize("log_n,op", [(21, "ifft"), (21, "coset_fft"), (21, "icoset_fft"), (22, "coset_fft"), (22, "icoset_fft"), (23, "ifft"),
+                                      (23, "coset_fft"), (23, "icoset_fft"), (24, "icoset_fft"), (25, "coset_fft"), (25, "icoset_fft"), (25, "ifft")])
+def test_scaled_transforms_without_a_full_table_match_oracle(zk, worker, log_n, op):
+    """(round 5) From 2^21 on there is no full inter-pass table; the scale factors of ifft / coset_fft / icoset_fft are folded into small
+    tables: the first pass's butterfly twiddles carry the row part of g^i (odd row lengths at 2^21 / 2^25: the lone stage 0 has a twiddle then)
+    and one product the column part; the last pass multiplies by (ginv^stride)^k and a per-row constant; minv alone rides on the twiddle
+    of the pass before the last.  Whole arrays against the oracle."""
+    a = inputs.random_fr_mont(1 << log_n, seed=500 + log_n)
+    want = O.fr_domain_op(a, log_n, op, log_cpus=3).reshape(-1, 4)
+    dom = zk.EvaluationDomain.from_coeffs(a)
+    getattr(dom, op)(worker)
+    assert np.array_equal(dom.into_coeffs(), want)
+
+
 @pytest.mark.parametrize("op", ["ifft", "coset_fft"])
 def test_2e24_three_pass_uneven_split_matches_oracle(zk, worker, op):
     """2^24 elements (512 MiB): three passes with an uneven digit split, the fused scalings on the first / last pass; all
