@@ -192,6 +192,18 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
             L.mi355zk_prof_get(b"ntt_pass", C.byref(ms), C.byref(cnt))
             if cnt.value:
                 pass_ms, passes = ms.value / cnt.value, cnt.value / 21.0
+    # (round 5) the prover's shape (prover.rs:217-241): a, b and c through ifft and coset_fft -- three independent transforms per operation,
+    # one launch per pass over all three (mi355zk_bn254_fr_domain_op_batch_dev); per transform
+    doms3 = [zk.EvaluationDomain(d.clone(), log_n) for _ in range(3)]
+    for op in ("ifft", "coset_fft"):
+        fn = getattr(zk.EvaluationDomain, op + "_many")
+        gc.collect()
+        t_warm = time.perf_counter() + 0.04
+        while time.perf_counter() < t_warm:
+            fn(worker, doms3)
+        dt3, _ = _timed(lambda: fn(worker, doms3), 20, collect=False)
+        ntt[op]["ms_per_transform_in_a_batch_of_3"] = round(dt3 / 3 * 1e3, 4)
+    del doms3
     achieved = 64 * n / (pass_ms * 1e-3) / 1e9 if pass_ms else None
     entry = {"metric": "2^%d-element BN254 Fr NTT (EvaluationDomain fft / ifft / coset_fft), in place in HBM" % log_n, **ntt,
              "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,

@@ -214,6 +214,12 @@ int mi355zk_bn254_fr_icoset_fft(uint64_t *a, uint32_t log_n);
 /* device-resident variants: asynchronous on `stream` (no host synchronisation). */
 int mi355zk_bn254_fr_ntt_dev(void *d_a, uint32_t log_n, const uint64_t omega[4], void *stream);
 int mi355zk_bn254_fr_domain_op_dev(void *d_a, uint32_t log_n, int op, void *stream);
+/* (round 5) The same EvaluationDomain operation on `batch` (1 .. 64) DISTINCT device arrays of 2^log_n elements each, in place -- what
+ * prover.rs:217-241 does to a, b and c one after the other (ifft, then coset_fft).  d_arrays: a HOST array of `batch` device pointers.
+ * Results are those of `batch` calls of mi355zk_bn254_fr_domain_op_dev, byte for byte; every pass is ONE launch over the tiles of all
+ * the arrays, so that one transform's loads and stores run under another's butterflies (2^20: 0.105 -> 0.087 ms per transform).
+ * 3 = a null or repeated pointer, batch out of range, unknown op. */
+int mi355zk_bn254_fr_domain_op_batch_dev(void *const *d_arrays, uint32_t batch, uint32_t log_n, int op, void *stream);
 /* the domain constants themselves (Montgomery form), for callers that keep their own EvaluationDomain */
 int mi355zk_bn254_fr_domain_constants(uint32_t log_n, uint64_t omega[4], uint64_t omegainv[4], uint64_t geninv[4], uint64_t minv[4]);
 

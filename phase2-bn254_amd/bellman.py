@@ -306,6 +306,43 @@ class EvaluationDomain:
         if rc != 0:
             raise DeviceError(f"mi355zk NTT failed rc={rc}")
 
+    @staticmethod
+    def _op_many(domains, op: int):
+        """The same operation on several device-resident domains of one size (prover.rs:217-241: a, b, c): one launch per pass over all of
+        them (mi355zk_bn254_fr_domain_op_batch_dev) -- the results are those of the separate calls, byte for byte."""
+        domains = list(domains)
+        if not domains:
+            return
+        d0 = domains[0]
+        if len(domains) == 1 or not all(_is_torch(d.coeffs) and d.coeffs.is_cuda and d.exp == d0.exp and d.coeffs.device == d0.coeffs.device for d in domains):
+            for d in domains:
+                d._op(op)
+            return
+        import torch
+
+        ptrs = (C.c_void_p * len(domains))(*[d.coeffs.data_ptr() for d in domains])
+        assert all(d.coeffs.is_contiguous() for d in domains)
+        with torch.cuda.device(d0.coeffs.device):
+            rc = _lib.load().mi355zk_bn254_fr_domain_op_batch_dev(ptrs, len(domains), d0.exp, op, _stream_ptr())
+        if rc != 0:
+            raise DeviceError(f"mi355zk batched NTT failed rc={rc}")
+
+    @staticmethod
+    def fft_many(worker: Worker, domains):
+        EvaluationDomain._op_many(domains, _lib.OP_FFT)
+
+    @staticmethod
+    def ifft_many(worker: Worker, domains):
+        EvaluationDomain._op_many(domains, _lib.OP_IFFT)
+
+    @staticmethod
+    def coset_fft_many(worker: Worker, domains):
+        EvaluationDomain._op_many(domains, _lib.OP_COSET_FFT)
+
+    @staticmethod
+    def icoset_fft_many(worker: Worker, domains):
+        EvaluationDomain._op_many(domains, _lib.OP_ICOSET_FFT)
+
     def fft(self, worker: Worker):  # domain.rs:154
         self._op(_lib.OP_FFT)
 

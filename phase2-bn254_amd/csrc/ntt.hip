@@ -67,6 +67,15 @@ struct NttPassParams {
   uint32_t post;            // last pass: 1 = multiply by post_c; 2 = by post_c * ginv^k (postA/postB, split post_h); 3 = by nothing; 4 = row output k *= postA[k]; 5 = that, and *= postB[first output index of the row]
   uint32_t post_h;
   uint32_t xcd_pair;        // 1: tiles 2j and 2j + 1 run on the same XCD, one dispatch round apart (see the kernel)
+  // (round 5) batch > 1: ONE launch runs this pass of `batch` independent transforms of the same size and kind: workgroup ids
+  // [t * tiles, (t + 1) * tiles) belong to transform t, whose arrays are NttBatch::in[t] / out[t]
+  uint32_t batch;
+  uint64_t tiles;
+};
+constexpr uint32_t NTT_MAX_BATCH = 8;
+struct NttBatch {
+  const Fr* in[NTT_MAX_BATCH];
+  Fr* out[NTT_MAX_BATCH];
 };
 
 // table entry (round 4): a twiddle as the PLAIN canonical integer w on nine 29-bit limbs followed by wq = floor(w * 2^261 / p) --
@@ -175,7 +184,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
                                                               const UTab* __restrict__ roots, const UTab* __restrict__ twA,
                                                               const UTab* __restrict__ twB, const UTab* __restrict__ preA,
                                                               const UTab* __restrict__ preB, const UTab* __restrict__ postA,
-                                                              const UTab* __restrict__ postB, TwU post_c, const UTab* __restrict__ twF) {
+                                                              const UTab* __restrict__ postB, TwU post_c, const UTab* __restrict__ twF, NttBatch BP) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr uint32_t np = 1u << LOG_NP;
   // twiddle-one products are skipped in stages 0 .. SKIP_MAX: rows longer than 2^10 give up stage 2 (a skipped stage doubles the
@@ -188,6 +197,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fr* __restr
   // the neighbouring tiles.  Workgroup ids go round the eight XCDs, so neighbours would sit behind different L2s; instead the 32 tiles
   // an XCD runs at a time (ids b + 8k) are made NEIGHBOURS, so that the XCD's L2 sees kilobyte runs.
   uint64_t tile = blockIdx.x;
+  if (P.batch > 1) {                                   // (uniform: scalar loads of the transform's two pointers from the kernel arguments)
+    const uint32_t bt = (uint32_t)(tile / P.tiles);
+    tile -= (uint64_t)bt * P.tiles;
+    in = BP.in[bt];
+    out = BP.out[bt];
+  }
   if (P.xcd_pair == 1) tile = (tile & ~15ull) | ((tile & 7ull) << 1) | ((tile >> 3) & 1ull);
   else if (P.xcd_pair == 5) tile = (tile & ~255ull) | ((tile & 7ull) << 5) | ((tile >> 3) & 31ull);  // 32 neighbours per XCD: what it runs at a time
   const uint64_t hi = tile / P.tiles_lo, lo = tile % P.tiles_lo;
@@ -409,7 +424,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
                                                                  const UTab* __restrict__ roots, const UTab* __restrict__ twA,
                                                                  const UTab* __restrict__ twB, const UTab* __restrict__ preA,
                                                                  const UTab* __restrict__ preB, const UTab* __restrict__ postA,
-                                                                 const UTab* __restrict__ postB, TwU post_c, const UTab* __restrict__ twF) {
+                                                                 const UTab* __restrict__ postB, TwU post_c, const UTab* __restrict__ twF, NttBatch BP) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   static_assert(LOG_NP >= 8, "full tiles of rows of at least 256 elements");
   constexpr uint32_t np = 1u << LOG_NP;
@@ -419,6 +434,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_wl_kernel(const Fr* __re
   const uint32_t G = P.g, log_g = 31u - (uint32_t)__clz(G);
   const uint32_t elems = G * np;                        // == 4 * blockDim.x
   uint64_t tile = blockIdx.x;
+  if (P.batch > 1) {
+    const uint32_t bt = (uint32_t)(tile / P.tiles);
+    tile -= (uint64_t)bt * P.tiles;
+    in = BP.in[bt];
+    out = BP.out[bt];
+  }
   if (P.xcd_pair == 1) tile = (tile & ~15ull) | ((tile & 7ull) << 1) | ((tile >> 3) & 1ull);
   else if (P.xcd_pair == 5) tile = (tile & ~255ull) | ((tile & 7ull) << 5) | ((tile >> 3) & 31ull);
   const uint64_t hi = tile / P.tiles_lo, lo = tile % P.tiles_lo;
@@ -916,12 +937,30 @@ static TwU to_tw(const Fr& x) {
 
 // d_a: 2^log_n Fr elements on the current device, in place:
 //   a[i] *= pre_g^i (if pre_g)  ->  X[k] = sum_i a[i] * omega^(i*k)  ->  X[k] *= post_c * post_g^k (if given).
+int ntt_run_batch(Fr* const* d_arrays, uint32_t batch, uint32_t log_n, const Fr& omega, const Fr* pre_g, const Fr* post_c, const Fr* post_g, hipStream_t st);
 int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, const Fr* post_c, const Fr* post_g, hipStream_t st) {
+  return ntt_run_batch(&d_a, 1, log_n, omega, pre_g, post_c, post_g, st);
+}
+
+// (round 5) `batch` (1 .. NTT_MAX_BATCH) independent transforms of the same size and kind (prover.rs:217-241 runs ifft and coset_fft on a, b and
+// c), every pass ONE launch over all their tiles.  Why: a 2^20 pass is 512 workgroups on 512 workgroup slots -- every CU loads, then computes,
+// then stores, and the load and store phases (~15 of a pass's 47 - 55 us) hide behind nothing.  With the tiles of the next transform queued in
+// the same launch a CU starts loading them while its other workgroup still computes: 2^20 fft 0.105 -> 0.087 ms per transform for batch = 2 .. 3
+// (tools/exp_ntt_streams.py measured the same with one stream per transform: profiles/r05_ntt_batch.txt).
+int ntt_run_batch(Fr* const* d_arrays, uint32_t batch, uint32_t log_n, const Fr& omega, const Fr* pre_g, const Fr* post_c, const Fr* post_g, hipStream_t st) {
+  if (batch == 0 || batch > NTT_MAX_BATCH || d_arrays == nullptr) return ZK_ERR_BAD_ARGS;
+  for (uint32_t t = 0; t < batch; ++t)
+    if (d_arrays[t] == nullptr) return ZK_ERR_BAD_ARGS;
   if (log_n == 0) {
     // single element: X[0] = a[0] * post_c
     if (post_c == nullptr) return 0;
-    return ntt_scale(d_a, 0, *post_c, nullptr, st);
+    for (uint32_t t = 0; t < batch; ++t) {
+      int rc0 = ntt_scale(d_arrays[t], 0, *post_c, nullptr, st);
+      if (rc0) return rc0;
+    }
+    return 0;
   }
+  Fr* const d_a = d_arrays[0];
   if (log_n > 30) return ZK_ERR_BAD_ARGS;
   const uint64_t n = 1ull << log_n;
   // factor the index: R passes of b[p] bits, b[0] most significant digit (DESIGN.md "NTT")
@@ -990,7 +1029,7 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       }
     }
     ScratchBuf& sb = g_scratch[std::make_pair(dev, st)];
-    const size_t scratch_bytes = n * sizeof(Fr);
+    const size_t scratch_bytes = n * sizeof(Fr) * batch;
     if (sb.bytes < scratch_bytes) {
       if (sb.p) {
         ZK_HIP(hipStreamSynchronize(st));  // earlier passes on this stream may still read the old buffer
@@ -1031,6 +1070,11 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     else if (p == 0) { src = d_a; dst = scratch; }
     else if (p == R - 1) { src = scratch; dst = d_a; }
     else { src = scratch; dst = scratch; }
+    NttBatch BP{};
+    for (uint32_t t = 0; t < batch; ++t) {
+      BP.in[t] = (src == d_a) ? d_arrays[t] : scratch + (uint64_t)t * n;
+      BP.out[t] = (dst == d_a) ? d_arrays[t] : scratch + (uint64_t)t * n;
+    }
     uint64_t tiles;
     if (p < R - 1 || R == 1) {
       // columns: G adjacent low positions share a tile
@@ -1071,6 +1115,8 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
       P.tw_mul = 0;
       tiles = (N1 / G) * mid;
     }
+    P.batch = batch;
+    P.tiles = tiles;
     static const bool no_pair = std::getenv("MI355ZK_NTT_NOPAIR") != nullptr;
     static const char* pair_env = std::getenv("MI355ZK_NTT_PAIR");
     static const bool pair_all = std::getenv("MI355ZK_NTT_PAIR_ALL") != nullptr;
@@ -1121,9 +1167,9 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
     }
 #define ZK_NTT_LAUNCH_WL(L)                                                                                                                \
   case L:                                                                                                                                  \
-    hipLaunchKernelGGL((ntt_pass_wl_kernel<L>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A,      \
+    hipLaunchKernelGGL((ntt_pass_wl_kernel<L>), dim3((unsigned)(tiles * batch)), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A,      \
                        k_twB_p, k_preA_p, k_preB_p, k_postA_p, k_postB_p,    \
-                       post_cu, k_full);                                                                                                  \
+                       post_cu, k_full, BP);                                                                                                  \
     break;
     if (wl_kernel) {
       switch (b[p]) {
@@ -1134,13 +1180,13 @@ int ntt_run_scaled(Fr* d_a, uint32_t log_n, const Fr& omega, const Fr* pre_g, co
 #define ZK_NTT_LAUNCH(L)                                                                                                                   \
   case L:                                                                                                                                  \
     if (r4)                                                                                                                                \
-      hipLaunchKernelGGL((ntt_pass_kernel<L, true>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
+      hipLaunchKernelGGL((ntt_pass_kernel<L, true>), dim3((unsigned)(tiles * batch)), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
                          k_twB_p, k_preA, k_preB, k_postA, k_postB,  \
-                         post_cu, k_full);                                                                                                \
+                         post_cu, k_full, BP);                                                                                                \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((ntt_pass_kernel<L, false>), dim3((unsigned)tiles), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
+      hipLaunchKernelGGL((ntt_pass_kernel<L, false>), dim3((unsigned)(tiles * batch)), dim3(threads), lds_bytes, st, src, dst, P, T->roots[b[p]], T->A, \
                          k_twB_p, k_preA, k_preB, k_postA, k_postB,  \
-                         post_cu, k_full);                                                                                                \
+                         post_cu, k_full, BP);                                                                                                \
     break;
     switch (b[p]) {
       ZK_NTT_LAUNCH(1) ZK_NTT_LAUNCH(2) ZK_NTT_LAUNCH(3) ZK_NTT_LAUNCH(4) ZK_NTT_LAUNCH(5) ZK_NTT_LAUNCH(6) ZK_NTT_LAUNCH(7) ZK_NTT_LAUNCH(8)

@@ -181,12 +181,10 @@ def create_proof(pool: Worker, params: Parameters, prover: ProvingAssignment, r:
     a = EvaluationDomain.from_coeffs(prover.a)
     b = EvaluationDomain.from_coeffs(prover.b)
     c = EvaluationDomain.from_coeffs(prover.c)
-    a.ifft(pool)
-    a.coset_fft(pool)
-    b.ifft(pool)
-    b.coset_fft(pool)
-    c.ifft(pool)
-    c.coset_fft(pool)
+    # (prover.rs:220-231 transforms a, b and c one after the other; the three are independent, and one launch per pass over all three lets
+    # one transform's loads and stores run under another's butterflies -- same bytes)
+    EvaluationDomain.ifft_many(pool, (a, b, c))
+    EvaluationDomain.coset_fft_many(pool, (a, b, c))
     a.mul_assign(pool, b)
     del b
     a.sub_assign(pool, c)

@@ -137,6 +137,37 @@ def test_2e24_three_pass_uneven_split_matches_oracle(zk, worker, op):
     assert np.array_equal(dom.into_coeffs(), want)
 
 
+@pytest.mark.parametrize("log_n,batch", [(0, 2), (3, 3), (10, 3), (12, 9), (16, 3), (20, 3), (20, 2), (21, 2)])
+def test_batched_domain_ops_match_oracle(zk, worker, log_n, batch):
+    """(round 5) mi355zk_bn254_fr_domain_op_batch_dev: the same operation on `batch` arrays, one launch per pass over all of them (prover.rs:217-241
+    transforms a, b and c one after the other).  Every array against the oracle, for the four operations; nine arrays cross the eight-per-launch chunk."""
+    import torch
+
+    for op in OPS:
+        hosts = [inputs.random_fr_mont(1 << log_n, seed=900 + 10 * log_n + t) for t in range(batch)]
+        doms = [zk.EvaluationDomain(torch.from_numpy(h.view(np.int64)).cuda(), log_n) for h in hosts]
+        getattr(zk.EvaluationDomain, op + "_many")(worker, doms)
+        for h, d in zip(hosts, doms):
+            want = O.fr_domain_op(h, log_n, op, log_cpus=3 if log_n >= 20 else 31).reshape(-1, 4)
+            assert np.array_equal(d.coeffs.cpu().numpy().view(np.uint64), want), (op, log_n)
+
+
+def test_batched_domain_op_rejects_bad_batches(zk, worker):
+    import ctypes as C
+
+    import torch
+
+    L = zk.lib.load()
+    a = torch.zeros((16, 4), dtype=torch.int64, device="cuda")
+    two = (C.c_void_p * 2)(a.data_ptr(), a.data_ptr())
+    assert L.mi355zk_bn254_fr_domain_op_batch_dev(two, 2, 4, zk.lib.OP_FFT, None) == 3        # one array twice
+    nul = (C.c_void_p * 2)(a.data_ptr(), None)
+    assert L.mi355zk_bn254_fr_domain_op_batch_dev(nul, 2, 4, zk.lib.OP_FFT, None) == 3
+    assert L.mi355zk_bn254_fr_domain_op_batch_dev(two, 0, 4, zk.lib.OP_FFT, None) == 3
+    one = (C.c_void_p * 1)(a.data_ptr())
+    assert L.mi355zk_bn254_fr_domain_op_batch_dev(one, 1, 4, 99, None) == 3
+
+
 def test_divide_by_z_on_coset_and_z(zk, worker):
     """domain.rs:207-234: z(tau) = tau^m - 1; divide_by_z_on_coset multiplies every coefficient by z(g)^-1, g = 7."""
     import torch
