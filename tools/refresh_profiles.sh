@@ -36,6 +36,11 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_nf -- python $R/tools/bench_ntt
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_nw -- python $R/tools/bench_ntt.py --log-n 20 > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/p_nf -name "*.db" | head -1) --pmc > $O/ntt20_pmc_fetch.txt
 python $R/tools/rocpd_summary.py $(find /tmp/p_nw -name "*.db" | head -1) --pmc > $O/ntt20_pmc_write.txt
+# round 5: per-pass durations of the four operations, transforms in batches, transforms on separate streams
+LOGN=20 bash $R/tools/ntt_pass_split.sh > /dev/null 2>&1; cp $R/gpurun_out/ntt_pass_split.txt $O/ntt_pass_split.txt
+for ln in 16 18 20; do timeout 300 python $R/tools/bench_ntt_batch.py --log-n $ln; done > $O/ntt_batch.json 2>/dev/null
+{ timeout 300 python $R/tools/exp_ntt_streams.py --k 2; timeout 300 python $R/tools/exp_ntt_streams.py --k 3; } > $O/ntt_streams.json 2>/dev/null
+{ for ln in 20 22 24; do MI355ZK_NTT_NO_FOLD=1 timeout 300 python $R/tools/bench_ntt.py --log-n $ln; done; } > $O/ntt_no_fold.json 2>/dev/null
 timeout 400 python $R/tools/bench_skew.py --log-n 26 --iters 2 > $O/skew_2e26.json 2>/dev/null
 timeout 400 $B --steps 5 --warmup 1 --bases tau --no-cpu-baseline --no-secondary > $O/bench_n1_tau.json 2>/dev/null
 $R/tools/bin/ubench_valu > $O/ubench_valu.txt 2>&1

@@ -66,6 +66,12 @@ if os.path.exists(os.path.join(SRC, "ntt20_pmc_fetch.txt")):
               open(os.path.join(DST, "latest_pmc_ntt.json"), "w"), indent=1)
     print(open(os.path.join(DST, "latest_pmc_ntt.json")).read())
 
+# ---- round 5 additions
+for src, dst, hdr in (("ntt_pass_split.txt", "ntt_pass_split.txt", "# bash tools/ntt_pass_split.sh: rocprofv3 --kernel-trace over tools/bench_ntt.py --ops <op>, the pass launches by their position in the transform (last 40 transforms;\n# these run with the library's per-pass HIP events on: the gaps are longer than in the timed loop)\n"),
+                      ("ntt_batch.json", "ntt_batch.json", None), ("ntt_streams.json", "ntt_streams.json", None),
+                      ("ntt_no_fold.json", "ntt_no_fold.json", None)):
+    if os.path.exists(os.path.join(SRC, src)): put(src, dst, hdr)
+
 # ---- round 4 additions
 for src, dst, hdr in (("ab_quad.txt", "ab_quad.txt", "# bash tools/ab_quad.sh: the reduce tails on quad additions (default) against one lane per addition (MI355ZK_MSM_QUAD=0), same box, same process order;\n# bench.py --log-n L --steps 30 --warmup 10 (ms per call, msm_reduce / msm_accumulate by HIP events, result limb) and tools/bench_g2.py\n"),
                       ("multi_device_2e26.json", "multi_device_2e26.json", None),
