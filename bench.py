@@ -170,7 +170,7 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
     host = inputs.random_fr_mont(n, seed=5)
     d = torch.from_numpy(host.view(np.int64)).to(dev)
     ntt = {}
-    pass_ms, passes = None, None
+    pass_ms, passes, pass_ms_events_per_launch = None, None, None
     for op in ("fft", "ifft", "coset_fft"):
         dom = zk.EvaluationDomain(d.clone(), log_n)
         # Timed WITHOUT the library's per-kernel HIP events and after a warm-up: rounds 1-3 recorded two events per pass inside the
@@ -192,6 +192,22 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
             L.mi355zk_prof_get(b"ntt_pass", C.byref(ms), C.byref(cnt))
             if cnt.value:
                 pass_ms, passes = ms.value / cnt.value, cnt.value / 21.0
+            # (round 5) the library's per-pass events bracket EVERY launch: two event records around a 50-us kernel put ~6 us on it (61.9 us here
+            # against 51.7 us per launch in rocprofv3's kernel trace, profiles/r05_final_ntt_pass_split.txt).  The figure the roofline uses
+            # is one pair of HIP events on the stream the passes run on (torch's current stream) around 40 back-to-back transforms, divided by
+            # their launches: the launch gaps (~2 us each) stay inside, the event overhead does not.
+            if passes:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with _no_gc(False):
+                    t_warm = time.perf_counter() + 0.04   # (the instrumented loop above collected garbage first: clocks down again)
+                    while time.perf_counter() < t_warm:
+                        dom.fft(worker)
+                    e0.record()
+                    for _ in range(40):
+                        dom.fft(worker)
+                    e1.record()
+                    e1.synchronize()
+                pass_ms_events_per_launch, pass_ms = pass_ms, e0.elapsed_time(e1) / (40 * round(passes))
     # (round 5) the prover's shape (prover.rs:217-241): a, b and c through ifft and coset_fft -- three independent transforms per operation,
     # one launch per pass over all three (mi355zk_bn254_fr_domain_op_batch_dev); per transform
     doms3 = [zk.EvaluationDomain(d.clone(), log_n) for _ in range(3)]
@@ -210,7 +226,8 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                           # a SEPARATE rocprofv3 --pmc pass, hash-locked to ntt.hip + fieldu.hpp (profiles/latest_pmc_ntt.json): null rather than stale
                           "traffic": _ntt_traffic(log_n),
-                          "passes_per_transform": passes, "pass_ms": round(pass_ms, 4) if pass_ms else None,
+                          "passes_per_transform": round(passes) if passes else None, "pass_ms": round(pass_ms, 4) if pass_ms else None,
+                          "pass_ms_with_an_event_pair_per_launch": round(pass_ms_events_per_launch, 4) if pass_ms_events_per_launch else None,
                           "note": "algorithmic 64 B per element per pass (32 B read + 32 B written); the pass is VALU-issue bound (DESIGN.md 3)"}}
     if cpu:
         omega = O.fr_domain(log_n)[0]
@@ -258,11 +275,13 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         for _ in range(25 if group == 1 else 12):
             zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
         iters = 20 if group == 1 else 10
+        plain_calls = []
         with _no_gc(collect=False):
-            t = time.perf_counter()
             for _ in range(iters):
+                t = time.perf_counter()
                 res = zk.multiexp(worker, (b, 0), zk.FullDensity(), sc).wait()
-            dt = (time.perf_counter() - t) / iters   # (no per-kernel events in the timed loop: ~20 event records are 1-2 % of a 2-ms call)
+                plain_calls.append(time.perf_counter() - t)
+            dt = sum(plain_calls) / iters   # (no per-kernel events in the timed loop: ~20 event records are 1-2 % of a 2-ms call)
         L.mi355zk_prof_reset()
         L.mi355zk_prof_enable(1)
         for _ in range(5):
@@ -274,6 +293,7 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
         achieved = bytes_per * n / (acc_ms * 1e-3) / 1e9 if acc_ms else None
         entry = {"metric": "2^%d-point BN254 %s multiexp, FullDensity, bases + exponents resident in HBM" % (log_n, name.upper()),
                  "value": round(n / dt / 1e6, 2), "unit": "Mscalar-mul/s", "ms": round(dt * 1e3, 3),
+                 "ms_min_median_max": [round(sorted(plain_calls)[i] * 1e3, 3) for i in (0, iters // 2, iters - 1)],
                  "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2) if achieved else None,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
                               "kernel_ms": {kk: (round(v, 4) if v is not None else None) for kk, v in kern.items()},
