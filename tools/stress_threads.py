@@ -25,6 +25,15 @@ for log_n in (8, 10, 11, 13, 15):
         def f(x=x, op=op):
             dom = zk.EvaluationDomain.from_coeffs(x.copy()); getattr(dom, op)(worker); return dom.into_coeffs()
         jobs.append((f"{op} 2^{log_n}", f, want))
+for log_n in (9, 12, 14):       # (round 5) three arrays per call: one launch per pass over all of them (mi355zk_bn254_fr_domain_op_batch_dev)
+    xs = [inputs.random_fr_mont(1 << log_n, seed=150 + 10 * log_n + t) for t in range(3)]
+    for op in ("ifft", "coset_fft", "icoset_fft"):
+        want = np.concatenate([O.fr_domain_op(x.copy(), log_n, op).reshape(-1, 4) for x in xs])
+        def fb(xs=xs, op=op, log_n=log_n):
+            doms = [zk.EvaluationDomain(dev(x), log_n) for x in xs]
+            getattr(zk.EvaluationDomain, op + "_many")(worker, doms)
+            return np.concatenate([host(d.coeffs) for d in doms])
+        jobs.append((f"{op}_many 2^{log_n} x 3", fb, want))
 for g, G in ((1, O.G1), (2, O.G2)):
     for n in ((700, 3000) if g == 1 else (300,)):
         b = inputs.bases_progression_cpu(g, n, seed=300 + g + n); s = inputs.random_scalars(n, seed=400 + n)
