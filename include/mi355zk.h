@@ -213,6 +213,13 @@ int mi355zk_bn254_fr_coset_fft(uint64_t *a, uint32_t log_n);
 int mi355zk_bn254_fr_icoset_fft(uint64_t *a, uint32_t log_n);
 /* device-resident variants: asynchronous on `stream` (no host synchronisation). */
 int mi355zk_bn254_fr_ntt_dev(void *d_a, uint32_t log_n, const uint64_t omega[4], void *stream);
+/* (round 5) best_fft with the scalings around it fused in, for ANY factors -- distribute_powers(g) takes any g (domain.rs:176-189); the four
+ * domain operations are this call with the domain's constants:
+ *     a[i] *= pre_g^i   (if pre_g)        X[k] = sum_i a[i] * omega^(i k)        X[k] *= post_c * post_g^k   (each factor if given)
+ * omega: a 2^log_n-th root of unity; all four are Montgomery forms (4 x u64); pre_g / post_c / post_g may be NULL.  Up to 2^20 the
+ * factors live in a per-(omega, factors) copy of the inter-pass twiddle table (at most four per omega are kept; see DESIGN.md, NTT). */
+int mi355zk_bn254_fr_ntt_scaled_dev(void *d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t pre_g[4], const uint64_t post_c[4],
+                                    const uint64_t post_g[4], void *stream);
 int mi355zk_bn254_fr_domain_op_dev(void *d_a, uint32_t log_n, int op, void *stream);
 /* (round 5) The same EvaluationDomain operation on `batch` (1 .. 64) DISTINCT device arrays of 2^log_n elements each, in place -- what
  * prover.rs:217-241 does to a, b and c one after the other (ifft, then coset_fft).  d_arrays: a HOST array of `batch` device pointers.

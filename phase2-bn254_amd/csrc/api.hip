@@ -2672,6 +2672,18 @@ int mi355zk_bn254_fr_ntt_dev(void* d_a, uint32_t log_n, const uint64_t omega[4],
     return ntt_run((Fr*)d_a, log_n, w, (hipStream_t)stream);
   });
 }
+int mi355zk_bn254_fr_ntt_scaled_dev(void* d_a, uint32_t log_n, const uint64_t omega[4], const uint64_t pre_g[4], const uint64_t post_c[4],
+                                    const uint64_t post_g[4], void* stream) {
+  return abi_guard([&]() -> int {
+    if (!d_a || !omega || log_n > 28) return ZK_ERR_BAD_ARGS;
+    Fr w, g, c, h;
+    std::memcpy(&w, omega, 32);
+    if (pre_g) std::memcpy(&g, pre_g, 32);
+    if (post_c) std::memcpy(&c, post_c, 32);
+    if (post_g) std::memcpy(&h, post_g, 32);
+    return ntt_run_scaled((Fr*)d_a, log_n, w, pre_g ? &g : nullptr, post_c ? &c : nullptr, post_g ? &h : nullptr, (hipStream_t)stream);
+  });
+}
 int mi355zk_bn254_fr_domain_op_dev(void* d_a, uint32_t log_n, int op, void* stream) {
   return abi_guard([&]() -> int {
     if (!d_a || log_n > 28) return ZK_ERR_BAD_ARGS;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mi355zk_bn254_fr_coset_fft": (_i, [_vp, _u32]),
     "mi355zk_bn254_fr_icoset_fft": (_i, [_vp, _u32]),
     "mi355zk_bn254_fr_ntt_dev": (_i, [_vp, _u32, _vp, _vp]),
+    "mi355zk_bn254_fr_ntt_scaled_dev": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "mi355zk_bn254_fr_domain_op_dev": (_i, [_vp, _u32, _i, _vp]),
     "mi355zk_bn254_fr_domain_op_batch_dev": (_i, [C.POINTER(C.c_void_p), _u32, _u32, _i, _vp]),
     "mi355zk_bn254_fr_domain_constants": (_i, [_u32, _vp, _vp, _vp, _vp]),

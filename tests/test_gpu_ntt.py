@@ -168,6 +168,63 @@ def test_batched_domain_op_rejects_bad_batches(zk, worker):
     assert L.mi355zk_bn254_fr_domain_op_batch_dev(one, 1, 4, 99, None) == 3
 
 
+def _mont(v):
+    import bn254_model as M
+
+    return np.array(M.to_limbs(v * (1 << 256) % M.R_ORDER), dtype=np.uint64)
+
+
+def _powers(g, n):
+    """[g^0 .. g^(n-1)] as Montgomery rows, by doubling through the oracle's field product"""
+    import bn254_model as M
+
+    p = _mont(1).reshape(1, 4)
+    m = 1
+    while m < n:
+        step = np.tile(_mont(pow(g, m, M.R_ORDER)), (m, 1))
+        p = np.concatenate([p, O.fe_mul_many(O.FR, p, step).reshape(-1, 4)])
+        m *= 2
+    return p[:n]
+
+
+@pytest.mark.parametrize("log_n", [3, 10, 12, 16, 20, 21])
+def test_scaled_transform_with_arbitrary_factors_matches_oracle(zk, worker, log_n):
+    """(round 5) mi355zk_bn254_fr_ntt_scaled_dev: a[i] *= g^i, X = NTT_omega(a), X[k] *= c * h^k for ANY g, c, h (distribute_powers takes any g:
+    domain.rs:176-189) against the oracle's serial_fft with the scalings done by its field product.  Seven factor sets on ONE root: the
+    per-root store of folded tables holds four, so the later ones evict the earlier ones, and the first set is run again at the end."""
+    import ctypes as C
+
+    import bn254_model as M
+    import torch
+
+    L = zk.lib.load()
+    n = 1 << log_n
+    r = M.R_ORDER
+    omega = pow(M.FR_ROOT_OF_UNITY, 1 << (M.FR_S - log_n), r)
+    a = inputs.random_fr_mont(n, seed=1300 + log_n)
+    rng = np.random.default_rng(1400 + log_n)
+    rnd = lambda: int.from_bytes(rng.bytes(32), "little") % (r - 2) + 2
+    sets = [(rnd(), None, None), (None, rnd(), None), (None, rnd(), rnd()), (rnd(), rnd(), rnd()), (None, None, rnd()), (rnd(), rnd(), None), (r - 1, 1, r - 1)]
+    if log_n >= 20:
+        sets = sets[:5] if log_n == 20 else sets[2:4]
+    sets = sets + [sets[0]]
+    for g, c, h in sets:
+        x = a
+        if g is not None:
+            x = O.fe_mul_many(O.FR, x, _powers(g, n)).reshape(-1, 4)
+        x = O.fr_serial_fft(x, log_n, _mont(omega)).reshape(-1, 4) if log_n < 20 else O.fr_parallel_fft(x, log_n, _mont(omega), 3).reshape(-1, 4)
+        if h is not None:
+            x = O.fe_mul_many(O.FR, x, _powers(h, n)).reshape(-1, 4)
+        if c is not None:
+            x = O.fe_mul_many(O.FR, x, np.tile(_mont(c), (n, 1))).reshape(-1, 4)
+        d = torch.from_numpy(a.view(np.int64)).cuda()
+        keep = [_mont(v) if v is not None else None for v in (omega, g, c, h)]
+        ptr = lambda k: None if k is None else k.ctypes.data_as(C.c_void_p)
+        rc = L.mi355zk_bn254_fr_ntt_scaled_dev(C.c_void_p(d.data_ptr()), log_n, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), None)
+        assert rc == 0
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), x), (log_n, g is not None, c is not None, h is not None)
+
+
 def test_divide_by_z_on_coset_and_z(zk, worker):
     """domain.rs:207-234: z(tau) = tau^m - 1; divide_by_z_on_coset multiplies every coefficient by z(g)^-1, g = 7."""
     import torch
