@@ -20,10 +20,13 @@ __global__ void __launch_bounds__(256) gather64(const uint4* __restrict__ table,
   }
   if (acc == 0x12345678u) sink[gid & 1023] = acc;
 }
-int main() {
+int main(int argc, char** argv) {
   const size_t max_bytes = 16ull << 30;
   uint4* table = nullptr; uint32_t* sink = nullptr;
-  CK(hipMalloc(&table, max_bytes)); CK(hipMalloc(&sink, 4096));
+  const bool contiguous = argc > 1 && argv[1][0] == 'c';   // `ubench_gather_footprint c`: hipExtMallocWithFlags(hipDeviceMallocContiguous) -- physically contiguous VRAM, large PTE fragments
+  if (contiguous) { CK(hipExtMallocWithFlags((void**)&table, max_bytes, hipDeviceMallocContiguous)); printf("(physically contiguous allocation)\n"); }
+  else CK(hipMalloc(&table, max_bytes));
+  CK(hipMalloc(&sink, 4096));
   CK(hipMemset(table, 1, max_bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const uint32_t lanes = 1u << 24; constexpr int K = 16;
