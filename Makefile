@@ -9,7 +9,7 @@ HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-re
 OBJS := build/ntt.o build/msm_g1.o build/msm_g2.o build/api.o build/field_ops.o build/point_fft.o build/point_fft_g2.o build/codec.o
 HDRS := $(SRC)/field.hpp $(SRC)/mont_mul_gfx950.inc $(SRC)/curve.hpp $(SRC)/fieldu.hpp $(SRC)/curveu.hpp $(SRC)/device_util.hpp $(SRC)/msm_impl.hpp include/mi355zk.h
 
-all: $(PKG)/libmi355zk.so oracle tools/bin/ubench_valu tools/bin/ubench_gather tools/bin/ubench_fieldmul tools/bin/ubench_wave_bucket
+all: $(PKG)/libmi355zk.so oracle tools/bin/ubench_valu tools/bin/ubench_gather tools/bin/ubench_fieldmul tools/bin/ubench_wave_bucket tools/bin/ubench_gather_footprint
 
 # standalone microbenchmarks (instruction issue rates; FETCH_SIZE calibration) used by tools/refresh_profiles.sh
 tools/bin/%: tools/%.hip $(HDRS)

@@ -47,6 +47,7 @@ $R/tools/bin/ubench_valu > $O/ubench_valu.txt 2>&1
 $R/tools/bin/ubench_gather > $O/ubench_gather.txt 2>&1
 $R/tools/bin/ubench_fieldmul > $O/ubench_fieldmul.txt 2>&1
 $R/tools/bin/ubench_wave_bucket > $O/ubench_wave_bucket.txt 2>&1
+$R/tools/bin/ubench_gather_footprint > $O/ubench_gather_footprint.txt 2>&1
 for lm in 16 20 22; do timeout 300 python $R/tools/bench_prover.py --log-m $lm; done > $O/prover.json 2>/dev/null
 { for ln in 19 20 22 23; do timeout 300 python $R/tools/bench_table.py --log-n $ln --iters 10; done; for ln in 16 20 22; do timeout 300 python $R/tools/bench_table.py --group 2 --log-n $ln --iters 8; done; } > $O/table_mode.json 2>/dev/null
 for ln in 16 20; do timeout 200 python $R/tools/bench_skew.py --log-n $ln --iters 10; done > $O/skew_small.json 2>/dev/null
