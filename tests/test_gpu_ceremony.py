@@ -503,3 +503,122 @@ def test_groth16_and_mpc_parameter_files(zk, worker):
         assert np.array_equal(_host(after[k]), vecs[k])
     for k in ("alpha_g1", "beta_g1", "beta_g2", "gamma_g2", "ic"):
         assert np.array_equal(_host(after["vk"][k]), vk[k])
+
+
+def _pack16(limbs16):
+    """(n, k <= 16) tensor of 16-bit values (int64) -> (n, 4) int64 bit patterns of u64 limbs, little-endian"""
+    import torch
+
+    n, k = limbs16.shape
+    out = torch.zeros((n, 4), dtype=torch.int64, device=limbs16.device)
+    for i in range(k):
+        out[:, i // 4] |= limbs16[:, i] << (16 * (i % 4))
+    return out
+
+
+@pytest.mark.parametrize("group,trusted", [(1, 0), (2, 0), (2, 2)])
+def test_config5_qap_evaluation_at_size(zk, worker, group, trusted):
+    """BASELINE config 5, MPCParameters::new on a ~2^20-constraint circuit (phase2/src/parameters.rs:225-294): the per-variable sums
+    a_g1 / b_g1 / b_g2 / ext as ONE CSR-matrix x point-vector product with 2^20 rows over 2^20 Lagrange points and ~3.2 M terms -- thirteen
+    2^18-term chunks of the scalar-multiplication loop, the per-base membership split of G2 (default flags), rows that straddle chunk
+    boundaries.  Circom-like coefficients: 10 % each of 1, r - 1 and 0; one 10^5-term row (the constant ONE of a circuit sits in most
+    constraints); empty rows; an infinity base that several terms name.  Checks:
+      (1) >= 1024 sampled rows + the rows at every chunk boundary + the long row + the rows naming the infinity base against the oracle's
+          mul_assign / add_assign / into_affine, bit exact;
+      (2) EVERY row at once through the linear form  sum_r rho_r out[r] == sum_j (M^T rho)_j bases[j]  with random 24-bit rho_r: both sides
+          by the library's dense_multiexp (parity-tested on its own), M^T rho as exact integers on the device (16-bit limb columns, int64
+          index_add), split S_j = lo_j + 2^240 hi_j so that both exponent vectors are canonical;
+      (3) the host-buffer form over 3 logical devices (row ranges of equal weight) returns the same records."""
+    import ctypes as C
+
+    import torch
+
+    import bench
+
+    G = O.G1 if group == 1 else O.G2
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW)
+    dev = torch.device("cuda", 0)
+    L = zk.lib.load()
+    n_rows = n_bases = 1 << 20
+    inf_base, long_row, long_len = 777, 345_678, 100_000
+    k = bench.gen_scalars(n_bases, 3100 + group, dev)
+    bases = torch.empty((n_bases, 8 * group), dtype=torch.int64, device=dev)
+    fn = L.mi355zk_bn254_g1_batch_mul_dev if group == 1 else L.mi355zk_bn254_g2_batch_mul_dev
+    assert fn(C.c_void_p(bases.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(k.data_ptr()), n_bases, None) == 0
+    bases[inf_base] = 0
+    g_ = torch.Generator(device=dev)
+    g_.manual_seed(3110 + group)
+    lens = torch.randint(0, 7, (n_rows,), device=dev, generator=g_, dtype=torch.int64)
+    lens[long_row] = long_len
+    lens[:3] = 0
+    lens[n_rows - 1] = 0
+    rp = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    rp[1:] = torch.cumsum(lens, 0)
+    nnz = int(rp[-1].item())
+    assert nnz > 12 << 18                                                   # >= 13 chunks of 2^18 terms
+    col = torch.randint(0, n_bases, (nnz,), device=dev, generator=g_, dtype=torch.int64)
+    col[torch.randint(0, nnz, (64,), device=dev, generator=g_)] = inf_base  # terms that name the infinity base
+    cf = bench.gen_scalars(nnz, 3120 + group, dev)
+    kind = torch.randint(0, 10, (nnz,), device=dev, generator=g_)
+    cf[kind == 0] = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=dev)
+    cf[kind == 1] = torch.from_numpy(_limbs(M.R_ORDER - 1).view(np.int64)).to(dev)
+    cf[kind == 2] = 0
+    rp32, col32 = rp.to(torch.int32), col.to(torch.int32)
+    out = zk.ceremony.eval_qap(bases, rp32, col32, cf, trusted_subgroup=bool(trusted))
+    torch.cuda.synchronize()
+
+    # (1) sampled rows against the oracle
+    h_rp = rp.cpu().numpy()
+    rng = np.random.default_rng(3130 + group)
+    boundary_rows = np.searchsorted(h_rp, np.arange(1, nnz >> 18) << 18, side="right") - 1   # the row holding term k * 2^18
+    inf_rows = np.searchsorted(h_rp, torch.nonzero(col == inf_base).flatten().cpu().numpy(), side="right") - 1
+    rows = np.unique(np.concatenate([[0, 1, 2, 3, n_rows - 2, n_rows - 1, long_row - 1, long_row + 1], boundary_rows, boundary_rows + 1, inf_rows,
+                                     rng.integers(0, n_rows, size=1060)]))
+    rows = rows[(rows != long_row) & (rows < n_rows)]
+    assert len(rows) >= 1024
+    h_out = _host(out[torch.from_numpy(rows).to(dev)])
+    zero = np.zeros(8 * group, np.uint64)
+    for i, r_ in enumerate(rows):
+        t0, t1 = int(h_rp[r_]), int(h_rp[r_ + 1])
+        hb, hc = _host(bases[col[t0:t1]]), _host(cf[t0:t1])
+        acc = G.from_affine(zero)
+        for t in range(t1 - t0):
+            acc = G.add(acc, G.mul(G.from_affine(hb[t]), hc[t]))
+        assert np.array_equal(h_out[i], G.to_affine(acc)), int(r_)
+    t0, t1 = int(h_rp[long_row]), int(h_rp[long_row + 1])
+    assert t1 - t0 == long_len
+    want = G.dense_multiexp(_host(bases[col[t0:t1]]), _host(cf[t0:t1]), cpus=8)
+    assert np.array_equal(_host(out[long_row]), G.to_affine(want))
+    assert not _host(out[:3]).any() and not _host(out[n_rows - 1]).any()   # empty rows are the infinity record
+
+    # (2) every row: sum_r rho_r out[r] == sum_j (M^T rho)_j bases[j]
+    rho = torch.randint(1, 1 << 24, (n_rows,), device=dev, generator=g_, dtype=torch.int64)
+    rho_t = torch.repeat_interleave(rho, lens)
+    s16 = torch.zeros((n_bases, 16), dtype=torch.int64, device=dev)
+    c16 = torch.stack([(cf[:, i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(16)], dim=1)
+    s16.index_add_(0, col, c16 * rho_t[:, None])
+    del c16
+    norm = torch.zeros((n_bases, 20), dtype=torch.int64, device=dev)
+    carry = torch.zeros(n_bases, dtype=torch.int64, device=dev)
+    for i in range(20):
+        v = carry + (s16[:, i] if i < 16 else 0)
+        norm[:, i] = v & 0xFFFF
+        carry = v >> 16
+    assert not carry.any()
+    lo, hi = _pack16(norm[:, :15]), _pack16(norm[:, 15:])
+    rho4 = torch.zeros((n_rows, 4), dtype=torch.int64, device=dev)
+    rho4[:, 0] = rho
+    lhs = zk.ceremony.dense_multiexp(out, rho4)
+    rhs = G.add(zk.ceremony.dense_multiexp(bases, lo), G.mul(zk.ceremony.dense_multiexp(bases, hi), _limbs(1 << 240)))
+    assert np.array_equal(G.to_affine(lhs), G.to_affine(rhs))
+
+    # (3) the host-buffer form over three logical devices: the same records
+    if trusted == 0:
+        h_bases, h_cf = _host(bases), _host(cf)
+        h_rp32, h_col32 = rp32.cpu().numpy().view(np.uint32), col32.cpu().numpy().view(np.uint32)
+        zk.Worker(devices=[0, 0, 0])
+        try:
+            got = zk.ceremony.eval_qap_host(h_bases, h_rp32, h_col32, h_cf)
+        finally:
+            zk.Worker(0)
+        assert np.array_equal(got, _host(out))

@@ -92,3 +92,71 @@ def test_point_ifft_matches_oracle_at_2e12(zk, worker, group, trusted):
     want = O.point_domain_op(group, pts, log_n, "ifft")
     got = _run(zk, pts, log_n, 1 | trusted, group=group)
     assert np.array_equal(got, want)
+
+
+def _scalars_to_dev(vals):
+    """list of Python ints (< 2^256) -> (n, 4) int64 device tensor of canonical limbs"""
+    import torch
+
+    buf = b"".join(v.to_bytes(32, "little") for v in vals)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.int64).reshape(-1, 4).copy()).cuda()
+
+
+@pytest.mark.parametrize("group,log_n,trusted", [(1, 16, 0), (1, 20, 0), (2, 16, 0), (2, 16, 2), (2, 18, 0)])
+def test_point_ifft_at_size_on_a_tau_table(zk, worker, group, log_n, trusted):
+    """prepare_phase2's Lagrange conversion (powersoftau/src/bin/prepare_phase2.rs:68-105; bellman/src/group.rs:22-51 under
+    domain.rs:154-173) at the sizes the reference runs it: G1 at 2^16 and 2^20, G2 at 2^16 and 2^18 (plain windows, and the psi split under the
+    caller's promise).  Input: the tau-table v_i = tau^i G; the ifft is then out_j = L_j(tau) G, L_j the Lagrange polynomials of the domain.
+      (1) >= 256 indices against the closed form L_j(tau) = (tau^n - 1) w^j / (n (tau - w^j)) through the oracle's mul + into_affine;
+      (2) sum_j out_j == G (the L_j sum to one) -- through the library's dense_multiexp with unit exponents;
+      (3) EVERY output record in one linear form, independent of the forward point FFT:  sum_j w^(jk) out_j == tau^k G  (row k of the DFT
+          that inverts the ifft), k = 1 and a large odd k, again by dense_multiexp (parity-tested on its own);
+      (4) fft(ifft(v)) == v, record for record (domain.rs:427-463)."""
+    import torch
+
+    G = O.G1 if group == 1 else O.G2
+    gen = np.ascontiguousarray(inputs.G1_GEN_RAW if group == 1 else inputs.G2_GEN_RAW)
+    L = zk.lib.load()
+    r = M.R_ORDER
+    n = 1 << log_n
+    tau = 0x2B3C4D5E6F708192A3B4C5D6E7F8091A2B3C4D5E6F708192A3B4C5D6E7F809 % r
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * tau % r
+    d_k = _scalars_to_dev(pw)
+    pts = torch.empty((n, 8 * group), dtype=torch.int64, device="cuda")
+    mul = L.mi355zk_bn254_g1_batch_mul_dev if group == 1 else L.mi355zk_bn254_g2_batch_mul_dev
+    fft = L.mi355zk_bn254_g1_point_fft_dev if group == 1 else L.mi355zk_bn254_g2_point_fft_dev
+    assert mul(C.c_void_p(pts.data_ptr()), gen.ctypes.data_as(C.c_void_p), C.c_void_p(d_k.data_ptr()), n, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(pts[1].cpu().numpy().view(np.uint64), G.to_affine(G.mul(G.from_affine(gen), np.array(M.to_limbs(tau), dtype=np.uint64))))
+    lag = pts.clone()
+    assert fft(C.c_void_p(lag.data_ptr()), log_n, 1 | trusted, None) == 0
+    # (1) the closed form on a sample
+    w = M.domain_omega(log_n)
+    rng = np.random.default_rng(9100 + log_n + group)
+    idx = np.unique(np.concatenate([[0, 1, 2, n // 2 - 1, n // 2, n - 2, n - 1], rng.integers(0, n, size=270)]))
+    assert len(idx) >= 256
+    h = lag[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    tn1 = (pow(tau, n, r) - 1) % r
+    g_jac = G.from_affine(gen)
+    for i, j in enumerate(idx):
+        wj = pow(w, int(j), r)
+        lj = tn1 * wj % r * pow(n * (tau - wj) % r, -1, r) % r
+        assert np.array_equal(h[i], G.to_affine(G.mul(g_jac, np.array(M.to_limbs(lj), dtype=np.uint64)))), int(j)
+    # (2) the outputs sum to G
+    ones = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    ones[:, 0] = 1
+    assert np.array_equal(G.to_affine(zk.ceremony.dense_multiexp(lag, ones)), gen)
+    # (3) rows of the inverting DFT over every output record
+    for k in (1, (n // 2 + 12345) | 1):
+        wk = pow(w, k, r)
+        col = [1] * n
+        for j in range(1, n):
+            col[j] = col[j - 1] * wk % r
+        got = zk.ceremony.dense_multiexp(lag, _scalars_to_dev(col))
+        assert np.array_equal(G.to_affine(got), pts[k].cpu().numpy().view(np.uint64)), k
+    # (4) the forward transform brings the table back
+    back = lag.clone()
+    assert fft(C.c_void_p(back.data_ptr()), log_n, 0 | trusted, None) == 0
+    assert torch.equal(back, pts)
