@@ -414,6 +414,222 @@ def secondary(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
     return sec
 
 
+# ---- mad models of the scalar-multiplication kernels behind the "next" rows (api.hip; counts of v_mad_u64_u32 per lane, from the formulas'
+# documented costs in curveu.hpp: Jacobian doubling 1071, table addition 2079, mixed addition 1593, U-form product 162)
+# G1, per-point scalars (batch_exp_win_kernel<SPLIT>): GLV halves in 33 signed 4-bit windows: 128 doublings + 2 x 33 x 15/16 table additions
+# (half of them with one more product by beta) + the {1..8}P table (4 doublings + 3 mixed additions)
+MADS_G1_SCALAR_MUL = 128 * 1071 + 62 * 2079 + 31 * 162 + 4 * 1071 + 3 * 1593
+# G2 default (plain windows, batch_exp_win_u2_kernel without the psi split): 65 windows = 260 doublings + 61 table additions + the table,
+# every Fq2 product = 3 Fq products
+MADS_G2_SCALAR_MUL_PLAIN = 3 * (260 * 1071 + 61 * 2079 + 4 * 1071 + 3 * 1593)
+MADS_FQ2_MIXED_ADD = 3 * MADS_PER_MIXED_ADD
+FQ_PRODUCT_PEAK_MEMORY_FORMAT = 125e9   # mont_mul_gfx950.inc: 125 G products/s (profiles/r05_final_ubench_fieldmul.txt)
+
+
+def secondary_rows(zk, L, worker, dev, log_n: int, cpu: bool = True) -> dict:
+    """SURVEY 8(f)'s rows on the same clock as the headline, inputs resident in HBM, every leg with the `roofline` of the
+    call (algorithmic HBM bytes / call time, plus the multiplier-instruction model -- all of them are integer-ALU bound) and the oracle's
+    restatement of the reference's loop timed on a bounded sample of the same input, compared record for record with the device's output:
+      qap_eval      MPCParameters::new's per-variable sums (phase2/src/parameters.rs:225-294): CSR matrix x Lagrange points, G1 and G2 --
+                    config 5's "G1 + G2 MSM mix"; general coefficients and circom-like ones (90 % +-1)
+      power_pairs   powersoftau/src/utils.rs:112-135 (merge_pairs of v[..n-1], v[1..]: two multiexps over one random vector), G1 and G2
+      point_ifft    prepare_phase2's Lagrange conversion (powersoftau/src/bin/prepare_phase2.rs:68-105; bellman/src/group.rs:22-51), G1
+      decode        EncodedPoint::into_affine of a G1Compressed accumulator chunk (pairing/src/bn256/ec.rs:763-946)"""
+    import inputs
+    import oracle_lib as O
+    import bn254_model as M
+
+    n = 1 << log_n
+    cores = os.cpu_count() or 1
+    rows = {}
+    vp = C.c_void_p
+    r_minus_1 = torch.from_numpy(np.array(M.to_limbs(M.R_ORDER - 1), dtype=np.uint64).view(np.int64)).to(dev)
+    one = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=dev)
+    nw = C.c_int()
+    L.mi355zk_msm_window_bits(n, C.byref(nw))
+    for g, limbs, gen, name in ((1, 8, inputs.G1_GEN_RAW, "g1"), (2, 16, inputs.G2_GEN_RAW, "g2")):
+        G = O.G1 if g == 1 else O.G2
+        rec = 64 * g
+        k = gen_scalars(n + 1, 31 + g, dev)
+        bases = torch.empty((n + 1, limbs), dtype=torch.int64, device=dev)
+        genr = np.ascontiguousarray(gen)
+        mul = L.mi355zk_bn254_g1_batch_mul_dev if g == 1 else L.mi355zk_bn254_g2_batch_mul_dev
+        assert mul(vp(bases.data_ptr()), genr.ctypes.data_as(vp), vp(k.data_ptr()), n + 1, None) == 0
+        torch.cuda.synchronize()
+        del k
+        # -- QAP evaluation: n variables over n Lagrange points, 0..5 terms each, the constant ONE (variable 0) in n/4 terms
+        g_ = torch.Generator(device=dev)
+        g_.manual_seed(77 + g)
+        lens = torch.randint(0, 6, (n,), device=dev, generator=g_, dtype=torch.int64)
+        lens[0] = n // 4
+        rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rp[1:] = torch.cumsum(lens, 0)
+        nnz = int(rp[-1].item())
+        rp32 = rp.to(torch.int32)
+        col = torch.randint(0, n, (nnz,), device=dev, generator=g_, dtype=torch.int32)
+        cf = gen_scalars(nnz, 61 + g, dev)
+        kind = torch.randint(0, 20, (nnz,), device=dev, generator=g_)
+        cf_unit = cf.clone()
+        cf_unit[kind < 9] = one
+        cf_unit[(kind >= 9) & (kind < 18)] = r_minus_1
+        out = torch.empty((n, limbs), dtype=torch.int64, device=dev)
+        smv = L.mi355zk_bn254_g1_sparse_matvec_dev if g == 1 else L.mi355zk_bn254_g2_sparse_matvec_dev
+        bytes_call = nnz * (rec + 32 + 4) + n * (rec + 4)
+        mads_term = MADS_G1_SCALAR_MUL if g == 1 else MADS_G2_SCALAR_MUL_PLAIN
+        entry = {"metric": "MPCParameters::new per-variable sums as one CSR x point-vector product (%s): %d rows, %d terms over 2^%d Lagrange points, affine out"
+                           % (name.upper(), n, nnz, log_n), "rows": n, "terms": nnz}
+        for label, coeffs in (("general_coefficients", cf), ("circom_like_90pct_unit_coefficients", cf_unit)):
+            def call(c=coeffs):
+                assert smv(vp(out.data_ptr()), vp(bases.data_ptr()), n, vp(rp32.data_ptr()), vp(col.data_ptr()), vp(c.data_ptr()), n, nnz, None, 0) == 0
+            dt, _ = _timed(call, 2)
+            general_terms = nnz if label.startswith("general") else int((kind >= 18).sum().item())
+            entry[label] = {"ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2),
+                            "roofline": {"bound": "hbm", "kernel": "batch_exp_win%s_kernel + segsum" % ("" if g == 1 else "_u2"),
+                                         "achieved": round(bytes_call / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(bytes_call / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                         "alu_model": {"mads_per_general_term": mads_term, "general_terms": general_terms,
+                                                       "frac_of_mad_peak": round(general_terms * mads_term / dt / MAD_PEAK_PER_S, 4)},
+                                         "note": "algorithmic bytes: %d B per term (base record + coefficient + column) + %d B per row; a scalar "
+                                                 "multiplication per general term: integer-ALU bound%s" % (rec + 36, rec + 4, "" if g == 1 else
+                                                 "; default flags: one subgroup-membership test per base, members' terms take the psi split "
+                                                 "(fewer mads than the plain-window model: the fraction is an upper estimate)")}}
+        if g == 2:
+            def call_t():
+                assert smv(vp(out.data_ptr()), vp(bases.data_ptr()), n, vp(rp32.data_ptr()), vp(col.data_ptr()), vp(cf.data_ptr()), n, nnz, None,
+                           zk.lib.G2_TRUSTED_SUBGROUP) == 0
+            dt, _ = _timed(call_t, 2)
+            entry["general_coefficients_trusted_subgroup"] = {"ms": round(dt * 1e3, 2), "Mterm_per_s": round(nnz / dt / 1e6, 2)}
+        if cpu:
+            smv(vp(out.data_ptr()), vp(bases.data_ptr()), n, vp(rp32.data_ptr()), vp(col.data_ptr()), vp(cf.data_ptr()), n, nnz, None, 0)
+            ns = 384 if g == 1 else 128
+            h_rp = rp[1:ns + 2].cpu().numpy()     # rows 1 .. ns (row 0 is the n/4-term constant)
+            t0, t1 = int(h_rp[0]), int(h_rp[-1])
+            hb = bases[col[t0:t1].long()].cpu().numpy().view(np.uint64)
+            hc = cf[t0:t1].cpu().numpy().view(np.uint64)
+            t = time.perf_counter()
+            want = np.zeros((ns, limbs), dtype=np.uint64)
+            for r_ in range(ns):
+                acc = G.from_affine(np.zeros(limbs, np.uint64))
+                for j in range(int(h_rp[r_]) - t0, int(h_rp[r_ + 1]) - t0):
+                    acc = G.add(acc, G.mul(G.from_affine(hb[j]), hc[j]))
+                want[r_] = G.to_affine(acc)
+            dt_cpu = time.perf_counter() - t
+            entry["cpu_baseline"] = {"value": round((t1 - t0) / dt_cpu / 1e6, 5), "unit": "Mterm/s", "cores": 1, "kind": "port",
+                                     "sample": "rows 1 .. %d of the same matrix (%d general terms): the oracle's mul_assign + add_assign per term and "
+                                               "into_affine per row on one core (the reference spreads the variables over its cores, "
+                                               "parameters.rs:250-294), %.2f s" % (ns, t1 - t0, dt_cpu),
+                                     "gpu_matches_oracle_on_sample": bool(np.array_equal(out[1:ns + 1].cpu().numpy().view(np.uint64), want))}
+        rows["qap_eval_%s_2e%d" % (name, log_n)] = entry
+        del cf, cf_unit, col, kind, out, lens, rp, rp32
+
+        # -- power_pairs: s = sum rho_i v_i, sx = sum rho_i v_{i+1} (two multiexps sharing digits and sorts)
+        rho = gen_scalars(n, 41 + g, dev)
+        mp = L.mi355zk_bn254_g1_merge_pairs_dev if g == 1 else L.mi355zk_bn254_g2_merge_pairs_dev
+        s, sx = np.zeros(12 * g, np.uint64), np.zeros(12 * g, np.uint64)
+
+        def pairs(m=n):
+            assert mp(vp(bases.data_ptr()), vp(bases.data_ptr() + rec), vp(rho.data_ptr()), m, None, s.ctypes.data_as(vp), sx.ctypes.data_as(vp)) == 0
+        for _ in range(3):
+            pairs()
+        dt, _ = _timed(pairs, 5)
+        bytes_call = n * (rec + 32)
+        mads = 2 * nw.value * n * (MADS_PER_MIXED_ADD if g == 1 else MADS_FQ2_MIXED_ADD)
+        entry = {"metric": "powersoftau power_pairs over 2^%d + 1 %s points (merge_pairs(v[..n], v[1..]): both sums of one call)" % (log_n, name.upper()),
+                 "ms": round(dt * 1e3, 3), "value": round(2 * n / dt / 1e6, 2), "unit": "Mscalar-mul/s (both sums)",
+                 "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel (two base vectors per digit)", "achieved": round(bytes_call / dt / 1e9, 2),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_call / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                              "alu_model": {"mads": mads, "frac_of_mad_peak": round(mads / dt / MAD_PEAK_PER_S, 4),
+                                            "note": "%d windows x 2 sums x one mixed addition per point over the WHOLE call (digits, partition and the two "
+                                                    "bucket reductions included in the time)" % nw.value},
+                              "note": "algorithmic bytes: every point (v2 is v1 shifted by one record) and every rho_i once = %d B per point" % (rec + 32)}}
+        if cpu:
+            ns = 1 << 16
+            pairs(ns)
+            got_s, got_sx = G.to_affine(s.copy()), G.to_affine(sx.copy())
+            hv = bases[:ns + 1].cpu().numpy().view(np.uint64)
+            hr = rho[:ns].cpu().numpy().view(np.uint64)
+            cpus = min(cores, 64)
+            t = time.perf_counter()
+            w_s, w_sx = G.dense_multiexp(hv[:ns], hr, cpus=cpus), G.dense_multiexp(hv[1:], hr, cpus=cpus)
+            dt_cpu = time.perf_counter() - t
+            entry["cpu_baseline"] = {"value": round(2 * ns / dt_cpu / 1e6, 4), "unit": "Mscalar-mul/s (both sums)", "cores": cpus, "kind": "port",
+                                     "sample": "the first 2^16 + 1 points: the oracle's restatement of powersoftau dense_multiexp (utils.rs:189-292) for "
+                                               "s and for sx, %d threads per region, %.2f s" % (cpus, dt_cpu),
+                                     "gpu_matches_oracle_on_sample": bool(np.array_equal(got_s, G.to_affine(w_s)) and np.array_equal(got_sx, G.to_affine(w_sx)))}
+        rows["power_pairs_%s_2e%d" % (name, log_n)] = entry
+        del rho
+
+        if g == 1:
+            # -- G1 point ifft at 2^(log_n - 2) and compressed decode at 2^log_n
+            ln = log_n - 2
+            m = 1 << ln
+            pts = bases[:m].clone()
+            pf = L.mi355zk_bn254_g1_point_fft_dev
+            assert pf(vp(pts.data_ptr()), ln, 1, None) == 0      # (warm-up; the transform of points is again a vector of points)
+            torch.cuda.synchronize()
+            with _no_gc():
+                t = time.perf_counter()
+                for _ in range(2):
+                    assert pf(vp(pts.data_ptr()), ln, 1, None) == 0
+                dt = (time.perf_counter() - t) / 2
+            bfly = m // 2 * ln
+            bytes_call = 128 * m * ln
+            entry = {"metric": "EvaluationDomain<Point<G1>>::ifft over 2^%d points (prepare_phase2's Lagrange conversion), affine in and out" % ln,
+                     "ms": round(dt * 1e3, 2), "value": round(bfly / dt / 1e6, 2), "unit": "Mbutterfly/s",
+                     "roofline": {"bound": "hbm", "kernel": "pfft_stage_kernel", "achieved": round(bytes_call / dt / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(bytes_call / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                  "alu_model": {"mads_per_butterfly": MADS_G1_SCALAR_MUL + 2 * 2079, "frac_of_mad_peak":
+                                                round(bfly * (MADS_G1_SCALAR_MUL + 2 * 2079) / dt / MAD_PEAK_PER_S, 4)},
+                                  "note": "algorithmic bytes as the reference's serial_fft moves them: every stage reads and writes every point (128 B "
+                                          "x n x log n); a butterfly is a scalar multiplication by the twiddle + an addition + a subtraction: integer-ALU bound"}}
+            if cpu:
+                ls = 9
+                hp = bases[:1 << ls].cpu().numpy().view(np.uint64)
+                t = time.perf_counter()
+                want = O.point_domain_op(1, hp, ls, "ifft")
+                dt_cpu = time.perf_counter() - t
+                small = bases[:1 << ls].clone()
+                assert pf(vp(small.data_ptr()), ls, 1, None) == 0
+                entry["cpu_baseline"] = {"value": round((1 << ls) // 2 * ls / dt_cpu / 1e6, 5), "unit": "Mbutterfly/s", "cores": 1, "kind": "port",
+                                         "sample": "the first 2^%d points: the oracle's Point<G1> serial_fft + batch_normalization (group.rs:22-51 under "
+                                                   "domain.rs:274-317) on one core, %.2f s" % (ls, dt_cpu),
+                                         "gpu_matches_oracle_on_sample": bool(np.array_equal(small.cpu().numpy().view(np.uint64), want))}
+            rows["point_ifft_g1_2e%d" % ln] = entry
+            del pts
+            enc = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+            back = torch.zeros((n, 8), dtype=torch.int64, device=dev)
+            assert L.mi355zk_bn254_g1_encode_dev(vp(enc.data_ptr()), vp(bases.data_ptr()), n, 1, None) == 0
+
+            def dec():
+                assert L.mi355zk_bn254_g1_decode_dev(vp(back.data_ptr()), vp(enc.data_ptr()), n, 1, 1, None, None) == 0
+            dt, _ = _timed(dec, 5)
+            products = 252 + 127 + 6     # y = (x^3 + 3)^((q + 1) / 4) by square-and-multiply (field.hpp pow_limbs), x^3, the root test, the form changes
+            entry = {"metric": "G1Compressed -> affine (EncodedPoint::into_affine, checked) of 2^%d points" % log_n, "ms": round(dt * 1e3, 3),
+                     "value": round(n / dt / 1e6, 1), "unit": "Mpoint/s", "roundtrip_ok": bool(torch.equal(back, bases[:n])),
+                     "roofline": {"bound": "hbm", "kernel": "g1_decode_kernel", "achieved": round(96 * n / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(96 * n / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                  "alu_model": {"fq_products_per_point": products, "products_per_s": round(products * n / dt),
+                                                "peak_products_per_s": FQ_PRODUCT_PEAK_MEMORY_FORMAT,
+                                                "frac": round(products * n / dt / FQ_PRODUCT_PEAK_MEMORY_FORMAT, 4)},
+                                  "note": "algorithmic bytes: 32 B in + 64 B out per point; one square root (a 252-bit power) per point: integer-ALU bound"}}
+            if cpu:
+                ns = 1 << 13
+                henc = enc[:ns].cpu().numpy()
+                t = time.perf_counter()
+                rc_cpu, _, want = O.decode_points(1, henc, True, True)
+                dt_cpu = time.perf_counter() - t
+                assert rc_cpu == 0
+                entry["cpu_baseline"] = {"value": round(ns / dt_cpu / 1e6, 5), "unit": "Mpoint/s", "cores": 1, "kind": "port",
+                                         "sample": "the first 2^13 records: the oracle's restatement of G1Compressed::into_affine (ec.rs:763-946) on one core, "
+                                                   "%.2f s" % dt_cpu,
+                                         "gpu_matches_oracle_on_sample": bool(np.array_equal(back[:ns].cpu().numpy().view(np.uint64).reshape(-1),
+                                                                                              np.asarray(want).reshape(-1)))}
+            rows["decode_g1_compressed_2e%d" % log_n] = entry
+            del enc, back
+        del bases
+    return rows
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -427,6 +643,7 @@ def main() -> int:
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra timing that includes the scalars' host-to-device copy")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs (NTT 2^20, G1 / G2 multiexp 2^20, contribute 2^20)")
     ap.add_argument("--secondary-log-n", type=int, default=20)
+    ap.add_argument("--no-rows", action="store_true", help="skip the SURVEY 8(f) legs of the secondary block (QAP sums, power_pairs, point ifft, decode)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -797,6 +1014,9 @@ def main() -> int:
         del bases, scalars
         torch.cuda.empty_cache()
         out["secondary"] = secondary(zk, L, worker, dev, args.secondary_log_n, cpu=not args.no_cpu_baseline)
+        if not args.no_rows:
+            torch.cuda.empty_cache()
+            out["secondary"].update(secondary_rows(zk, L, worker, dev, args.secondary_log_n, cpu=not args.no_cpu_baseline))
     if rank == 0:
         full = [ms for g, ms in _GC_LOG if g == 2]
         out["host_gc"] = {"collections": len(_GC_LOG), "full_collections": len(full), "longest_ms": round(max([ms for _, ms in _GC_LOG], default=0.0), 2),
