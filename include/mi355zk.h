@@ -88,6 +88,12 @@ int mi355zk_device_count(void);
 int mi355zk_visible_devices(void);
 void mi355zk_shutdown(void);
 const char *mi355zk_version(void);
+/* The ABI revision this library was built with; a binding compares it with the MI355ZK_ABI_VERSION of the header it was written against
+ * and refuses to run on a mismatch (lib.py and integration/mi355zk.rs do).  Bumped whenever a prototype or the meaning of an argument
+ * changes: 6 = round 5's breaks -- batch_exp's `same_scalar` and point_fft's `inverse` became the bit masks `mode` (a legacy "true" of 2
+ * would now read as MI355ZK_G2_TRUSTED_SUBGROUP), sparse_matvec[_dev] gained a trailing `flags`. */
+#define MI355ZK_ABI_VERSION 6
+int mi355zk_abi_version(void);
 
 /* ---- multiexp: host buffers.  Replaces bellman/src/multiexp.rs:330 `multiexp` for
  * S = (Arc<Vec<G1Affine>>, usize) (source.rs:36-70); `base_offset` is that usize. */
@@ -267,7 +273,9 @@ int mi355zk_selftest_g2_scalar_mul_u(const uint64_t affine_pt[16], const uint64_
 int mi355zk_selftest_g2_accumulate(int mode, const uint64_t *affine_pts, const uint8_t *negate, size_t n, uint64_t out_xyzz[32]);
 
 /* ---- mode / flag bits of the scalar-multiplication entry points below (batch_exp: `mode`; point_fft: `mode`; sparse_matvec: `flags`).
- * Every one of them returns, by default, the reference's result for EVERY record the reference's decoders admit: its `mul` is a wNAF
+ * batch_exp and sparse_matvec return, by default, the reference's result for EVERY record the reference's decoders admit (point_fft: for
+ * G2 records on the twist -- in the subgroup or not -- and G1 records on the curve; its stage kernels do not carry batch_exp's handling of
+ * records on no curve, whose sums have no order-independent meaning anyway): the reference's `mul` is a wNAF
  * double-and-add (pairing/src/wnaf.rs:4-71, ec.rs:538-560, 983-997), i.e. the plain group law, and its bn256 decoders test the curve
  * equation at most (ec.rs:133-150, 1136-1344) -- never membership in the order-r subgroup of the twist -- while `compute_constrained`
  * reads its challenge unchecked (powersoftau/src/bin/compute_constrained.rs:16).  The G2 kernels therefore run PLAIN fixed windows over
@@ -340,9 +348,9 @@ int mi355zk_bn254_g2_batch_mul_dev(void *d_out_affine, const uint64_t base_affin
  * like `batch_normalization` (ec.rs:251-299); the all-zero record is infinity on both sides.  mode: MI355ZK_EXP_SAME_SCALAR |
  * MI355ZK_G2_TRUSTED_SUBGROUP (other bits: 3 = bad arguments).  Asynchronous on `stream`.
  * G2 is the reference's `mul` for every record -- in the subgroup, on the twist outside it, or (checked = 0 decoding) on no curve at
- * all: the plain windows are the group law of y^2 = x^3 + (y0^2 - x0^3), which no formula names.  G1 is exact for every point ON the
- * curve; an off-curve G1 record (checked = 0 decoding only) has no order-r structure for the split to use and is NOT the reference's
- * value -- decode G1 with checked != 0, as every reference binary but compute_constrained does. */
+ * all: the plain windows are the group law of y^2 = x^3 + (y0^2 - x0^3), which no formula names.  G1 likewise: the split kernels test
+ * y^2 = x^3 + 3 per record and hand an off-curve record (checked = 0 decoding only) to the plain-window kernel, so batch_exp returns the
+ * reference's `mul` for those too (tests/test_g2_subgroup.py::test_batch_exp_of_records_that_are_on_no_curve). */
 int mi355zk_bn254_g1_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int mode, void *stream);
 int mi355zk_bn254_g2_batch_exp_dev(void *d_out_affine, const void *d_bases_affine, const void *d_scalars, size_t n, int mode, void *stream);
 /* The same on HOST buffers, spread over the device set of mi355zk_init: what MPCParameters::contribute (parameters.rs:423-470) and

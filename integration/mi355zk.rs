@@ -29,6 +29,8 @@ use crate::group::Group;
 use crate::source::{QueryDensity, SourceBuilder};
 use crate::SynthesisError;
 
+/// MI355ZK_ABI_VERSION of the header the block below was generated from; `abi_ok()` compares it with the loaded library's.
+pub const MI355ZK_ABI_VERSION: c_int = 6;
 // mode / flag bits (include/mi355zk.h)
 pub const MI355ZK_MSM_SCALARS_MONTGOMERY: u32 = 1; // msm_ex_dev / msm_table_dev `flags`: the exponents are Montgomery Fr (prover.rs:89-129 fused)
 pub const MI355ZK_EXP_SAME_SCALAR: c_int = 1; // batch_exp `mode`: ONE scalar for all points (phase2 contribute)
@@ -43,6 +45,7 @@ extern "C" {
     pub fn mi355zk_visible_devices() -> c_int;
     pub fn mi355zk_shutdown();
     pub fn mi355zk_version() -> *const c_char;
+    pub fn mi355zk_abi_version() -> c_int;
     pub fn mi355zk_bn254_g1_msm(bases: *const u8, n_bases: usize, base_offset: usize, scalars: *const u64, n_scalars: usize, density: *const u32, density_bits: usize, out_xyz: *mut u64 /* [12] */) -> c_int;
     pub fn mi355zk_bases_cache_pin(host_bases: *const c_void, n_bases: usize, group: c_int) -> c_int;
     pub fn mi355zk_bases_cache_pin_tables(host_bases: *const c_void, n_bases: usize, group: c_int) -> c_int;
@@ -129,6 +132,18 @@ pub fn map_err(rc: c_int) -> Option<SynthesisError> {
         2 => Some(io::Error::new(io::ErrorKind::UnexpectedEof, "expected more bases when adding from source").into()), // source.rs:46-48
         3 => Some(SynthesisError::IoError(io::Error::new(io::ErrorKind::InvalidInput, "mi355zk: bad arguments"))),
         _ => None,
+    }
+}
+
+/// The library speaks the revision this file was generated against (argument MEANINGS changed between revisions -- batch_exp's and
+/// point_fft's `mode`, sparse_matvec's `flags` -- so a mismatch is a refusal, i.e. the CPU path, never a guess).  Checked once.
+pub fn abi_ok() -> bool {
+    use std::sync::Once;
+    static CHECK: Once = Once::new();
+    static mut OK: bool = false;
+    unsafe {
+        CHECK.call_once(|| OK = mi355zk_abi_version() == MI355ZK_ABI_VERSION);
+        OK
     }
 }
 
@@ -221,7 +236,7 @@ where
     S: SourceBuilder<G>,
 {
     let is_g1 = TypeId::of::<G>() == TypeId::of::<G1Affine>();
-    if !is_g1 && TypeId::of::<G>() != TypeId::of::<G2Affine>() {
+    if (!is_g1 && TypeId::of::<G>() != TypeId::of::<G2Affine>()) || !abi_ok() {
         return None;
     }
     let (slice, offset) = bases.as_contiguous()?;
@@ -248,7 +263,7 @@ where
 /// `Fr`): in place on the device copy, written back only on success -- `false` leaves `a` untouched for serial_fft / parallel_fft.
 /// `Point<G>` (96 / 192 B) and other engines return `false` at once.
 pub fn try_best_fft<E: Engine, T: Group<E>>(a: &mut [T], omega: &E::Fr, log_n: u32) -> bool {
-    if TypeId::of::<E>() != TypeId::of::<Bn256>() || mem::size_of::<T>() != 32 || log_n > 28 || a.len() != 1usize << log_n {
+    if TypeId::of::<E>() != TypeId::of::<Bn256>() || mem::size_of::<T>() != 32 || log_n > 28 || a.len() != 1usize << log_n || !abi_ok() {
         return false;
     }
     unsafe { mi355zk_bn254_fr_ntt(a.as_mut_ptr() as *mut u64, log_n, omega as *const E::Fr as *const u64) == 0 }

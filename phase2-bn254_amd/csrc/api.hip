@@ -118,7 +118,8 @@ void prof_begin(int slot, hipStream_t st) {
   if (e == nullptr) return;
   (void)hipEventRecord(e, st);
   for (auto& o : g_prof[slot].open)
-    if (o.st == st) {                     // (a begin without its end on this stream: an error path)
+    if (o.st == st && o.dev == dev) {     // (a begin without its end on this (device, stream): an error path.  Keyed by BOTH: two host threads on
+                                          //  different devices may each use their device's NULL stream -- ADVICE r5)
       g_prof_free[o.dev].push_back(o.e);
       o.e = e;
       o.dev = dev;
@@ -130,13 +131,12 @@ void prof_end(int slot, hipStream_t st) {
   if (g_prof_on == 0 || (g_prof_on == 2 && slot != g_prof_only)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   auto& open = g_prof[slot].open;
-  size_t k = 0;
-  while (k < open.size() && open[k].st != st) ++k;
-  if (k == open.size()) return;
   int dev = 0;
   hipEvent_t e = prof_event(&dev);
   if (e == nullptr) return;
-  if (dev != open[k].dev) {             // the pair must be on one device
+  size_t k = 0;
+  while (k < open.size() && !(open[k].st == st && open[k].dev == dev)) ++k;
+  if (k == open.size()) {               // no begin on this (device, stream)
     g_prof_free[dev].push_back(e);
     return;
   }
@@ -1355,12 +1355,16 @@ int bases_cache_pin(const void* host, size_t n, int group, bool tables = false) 
 }
 // returns the entry (locked for filling when *fill == true: the caller uploads and then sets ready) or nullptr (cache off / not
 // pinned / no room)
+// the vector a multi-GPU cell's slice was cut from (set by the cell's thread around its msm_host_run): the owner of an IMPLICITLY cached
+// slice, so that mi355zk_bases_cache_invalidate(vector) reaches the slices on every device (a pinned vector's slices find
+// their owner in the pin list)
+thread_local const void* t_bases_parent = nullptr;
 std::shared_ptr<BasesEntry> bases_lookup(const void* host, size_t n, int group, size_t bytes, int dev, bool* fill) {
   *fill = false;
   const size_t cap = bases_cache_cap();
   if (cap == 0 || bytes > cap) return nullptr;
   bool want_table = false;
-  const void* owner = host;
+  const void* owner = t_bases_parent ? t_bases_parent : host;
   {
     std::lock_guard<std::mutex> lk(g_bc_mu);
     // pinned: the vector itself, or a record range INSIDE a pinned vector (the single-process multi-GPU mode caches on each device only
@@ -1924,6 +1928,10 @@ int msm_host_multi(const std::vector<int>& devs, const uint8_t* bases, size_t n_
     constexpr size_t bsz = GROUP == 1 ? 64 : 128;
     const uint64_t boff = base_offset + density_rank(P, density, c.lo);
     const uint64_t used = density_rank(P, density, c.hi) - density_rank(P, density, c.lo);
+    struct ParentScope {
+      explicit ParentScope(const void* p) { t_bases_parent = p; }
+      ~ParentScope() { t_bases_parent = nullptr; }
+    } parent_scope(bases);
     c.rc = msm_host_run<GROUP>(bases + boff * bsz, used, 0, scalars + c.lo * 4, c.hi - c.lo, density ? density + (c.lo >> 5) : nullptr,
                                density ? c.hi - c.lo : 0, reinterpret_cast<uint64_t*>(&c.part), wg, c.wgi);
     c.err = t_last_err_index;
@@ -2457,6 +2465,7 @@ void mi355zk_shutdown(void) {
 }
 
 const char* mi355zk_version(void) { return "mi355zk 0.3 (gfx950)"; }
+int mi355zk_abi_version(void) { return MI355ZK_ABI_VERSION; }
 
 int mi355zk_bases_cache_pin(const void* host_bases, size_t n_bases, int group) { return abi_guard([&]() -> int { return bases_cache_pin(host_bases, n_bases, group); }); }
 int mi355zk_bases_cache_pin_tables(const void* host_bases, size_t n_bases, int group) { return abi_guard([&]() -> int { return bases_cache_pin(host_bases, n_bases, group, true); }); }

@@ -660,7 +660,15 @@ struct Key {
 
 // Per (device, log_n, omega) tables; built once and kept (the prover reuses one domain size for
 // every fft of a proof: bellman/src/groth16/prover.rs:217-241).
+// hipMalloc that adds to the owner's byte count (the table cache is bounded by BYTES per device: tables_make_room)
+template <class T>
+static hipError_t tab_malloc(T** p, size_t bytes, size_t* account) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) *account += bytes;
+  return e;
+}
 struct PowTables {
+  size_t bytes = 0;        // device bytes of A, B, roots, full (folded tables count in their own `bytes`)
   uint32_t h = 0;          // w^e = A[e >> h] * B[e & (2^h-1)], e < 2^log_n
   UTab* A = nullptr;
   UTab* B = nullptr;
@@ -670,6 +678,7 @@ struct PowTables {
   // (round 5) `full` with a transform's scale factors folded in (ntt_full_folded_kernel), one per (pre_g, post_c, post_g) this root has
   // been used with -- a domain uses two roots with two each: (fft, coset_fft) and (ifft, icoset_fft)
   struct Folded {
+    size_t bytes = 0;
     bool has_pre = false, has_post_c = false, has_post_g = false;
     Fr pre{}, post_c{}, post_g{};
     uint32_t log_s = 0;
@@ -711,14 +720,35 @@ std::map<Key, PowTables> g_tables;
 // three table lookups: a drop between two lookups of one call would free the tables the first lookup has just returned (found by the
 // NTT fuzz: 64 + entries in one process).  Dropping this device's entries is safe once the device is idle.
 constexpr size_t NTT_TABLES_MAX = 64;
+// ... and by BYTES: an entry is small up to 2^20 except for its full tables -- 72 B x 2^log_n each, up to 1 + NTT_FOLDED_MAX per
+// root -- so 64 entries could hold ~18 GiB.  Default budget 4 GiB per device (env MI355ZK_NTT_TABLES_GB): a prover's two roots with their
+// folded tables at 2^20 are 0.3 GiB.
+static size_t tables_byte_budget() {
+  static const size_t v = [] {
+    const char* e = std::getenv("MI355ZK_NTT_TABLES_GB");
+    const double gb = e ? std::atof(e) : 4.0;
+    return (size_t)((gb > 0.03125 ? gb : 0.03125) * 1073741824.0);
+  }();
+  return v;
+}
 int tables_make_room(size_t need) {
   int dev = 0;
   ZK_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_mu);
-  size_t mine = 0;
-  for (auto& kv : g_tables) mine += kv.first.dev == dev ? 1 : 0;
-  if (mine + need <= NTT_TABLES_MAX) return ZK_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t mine = 0, bytes = 0;
+    for (auto& kv : g_tables) {
+      if (kv.first.dev != dev) continue;
+      ++mine;
+      bytes += kv.second.bytes;
+      for (auto& f : kv.second.folded) bytes += f.bytes;
+    }
+    if (mine + need <= NTT_TABLES_MAX && bytes <= tables_byte_budget()) return ZK_OK;
+  }
+  // the device drains OUTSIDE g_mu (callers on other devices keep looking their tables up); g_run_mu, held by the caller, keeps new
+  // launches of THIS cache's tables from starting meanwhile
   ZK_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g_mu);
   for (auto it = g_tables.begin(); it != g_tables.end();) {
     if (it->first.dev != dev) { ++it; continue; }
     it->second.free_all();
@@ -752,8 +782,8 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
     built = true;
     T.h = (log_n + 1) / 2;
     uint64_t nB = 1ull << T.h, nA = 1ull << (log_n - T.h);
-    if ((e = hipMalloc(&T.A, nA * sizeof(UTab))) != hipSuccess) return fail(e, "A");
-    if ((e = hipMalloc(&T.B, nB * sizeof(UTab))) != hipSuccess) return fail(e, "B");
+    if ((e = tab_malloc(&T.A, nA * sizeof(UTab), &T.bytes)) != hipSuccess) return fail(e, "A");
+    if ((e = tab_malloc(&T.B, nB * sizeof(UTab), &T.bytes)) != hipSuccess) return fail(e, "B");
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, st, T.A, w, nB, nA);
     hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, st, T.B, w, 1ull, nB);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
@@ -764,7 +794,7 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
       if (b == 0 || T.roots[b] != nullptr) continue;
       built = true;
       uint64_t cnt = 1ull << (b - 1);
-      if ((e = hipMalloc(&T.roots[b], cnt * sizeof(UTab))) != hipSuccess) return fail(e, "roots");
+      if ((e = tab_malloc(&T.roots[b], cnt * sizeof(UTab), &T.bytes)) != hipSuccess) return fail(e, "roots");
       hipLaunchKernelGGL(ntt_pow_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.roots[b], w, 1ull << (log_n - b), cnt);
       if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
     }
@@ -774,10 +804,11 @@ int build_pow_tables(hipStream_t st, uint32_t log_n, const Fr& w, bool want_root
       if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "sync");
       (void)hipFree(T.full);
       T.full = nullptr;
+      T.bytes -= sizeof(UTab) << log_n;
     }
     built = true;
     const uint64_t cnt = 1ull << log_n;
-    if ((e = hipMalloc(&T.full, cnt * sizeof(UTab))) != hipSuccess) return fail(e, "full");
+    if ((e = tab_malloc(&T.full, cnt * sizeof(UTab), &T.bytes)) != hipSuccess) return fail(e, "full");
     T.full_log_s = full_log_s;
     hipLaunchKernelGGL(ntt_full_twiddle_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, T.full, T.A, T.B, T.h, full_log_s, cnt);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
@@ -828,30 +859,30 @@ int build_folded(hipStream_t st, uint32_t log_n, const Fr& omega, PowTables* T, 
   auto grid = [](uint64_t c) { return dim3((unsigned)((c + 255) / 256)); };
   if (pre_g) {
     // i = x * n_cols + col:  pre^i = (pre^n_cols)^x * pre^col
-    if ((e = hipMalloc(&f.pre_rows, n_first * sizeof(UTab))) != hipSuccess) return fail(e, "pre rows");
+    if ((e = tab_malloc(&f.pre_rows, n_first * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "pre rows");
     hipLaunchKernelGGL(ntt_pow_table_kernel, grid(n_first), dim3(256), 0, st, f.pre_rows, *pre_g, n_cols, n_first);
-    if ((e = hipMalloc(&f.pre_stages, n_first * sizeof(UTab))) != hipSuccess) return fail(e, "pre stages");
+    if ((e = tab_malloc(&f.pre_stages, n_first * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "pre stages");
     hipLaunchKernelGGL(ntt_stage_table_kernel, grid(n_first), dim3(256), 0, st, f.pre_stages, *pre_g, n_cols, omega, n_cols, log_first);
     if (!with_full) {
-      if ((e = hipMalloc(&f.pre_cols, n_cols * sizeof(UTab))) != hipSuccess) return fail(e, "pre cols");
+      if ((e = tab_malloc(&f.pre_cols, n_cols * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "pre cols");
       hipLaunchKernelGGL(ntt_pow_table_kernel, grid(n_cols), dim3(256), 0, st, f.pre_cols, *pre_g, 1ull, n_cols);
     }
   }
   if (post_g) {
     // K = rb + n_rows_last * k (rb < n_rows_last the row's first output index):  post^K = post^rb * (post^n_rows_last)^k
-    if ((e = hipMalloc(&f.post_rows, n_last * sizeof(UTab))) != hipSuccess) return fail(e, "post rows");
+    if ((e = tab_malloc(&f.post_rows, n_last * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "post rows");
     hipLaunchKernelGGL(ntt_pow_table_kernel, grid(n_last), dim3(256), 0, st, f.post_rows, *post_g, n_rows_last, n_last);
     if (!with_full) {
-      if ((e = hipMalloc(&f.post_rowc, n_rows_last * sizeof(UTab))) != hipSuccess) return fail(e, "post row constants");
+      if ((e = tab_malloc(&f.post_rowc, n_rows_last * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "post row constants");
       hipLaunchKernelGGL(ntt_pow_scaled_table_kernel, grid(n_rows_last), dim3(256), 0, st, f.post_rowc, *post_g, post_c ? *post_c : Fr::one(), n_rows_last);
     }
   } else if (post_c && !with_full) {
     const uint64_t nB = 1ull << T->h;
-    if ((e = hipMalloc(&f.tw_b_scaled, nB * sizeof(UTab))) != hipSuccess) return fail(e, "scaled twiddles");
+    if ((e = tab_malloc(&f.tw_b_scaled, nB * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "scaled twiddles");
     hipLaunchKernelGGL(ntt_pow_scaled_table_kernel, grid(nB), dim3(256), 0, st, f.tw_b_scaled, omega, *post_c, nB);
   }
   if (with_full) {
-    if ((e = hipMalloc(&f.full, cnt * sizeof(UTab))) != hipSuccess) return fail(e, "full");
+    if ((e = tab_malloc(&f.full, cnt * sizeof(UTab), &f.bytes)) != hipSuccess) return fail(e, "full");
     hipLaunchKernelGGL(ntt_full_folded_kernel, grid(cnt), dim3(256), 0, st, f.full, T->A, T->B, T->h, log_s, cnt,
                        Tpre ? Tpre->A : nullptr, Tpre ? Tpre->B : nullptr, Tpre ? Tpre->h : 0u, Tpost ? Tpost->A : nullptr,
                        Tpost ? Tpost->B : nullptr, Tpost ? Tpost->h : 0u, post_cu, post_c != nullptr ? 1 : 0);

@@ -15,6 +15,7 @@ SO_PATH = os.environ.get("MI355ZK_SO") or os.path.join(_HERE, "libmi355zk.so")
 OK, ERR_UNEXPECTED_IDENTITY, ERR_UNEXPECTED_EOF, ERR_BAD_ARGS, ERR_DEVICE = 0, 1, 2, 3, -1
 OP_FFT, OP_IFFT, OP_COSET_FFT, OP_ICOSET_FFT = 0, 1, 2, 3
 MSM_SCALARS_MONTGOMERY = 1
+ABI_VERSION = 6   # MI355ZK_ABI_VERSION of the include/mi355zk.h this table was written against: load() refuses another library
 EXP_SAME_SCALAR, FFT_INVERSE, G2_TRUSTED_SUBGROUP = 1, 1, 2   # mode / flag bits of batch_exp, point_fft, sparse_matvec (include/mi355zk.h)
 
 _vp, _sz, _i, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
@@ -27,6 +28,7 @@ SIGNATURES = {
     "mi355zk_visible_devices": (_i, []),
     "mi355zk_shutdown": (None, []),
     "mi355zk_version": (C.c_char_p, []),
+    "mi355zk_abi_version": (_i, []),
     "mi355zk_bases_cache_pin": (_i, [_vp, _sz, _i]),
     "mi355zk_bases_cache_pin_tables": (_i, [_vp, _sz, _i]),
     "mi355zk_bases_cache_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
@@ -143,5 +145,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if lib.mi355zk_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{SO_PATH}: ABI revision {lib.mi355zk_abi_version()}, this binding was written against {ABI_VERSION} "
+                               "(argument meanings differ between revisions: include/mi355zk.h)")
         _lib = lib
     return _lib
