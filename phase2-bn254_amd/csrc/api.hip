@@ -1637,8 +1637,8 @@ int msm_host_run(const uint8_t* bases, size_t n_bases, size_t base_offset, const
   // partition -> accumulate into the ONE bucket array of the call (msm_device, MsmChunks); what a chunk costs on top of its share
   // of the work is the re-partition of the bucket bounds and one read + write of every bucket record it touches (~1.3 ms at 2^26).
   std::vector<uint64_t> cuts{0};
-  static const char* env_grow = std::getenv("MI355ZK_HOST_CHUNK_GROWTH");  // percent, default 180
-  static const char* env_first = std::getenv("MI355ZK_HOST_CHUNK_FIRST");  // log2 of the first chunk (bases on the device)
+  const char* env_grow = std::getenv("MI355ZK_HOST_CHUNK_GROWTH");  // percent (read per call: tools/exp_host_chunks.py sweeps it in one process)
+  const char* env_first = std::getenv("MI355ZK_HOST_CHUNK_FIRST");  // log2 of the first chunk (bases on the device)
   // (test hook, read on every call: MI355ZK_HOST_CHUNK_TEST = exponents per chunk, a multiple of 32 -- cuts calls of ANY size, so
   // that the chunked path can be held against the CPU oracle at sizes the oracle finishes in seconds)
   const char* env_test = std::getenv("MI355ZK_HOST_CHUNK_TEST");

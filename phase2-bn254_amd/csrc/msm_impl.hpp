@@ -1315,6 +1315,10 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const Affine<F>* __
     return;
   }
   typename BucketAcc<F>::type acc = BucketAcc<F>::type::zero();
+  // (r6, profiles/r06_carry_cost.txt: what a carried launch costs over a fresh one is its first addition -- a full mixed addition where the
+  //  fresh launch copies the point into an empty accumulator -- i.e. one addition per TOUCHED BUCKET per extra chunk; the record's load and
+  //  its two products are not measurable.  Adding the record at the END by a full addition instead was 1.2 x slower per launch: ~3000
+  //  instructions executed once per wave run from a cold instruction cache.)
   if constexpr (CARRY) acc = xyzzu_from_r(load_vec(buckets + b));
   store_vec(buckets + b, xyzzu_to_r(accumulate_run<F, A4>(acc, bases, vals, j, e, 1, skip_zero != 0, err_base)));
 }

@@ -1,0 +1,20 @@
+#!/bin/bash
+# tools/build_variant.sh NAME "<extra hipcc flags>" [unit ...]: a second build of the library for a same-box A/B run -- the listed translation
+# units (default: msm_g1) recompiled with the extra flags, linked with the other objects of build/ into tools/bin/libmi355zk_NAME.so
+# (git-ignored, travels with gpurun).  Use: MI355ZK_SO=tools/bin/libmi355zk_NAME.so python tools/...
+set -e
+cd "$(dirname "$0")/.."
+name=$1; flags=$2; shift 2 || true
+units=${@:-msm_g1}
+mkdir -p build_$name tools/bin
+objs=""
+for o in ntt msm_g1 msm_g2 api field_ops point_fft point_fft_g2 codec; do
+  if [[ " $units " == *" $o "* ]]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags -c phase2-bn254_amd/csrc/$o.hip -o build_$name/$o.o
+    objs="$objs build_$name/$o.o"
+  else
+    objs="$objs build/$o.o"
+  fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libmi355zk_$name.so $objs
+echo tools/bin/libmi355zk_$name.so
