@@ -31,3 +31,18 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
+
+# ---- sanitizer build: the same sources with the HOST side instrumented by AddressSanitizer + UndefinedBehaviorSanitizer
+# (-fno-gpu-sanitize: the gfx950 code objects are the product's).  `make asan` -> tools/bin/libmi355zk_asan.so; run a python process over it with
+#   LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 MI355ZK_SO=tools/bin/libmi355zk_asan.so
+# tests/test_asan_host.py (CPU: the host arithmetic / self-test hooks / argument paths) and tests/test_gpu_asan.py (GPU: a slice of the suite) do that.
+ASAN_RT := $(shell /opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so 2>/dev/null)
+ASAN_OBJS := $(patsubst build/%.o,build_asan/%.o,$(OBJS))
+asan: tools/bin/libmi355zk_asan.so
+tools/bin/libmi355zk_asan.so: $(ASAN_OBJS)
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fsanitize=address,undefined -shared-libsan -o $@ $(ASAN_OBJS)
+build_asan/%.o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p build_asan
+	$(HIPCC) $(HIPFLAGS) -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -shared-libsan -c $< -o $@
+.PHONY: asan

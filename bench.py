@@ -692,6 +692,32 @@ def main() -> int:
     L = zk.lib.load()
     worker = zk.Worker(dev_index)
 
+    # ---- preflight (N > 1), BEFORE the input generation: the collective this run depends on, once, through the very code path the timed
+    # steps use (shard._allgather_words: pinned -> H2D -> all_gather_into_tensor -> D2H on RCCL, the plain tensor form on gloo), with the
+    # 14-word record of shard.exchange (12 Jacobian limbs + rc + index = 112 bytes).  A first lease of a real multi-GPU node then fails in
+    # seconds with a message -- a missing IPC mode, a rank on the wrong device, a world that is not --gpus -- instead of after 40 s of setup.
+    preflight = None
+    if world > 1:
+        t_pf = time.perf_counter()
+        assert dist.get_world_size() == args.gpus, "torch.distributed sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
+        probe = np.arange(14, dtype=np.uint64) + (np.uint64(rank) << np.uint64(32))
+        try:
+            uuid = str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", dev_index))
+        except Exception:  # noqa: BLE001
+            uuid = str(dev_index)
+        probe[13] = np.uint64(int.from_bytes(__import__("hashlib").sha256(uuid.encode()).digest()[:7], "little"))
+        got = zk.shard._allgather_words(probe, dev if backend == "nccl" else None, None, world)
+        bad = [r for r in range(world) if got.shape != (world, 14) or int(got[r, 0]) != (r << 32) or int(got[r, 12]) != (r << 32) + 12]
+        if bad:
+            print("bench.py preflight: the 112-byte all-gather returned a wrong record for rank(s) %s" % bad, file=sys.stderr)
+            return 3
+        distinct = len({int(got[r, 13]) for r in range(world)})
+        if backend == "nccl" and distinct != world:
+            print("bench.py preflight: %d ranks on %d distinct GPU(s) (LOCAL_RANK -> device mapping)" % (world, distinct), file=sys.stderr)
+            return 3
+        preflight = {"ms": round((time.perf_counter() - t_pf) * 1e3, 1), "ranks": world, "distinct_devices": distinct, "record_bytes": 112,
+                     "path": "shard._allgather_words (%s)" % ("pinned -> H2D -> all_gather_into_tensor -> D2H, one stream sync" if backend == "nccl" else "gloo, host tensors")}
+
     log_n = args.log_n
     n_total = 1 << log_n
     # sharding (shard.plan): a few contiguous point ranges x groups of scalar windows; BENCH_SHARD=points forces point ranges only
@@ -848,6 +874,50 @@ def main() -> int:
     except (OSError, ValueError, KeyError):
         pass
 
+    # ---- (N > 1) the OTHER plan in the same run, so that the first real scaling record explains its own efficiency: the default plan gives a
+    # rank a (point range x window group) cell (shard.plan: 1 x 2, 1 x 4, 2 x 4); the alternative is point ranges only (N x 1) -- every window
+    # reduced once per rank, 1 / N of the points each.  Rank r's N x 1 range is the (r mod window_groups)-th part of the range it already
+    # holds, so nothing is generated again.  Same barriers, same max-over-ranks clock, result checked against the timed plan's.
+    alt_plan = None
+    if world > 1 and wgroups > 1 and os.environ.get("BENCH_NO_ALT_PLAN") is None:
+        n_alt = n_total // world
+        off = wgroup * n_alt
+        b_alt, s_alt = bases[off:off + n_alt], scalars[off:off + n_alt]
+        lo_alt = lo_global + off
+
+        def step_alt():
+            fut = zk.multiexp(worker, (b_alt, 0), zk.FullDensity(), s_alt)
+            return zk.shard.exchange(fut, 12, index_offset=lo_alt, device=dev if backend == "nccl" else None)
+
+        for _ in range(max(1, args.warmup)):
+            step_alt()
+        L.mi355zk_prof_reset()
+        L.mi355zk_prof_enable(1)
+        dist.barrier()
+        torch.cuda.synchronize()
+        with _no_gc(collect=False):
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                r_alt = step_alt()
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt_alt = time.perf_counter() - t1
+        L.mi355zk_prof_enable(0)
+        tt = torch.tensor([dt_alt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_alt = float(tt.item()) / args.steps
+        kern_alt = _prof(L, ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce"))
+        a_alt, a_main = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        L.mi355zk_bn254_g1_to_affine(a_alt.ctypes.data_as(C.c_void_p), np.ascontiguousarray(r_alt).ctypes.data_as(C.c_void_p))
+        L.mi355zk_bn254_g1_to_affine(a_main.ctypes.data_as(C.c_void_p), np.ascontiguousarray(result).ctypes.data_as(C.c_void_p))
+        nw_alt = C.c_int()
+        c_alt = L.mi355zk_msm_window_bits_groups(n_alt, 1, C.byref(nw_alt))
+        alt_plan = {"parallelism": "%d point range(s) x 1 window group(s), all-gather of 96-B partials" % world, "points_per_gpu": n_alt,
+                    "window_bits": c_alt, "windows": nw_alt.value, "ms_per_step": round(dt_alt * 1e3, 3), "value": round(n_total / dt_alt / 1e6, 3),
+                    "kernel_ms_rank0": {k: (round(v, 4) if v is not None else None) for k, v in kern_alt.items()},
+                    "same_point_as_the_timed_plan": bool(np.array_equal(a_alt, a_main))}
+        assert alt_plan["same_point_as_the_timed_plan"], "the N x 1 plan's result differs from the timed plan's"
+
     # ---- the same step with the scalars' host-to-device copy inside the timed region (SURVEY 8d defines the metric with "H2D of
     # scalars included"; `value` keeps inputs resident as the bench contract asks): pinned host buffer -> HBM -> multiexp
     h2d = None
@@ -961,6 +1031,8 @@ def main() -> int:
             "result_affine_x_limb0": hex(int(aff[0])),
             "full_size_linearity_check": additive_ok,
             "sharded_result_matches_unsharded": sharded_ok if world > 1 else None,
+            "preflight": preflight,
+            "alt_plan": alt_plan,
             # SURVEY 8(d) defines the metric with the exponents' upload inside the call; the bench contract defines `value` with
             # every input resident.  Both are reported, each under its own name.
             "value_definition": "`value`: every input resident in HBM when the timed region starts -- the bench contract's definition, which says of a "
@@ -1017,6 +1089,27 @@ def main() -> int:
         if not args.no_rows:
             torch.cuda.empty_cache()
             out["secondary"].update(secondary_rows(zk, L, worker, dev, args.secondary_log_n, cpu=not args.no_cpu_baseline))
+    # ---- (N > 1) the single-process form of the same job in the same line (VERDICT r5 #6c): ONE process, mi355zk_init over the N devices, one
+    # host-buffer call cut into a point range per device (include/mi355zk.h).  A child of rank 0 with a time limit, run while the other
+    # ranks wait at the barrier below with their GPUs idle; needs every GPU visible to rank 0 (nccl runs only).  BENCH_SINGLE_PROCESS_LEG=0 skips it.
+    if world > 1 and backend == "nccl" and os.environ.get("BENCH_SINGLE_PROCESS_LEG", "1") != "0":
+        del bases, scalars
+        torch.cuda.empty_cache()
+        dist.barrier()
+        if rank == 0:
+            import subprocess
+
+            counts = [str(k) for k in (1, world) if k <= torch.cuda.device_count()]
+            env_child = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                       "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+            try:
+                ch = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_multi_device.py"), "--log-n", "24", "--iters", "3", "--no-batch-exp", "--devices"] + counts,
+                                    capture_output=True, text=True, timeout=200, cwd=ROOT, env=env_child)
+                line = [ln for ln in ch.stdout.splitlines() if ln.startswith("{")]
+                out["single_process_multi_gpu_2e24"] = json.loads(line[-1]) if ch.returncode == 0 and line else {"error": "rc %d: %s" % (ch.returncode, ch.stderr[-300:])}
+            except Exception as e:  # noqa: BLE001
+                out["single_process_multi_gpu_2e24"] = {"error": repr(e)[:300]}
+        dist.barrier()
     if rank == 0:
         full = [ms for g, ms in _GC_LOG if g == 2]
         out["host_gc"] = {"collections": len(_GC_LOG), "full_collections": len(full), "longest_ms": round(max([ms for _, ms in _GC_LOG], default=0.0), 2),

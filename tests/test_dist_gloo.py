@@ -128,3 +128,87 @@ def test_two_rank_contribute_by_point_range():
         p.join(180)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def _worker_plan(rank, world, port, n, q):
+    """world = 4 / 8 under shard.plan (1 x 4, 2 x 4): the cell of a rank is (point range of its point group) x (its window group).  The
+    oracle has no window-group partial, so window group 0 of every point range contributes the range's whole sum and the other groups the
+    identity -- the join is a sum of `world` partials whatever they mean, which is what is under test, together with the error rule."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import inputs
+    import oracle_lib as O
+    import phase2_bn254_amd as zk
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = O.G1
+    bases = inputs.bases_progression_cpu(1, n, seed=41)
+    scalars = inputs.random_scalars(n, seed=42)
+    pg, pgi, wg, wgi = zk.shard.rank_groups(world, rank)
+    assert pg * wg == world and rank == pgi * wg + wgi
+    lo, hi = zk.shard.shard_range(n, pg, pgi)
+    if wgi == 0:
+        rc, part = G.multiexp(bases[lo:hi], scalars[lo:hi])
+        assert rc == 0
+    else:
+        part = G.from_affine(np.zeros(8, np.uint64))
+    rc_full, full = G.multiexp(bases, scalars)
+    ok = bool(np.array_equal(G.to_affine(zk.shard.exchange(zk.bellman._Ready(part), 12, index_offset=lo)), G.to_affine(full)))
+    ok = ok and bool(np.array_equal(G.to_affine(zk.shard.allgather_join(part)), G.to_affine(full)))
+
+    def err(kind, idx):
+        return zk.bellman._Ready(error=zk.SynthesisError(kind, idx))
+
+    ID, EOF = zk.SynthesisError.UNEXPECTED_IDENTITY, zk.SynthesisError.IO_UNEXPECTED_EOF
+    lo_of = lambda r: zk.shard.shard_range(n, pg, zk.shard.rank_groups(world, r)[1])[0]  # noqa: E731
+    # (a) three ranks fail at different places: everybody raises the error at the lowest GLOBAL exponent index
+    failing = {1: (ID, 3), 2: (ID, 0), world - 1: (EOF, 1)}
+    want = min((lo_of(r) + i, 0 if k == EOF else 1, k) for r, (k, i) in failing.items())
+    try:
+        zk.shard.exchange(err(*failing[rank]) if rank in failing else zk.bellman._Ready(part), 12, index_offset=lo)
+        ok = False
+    except zk.SynthesisError as e:
+        ok = ok and (e.index, e.kind) == (want[0], want[2])
+    # (b) two ranks of ONE point range report the same global index, one Eof and one identity: Eof wins (oracle/tmpl_multiexp.h)
+    failing = {0: (ID, 7), wg - 1: (EOF, 7)} if wg > 1 else {0: (EOF, 7)}
+    try:
+        zk.shard.exchange(err(*failing[rank]) if rank in failing else zk.bellman._Ready(part), 12, index_offset=lo)
+        ok = False
+    except zk.SynthesisError as e:
+        ok = ok and (e.index, e.kind) == (7, EOF)
+    # (c) one rank's multiexp dies with something that is not a SynthesisError (a device failure): every rank still reaches the collective
+    # and every rank raises -- nobody is left waiting
+    class Boom:
+        def wait(self):
+            raise RuntimeError("device lost")
+
+    try:
+        zk.shard.exchange(Boom() if rank == world - 2 else zk.bellman._Ready(part), 12, index_offset=lo)
+        ok = False
+    except RuntimeError:
+        pass
+    # ... and the group is still usable afterwards
+    ok = ok and bool(np.array_equal(G.to_affine(zk.shard.exchange(zk.bellman._Ready(part), 12, index_offset=lo)), G.to_affine(full)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_plan_cells_and_error_order_with_4_and_8_ranks(world):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_plan, args=(r, world, port, 203, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, True) for r in range(world)]

@@ -44,6 +44,9 @@ def test_bench_result_is_identical_for_every_rank_count(bases):
         got = _run(n, bases)
         assert got["n_gpus"] == n and got["full_size_linearity_check"] and got["sharded_result_matches_unsharded"]
         assert got["result_affine_x_limb0"] == ref["result_affine_x_limb0"], (n, bases)
+        # the preflight all-gather (before the input generation) and the N x 1 plan timed next to the default one, same point
+        assert got["preflight"]["ranks"] == n and got["preflight"]["record_bytes"] == 112
+        assert got["alt_plan"]["same_point_as_the_timed_plan"] and got["alt_plan"]["points_per_gpu"] == (1 << 21) // n
         assert got["config"]["bases_bytes_per_gpu"] * (n // min(n, 4)) == (1 << 21) * 64
 
 
@@ -57,6 +60,7 @@ def test_eight_ranks_at_the_baseline_size():
     assert got["n_gpus"] == 8 and got["full_size_linearity_check"] and got["sharded_result_matches_unsharded"]
     assert got["result_affine_x_limb0"] == "0x5c2b6af288baf266"
     assert got["config"]["points_per_gpu"] == 1 << 25 and "2 point range(s) x 4 window group(s)" in got["config"]["parallelism"]
+    assert got["alt_plan"]["same_point_as_the_timed_plan"] and got["alt_plan"]["points_per_gpu"] == 1 << 23 and "8 point range(s) x 1" in got["alt_plan"]["parallelism"]
 
 
 def test_plain_command_launches_its_own_ranks():
