@@ -84,6 +84,31 @@ def ntt_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def host_cpu_info() -> dict:
+    """what the cpu_baseline figures were timed on (the same '16 threads of a 256-core host' read 3.04 and 2.57 M/s on two boxes)"""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+        models = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
+        mhz = [float(ln.split(":", 1)[1]) for ln in txt.splitlines() if ln.startswith("cpu MHz")]
+        info["model"] = models[0] if models else None
+        info["sockets"] = len({ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("physical id")}) or None
+        info["cpu_mhz_now_min_max"] = [round(min(mhz)), round(max(mhz))] if mhz else None
+    except OSError:
+        pass
+    try:
+        with open("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor") as f:
+            info["governor"] = f.read().strip()
+    except OSError:
+        info["governor"] = None
+    try:
+        info["loadavg_1m"] = round(os.getloadavg()[0], 2)
+    except OSError:
+        pass
+    return info
+
+
 def _ntt_traffic(log_n: int):
     """HBM bytes per ntt_pass_kernel launch from the committed PMC record, only while it was measured at this size on these sources"""
     try:
@@ -1078,7 +1103,7 @@ def main() -> int:
             at_metric = {"window_bits": c_metric, "windows": w_m, "threads": min(cores, w_m), "Mscalar_mul_per_s": round(ns / dt_m / 1e6, 4),
                          "seconds": round(dt_m, 2), "same_point": bool(rc_m == 0 and np.array_equal(O.G1.to_affine(ref_m), O.G1.to_affine(ref)))}
         out["cpu_baseline"] = {"value": round(ns / dt / 1e6, 4), "unit": "Mscalar-mul/s", "cores": threads, "threads": threads, "host_cores": cores,
-                               "kind": "port", "at_the_metric_size_window": at_metric,
+                               "host_cpu": host_cpu_info(), "kind": "port", "at_the_metric_size_window": at_metric,
                                "sample": "first 2^%d points of the same input, oracle restatement of bellman_ce multiexp "
                                          "(c=%d, one thread per window, %d windows), %.2f s" % (int(np.log2(ns)), c_ref, windows, dt),
                                "gpu_matches_oracle_on_sample": ok}

@@ -16,5 +16,5 @@ for o in ntt msm_g1 msm_g2 api field_ops point_fft point_fft_g2 codec; do
     objs="$objs build/$o.o"
   fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/libmi355zk_$name.so $objs
+hipcc --offload-arch=gfx950 -shared -fPIC $LINKFLAGS -o tools/bin/libmi355zk_$name.so $objs
 echo tools/bin/libmi355zk_$name.so
