@@ -170,6 +170,98 @@ __global__ void k_f64_check(const Fq* io, Fq* out, int n) {
   out[0] = reduce_once(f5_to_std(x));   // (< 2p -> canonical)
   out[1] = m;
 }
+
+// ---- (round 6) LOWER BOUND of a product whose Montgomery reduction runs on the int8 matrix cores.  The reduction is two products by
+// CONSTANTS -- m = (t mod 2^261) * (-p^-1) mod 2^261 and m * p -- i.e., over the 64 elements of a wave, two GEMMs against constant Toeplitz matrices of the
+// constants' bytes (V_MFMA_I32_16X16X64_I8: a 64 x 33 by 33 x 33 and a 64 x 33 by 33 x 66 product of signed bytes, i32 column sums < 33 * 2^14).  That would take
+// 81 of the U-form's 162 v_mad_u64_u32 off the VALU.  What stays ON the VALU whatever the MFMA costs: the 81 mads of the variable product, re-limbing its low
+// half from 29-bit limbs to packed signed bytes, carry-propagating the 33 i32 columns of m into signed bytes for the second GEMM, carry-propagating its 66 columns
+// into words, re-limbing those to 29 bits and adding them to the upper half.  This kernel runs exactly that and NOTHING of the matrix part -- no MFMA, none of the
+// three lane <-> operand-layout transposes (an element lives in one lane; the MFMA operands spread an element's bytes over four lanes and return 4 columns of 16
+// elements per lane: through LDS that is 33 + 33 + 66 dword stores and loads per element more).  The column values the MFMA would deliver are stand-ins aliased to
+// live registers (zero instructions), so the figure is a strict lower bound of the real thing's time.  Gate: >= 1.15 x the U-form's rate.
+template <int CHAINS>
+__global__ void __launch_bounds__(256) k_mfma_glue(Fq* io) {
+  FpU<FqParams> x[CHAINS], y = u_from_std(io[1]);
+  for (int c = 0; c < CHAINS; ++c) { Fq t = io[0]; t.l[0] += threadIdx.x + c; x[c] = u_from_std(t); }
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      const FpU<FqParams> a = x[c];
+      // (1) the variable product: 81 mads, 17 columns -> 18 limbs of 29 bits
+      uint32_t t[18];
+      uint64_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < 17; ++k) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const int j = k - i;
+          if (j >= 0 && j < 9) u_mad(acc, a.l[i], y.l[j]);
+        }
+        t[k] = (uint32_t)acc & U_MASK;
+        acc >>= U_BITS;
+      }
+      t[17] = (uint32_t)acc;
+      // (2) low half: 9 x 29 bits -> 9 packed words of 4 bytes (33 bytes), then SIGNED bytes: (w + 0x80..80 with the carries between words) ^ 0x80..80
+      uint32_t w[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int bit = 32 * k, lo = bit / 29, sh = bit % 29;
+        uint64_t v = (uint64_t)t[lo] >> sh;
+        if (lo + 1 < 9) v |= (uint64_t)t[lo + 1] << (29 - sh);
+        if (lo + 2 < 9 && 58 - sh < 32) v |= (uint64_t)t[lo + 2] << (58 - sh);
+        w[k] = (uint32_t)v;
+      }
+      uint64_t cy = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        cy += (uint64_t)w[k] + 0x80808080u;
+        w[k] = (uint32_t)cy ^ 0x80808080u;
+        cy >>= 32;
+      }
+      // (3) [MFMA 1: 33 i32 columns of m] stand-ins c1[i] = w[i % 9];  carry-propagate them into 33 bytes, packed, signed again
+      uint32_t mw[9] = {};
+      int32_t sgn = 0;
+#pragma unroll
+      for (int i = 0; i < 33; ++i) {
+        sgn += (int32_t)w[i % 9];
+        mw[i / 4] |= ((uint32_t)sgn & 0xffu) << (8 * (i % 4));
+        sgn >>= 8;
+      }
+      cy = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        cy += (uint64_t)mw[k] + 0x80808080u;
+        mw[k] = (uint32_t)cy ^ 0x80808080u;
+        cy >>= 32;
+      }
+      // (4) [MFMA 2: 66 i32 columns of m * p] stand-ins c2[i] = mw[i % 9];  carry-propagate into 17 words
+      uint32_t q[17] = {};
+      sgn = 0;
+#pragma unroll
+      for (int i = 0; i < 66; ++i) {
+        sgn += (int32_t)mw[i % 9];
+        q[i / 4] |= ((uint32_t)sgn & 0xffu) << (8 * (i % 4));
+        sgn >>= 8;
+      }
+      // (5) the upper half of t + m p: re-limb q's bits 261 .. 521 to 29-bit limbs and add (lazy limbs: no carries)
+      FpU<FqParams> r;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int bit = 261 + 29 * k, lo = bit / 32, sh = bit % 32;
+        uint64_t v = (uint64_t)q[lo] >> sh;
+        if (lo + 1 < 17) v |= (uint64_t)q[lo + 1] << (32 - sh);
+        r.l[k] = (((uint32_t)v) & U_MASK) + t[9 + k];
+      }
+      r.l[0] += (uint32_t)sgn & 1u;
+      x[c] = r;
+    }
+  FpU<FqParams> s = x[0];
+  for (int c = 1; c < CHAINS; ++c) s = u_add(s, x[c]);
+  uint32_t o = 0;
+  for (int k = 0; k < 9; ++k) o ^= s.l[k];
+  if (o == 0x12345678u) io[2] = u_to_std_lt2p(u_mul(s, y));
+}
 template <class K>
 static void run(const char* name, K kern, int chains, Fq* d) {
   hipEvent_t a, b;
@@ -216,6 +308,9 @@ int main() {
   }
   run("f64 5x52 (v_fma_f64)", k_f64<1>, 1, d);
   run("f64 5x52 (v_fma_f64)", k_f64<2>, 2, d);
+  std::printf("-- lower bound of a product with its Montgomery reduction on V_MFMA_I32_*_I8: 81 mads + the VALU glue, no MFMA, no transposes (garbage values) --\n");
+  run("MFMA-reduce glue bound", k_mfma_glue<1>, 1, d);
+  run("MFMA-reduce glue bound", k_mfma_glue<2>, 2, d);
   hipFree(d);
   return 0;
 }
