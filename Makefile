@@ -35,7 +35,7 @@ clean:
 # ---- sanitizer build: the same sources with the HOST side instrumented by AddressSanitizer + UndefinedBehaviorSanitizer
 # (-fno-gpu-sanitize: the gfx950 code objects are the product's).  `make asan` -> tools/bin/libmi355zk_asan.so; run a python process over it with
 #   LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 MI355ZK_SO=tools/bin/libmi355zk_asan.so
-# tests/test_asan_host.py (CPU: the host arithmetic / self-test hooks / argument paths) and tests/test_gpu_asan.py (GPU: a slice of the suite) do that.
+# tests/test_asan_host.py (CPU: the host arithmetic / self-test hooks / argument paths) and tests/test_gpu_ubsan.py (GPU, UBSan build below) do that.
 ASAN_RT := $(shell /opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so 2>/dev/null)
 ASAN_OBJS := $(patsubst build/%.o,build_asan/%.o,$(OBJS))
 asan: tools/bin/libmi355zk_asan.so
@@ -45,4 +45,15 @@ tools/bin/libmi355zk_asan.so: $(ASAN_OBJS)
 build_asan/%.o: $(SRC)/%.hip $(HDRS)
 	@mkdir -p build_asan
 	$(HIPCC) $(HIPFLAGS) -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -shared-libsan -c $< -o $@
-.PHONY: asan
+# The GPU box cannot run the ASan build: ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate and needs an xnack / ASan-enabled ROCr ("AddressSanitizer:
+# out of memory ... hsa_amd_memory_pool_allocate" at the first device allocation: profiles/r06_asan_on_gpu.txt).  What runs WITH device work is the
+# UBSan-only build (no interceptors): `make ubsan` -> tools/bin/libmi355zk_ubsan.so, -fno-sanitize-recover: the first report aborts the process.
+UBSAN_OBJS := $(patsubst build/%.o,build_ubsan/%.o,$(OBJS))
+ubsan: tools/bin/libmi355zk_ubsan.so
+tools/bin/libmi355zk_ubsan.so: $(UBSAN_OBJS)
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fsanitize=undefined -shared-libsan -Wl,-rpath,$(dir $(ASAN_RT)) -o $@ $(UBSAN_OBJS)
+build_ubsan/%.o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p build_ubsan
+	$(HIPCC) $(HIPFLAGS) -fsanitize=undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libsan -c $< -o $@
+.PHONY: asan ubsan

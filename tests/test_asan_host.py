@@ -2,7 +2,7 @@
 include/mi355zk.h's pools, caches, planners and the host arithmetic the kernels share -- field.hpp, fieldu.hpp, curveu.hpp, glv.hpp, the digit
 extraction, the host join) under the CPU suite: the host-side test files run once more in a child process that loads
 tools/bin/libmi355zk_asan.so with the ASan runtime preloaded and halt_on_error set, so any report -- out-of-bounds, use-after-free,
-signed overflow, misaligned access, a shift past the width -- fails the child.  tests/test_gpu_asan.py does the same with device work.
+signed overflow, misaligned access, a shift past the width -- fails the child.  tests/test_gpu_ubsan.py does the same with device work (UBSan only: see there).
 Skipped (with the reason) where the sanitizer library has not been built: __graft_entry__.build() builds it."""
 import os
 import subprocess
