@@ -6,8 +6,8 @@ ARCH ?= gfx950
 PKG := phase2-bn254_amd
 SRC := $(PKG)/csrc
 HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result
-OBJS := build/ntt.o build/msm_g1.o build/msm_g2.o build/api.o build/field_ops.o build/point_fft.o build/point_fft_g2.o build/codec.o
-HDRS := $(SRC)/field.hpp $(SRC)/mont_mul_gfx950.inc $(SRC)/curve.hpp $(SRC)/fieldu.hpp $(SRC)/curveu.hpp $(SRC)/device_util.hpp $(SRC)/msm_impl.hpp include/mi355zk.h
+OBJS := build/ntt.o build/msm_g1.o build/msm_g2.o build/api.o build/host_entry.o build/scalar_mul.o build/field_ops.o build/point_fft.o build/point_fft_g2.o build/codec.o
+HDRS := $(SRC)/field.hpp $(SRC)/mont_mul_gfx950.inc $(SRC)/curve.hpp $(SRC)/fieldu.hpp $(SRC)/curveu.hpp $(SRC)/device_util.hpp $(SRC)/msm_impl.hpp $(SRC)/api_internal.hpp $(SRC)/glv.hpp include/mi355zk.h
 
 all: $(PKG)/libmi355zk.so oracle tools/bin/ubench_valu tools/bin/ubench_gather tools/bin/ubench_fieldmul tools/bin/ubench_wave_bucket tools/bin/ubench_gather_footprint
 

@@ -8,7 +8,7 @@ name=$1; flags=$2; shift 2 || true
 units=${@:-msm_g1}
 mkdir -p build_$name tools/bin
 objs=""; pids=""
-for o in ntt msm_g1 msm_g2 api field_ops point_fft point_fft_g2 codec; do
+for o in ntt msm_g1 msm_g2 api host_entry scalar_mul field_ops point_fft point_fft_g2 codec; do
   if [[ " $units " == *" $o "* ]]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags -c phase2-bn254_amd/csrc/$o.hip -o build_$name/$o.o &
     pids="$pids $!"
