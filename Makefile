@@ -56,4 +56,14 @@ tools/bin/libmi355zk_ubsan.so: $(UBSAN_OBJS)
 build_ubsan/%.o: $(SRC)/%.hip $(HDRS)
 	@mkdir -p build_ubsan
 	$(HIPCC) $(HIPFLAGS) -fsanitize=undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared-libsan -c $< -o $@
-.PHONY: asan ubsan
+# ThreadSanitizer on the host side (`make tsan` -> tools/bin/libmi355zk_tsan.so; tools/run_tsan.sh <command>): runs with device work, ~10 x slower; the HIP runtime is not
+# instrumented, so its internal races are suppressed (tools/tsan.supp) and only reports that name this library count (tests/test_gpu_tsan.py; profiles/r06_tsan.txt).
+TSAN_OBJS := $(patsubst build/%.o,build_tsan/%.o,$(OBJS))
+tsan: tools/bin/libmi355zk_tsan.so
+tools/bin/libmi355zk_tsan.so: $(TSAN_OBJS)
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fsanitize=thread -shared-libsan -o $@ $(TSAN_OBJS)
+build_tsan/%.o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p build_tsan
+	$(HIPCC) $(HIPFLAGS) -fsanitize=thread -fno-gpu-sanitize -fno-omit-frame-pointer -shared-libsan -c $< -o $@
+.PHONY: asan ubsan tsan

@@ -1769,12 +1769,17 @@ int tws_acquire(int dev, size_t bytes, hipStream_t st, SmallWsLease* lease, void
   lease->st = st;
   lease->idle = true;  // nothing queued on it yet
   for (void* d : drop) (void)hipFree(d);  // idle: their last users synchronised before releasing them
-  if (pick->p == nullptr) {
-    ZK_HIP(hipMalloc(&pick->p, cls));
+  void* p = pick->p;   // (ours: busy was set under the lock)
+  if (p == nullptr) {
+    ZK_HIP(hipMalloc(&p, cls));
+    // published under the lock: another thread's scan sums `bytes` over ALL slots, busy ones included (r6: ThreadSanitizer on the GPU box
+    // reported this write against that read, profiles/r06_tsan.txt -- the only report inside this library)
+    std::lock_guard<std::mutex> lk(g_tws_mu);
+    pick->p = p;
     pick->bytes = cls;
   }
   lease->idle = false;
-  *out = pick->p;
+  *out = p;
   return 0;
 }
 
