@@ -254,9 +254,9 @@ where
     };
     if rc == 0 {
         let p: <G as CurveAffine>::Projective = if is_g1 { same_type_copy(&g1_from_jacobian(&out)) } else { same_type_copy(&g2_from_jacobian(&out)) };
-        return Some(Box::new(future::ok(p)));
+        return Some(Box::new(future::ok::<_, SynthesisError>(p)));
     }
-    map_err(rc).map(|e| Box::new(future::err(e)) as Box<dyn Future<Item = <G as CurveAffine>::Projective, Error = SynthesisError>>)
+    map_err(rc).map(|e| Box::new(future::err::<<G as CurveAffine>::Projective, _>(e)) as Box<dyn Future<Item = <G as CurveAffine>::Projective, Error = SynthesisError>>)
 }
 
 /// `best_fft` (domain.rs:263-272) for `T = Scalar<Bn256>` (group.rs:53: a transparent wrapper around the four Montgomery limbs of an
