@@ -1115,34 +1115,36 @@ def main() -> int:
             torch.cuda.empty_cache()
             out["secondary"].update(secondary_rows(zk, L, worker, dev, args.secondary_log_n, cpu=not args.no_cpu_baseline))
     # ---- (N > 1) the single-process form of the same job in the same line (VERDICT r5 #6c): ONE process, mi355zk_init over the N devices, one
-    # host-buffer call cut into a point range per device (include/mi355zk.h).  A child of rank 0 with a time limit, run while the other
-    # ranks wait at the barrier below with their GPUs idle; needs every GPU visible to rank 0 (nccl runs only).  BENCH_SINGLE_PROCESS_LEG=0 skips it.
-    if world > 1 and backend == "nccl" and os.environ.get("BENCH_SINGLE_PROCESS_LEG", "1") != "0":
-        del bases, scalars
-        torch.cuda.empty_cache()
+    # host-buffer call cut into a point range per device (include/mi355zk.h).  A child of rank 0 with a time limit, started AFTER the process group is gone:
+    # the other ranks have left by then (their GPUs are idle and their memory is free), so nothing of this optional leg can hang a collective or cost the
+    # headline its line.  Needs every GPU visible to rank 0 (nccl runs only).  BENCH_SINGLE_PROCESS_LEG=0 skips it.
+    single_leg = world > 1 and backend == "nccl" and os.environ.get("BENCH_SINGLE_PROCESS_LEG", "1") != "0"
+    if world > 1:
+        if single_leg:
+            del bases, scalars
+            torch.cuda.empty_cache()
         dist.barrier()
-        if rank == 0:
-            import subprocess
+        dist.destroy_process_group()
+    if single_leg and rank == 0:
+        import subprocess
 
-            counts = [str(k) for k in (1, world) if k <= torch.cuda.device_count()]
-            env_child = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
-                                                                       "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-            try:
-                ch = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_multi_device.py"), "--log-n", "24", "--iters", "3", "--no-batch-exp", "--devices"] + counts,
-                                    capture_output=True, text=True, timeout=200, cwd=ROOT, env=env_child)
-                line = [ln for ln in ch.stdout.splitlines() if ln.startswith("{")]
-                out["single_process_multi_gpu_2e24"] = json.loads(line[-1]) if ch.returncode == 0 and line else {"error": "rc %d: %s" % (ch.returncode, ch.stderr[-300:])}
-            except Exception as e:  # noqa: BLE001
-                out["single_process_multi_gpu_2e24"] = {"error": repr(e)[:300]}
-        dist.barrier()
+        time.sleep(2.0)   # (the other ranks are exiting)
+        counts = [str(k) for k in (1, world) if k <= torch.cuda.device_count()]
+        env_child = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                   "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        try:
+            ch = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_multi_device.py"), "--log-n", "24", "--iters", "3", "--no-batch-exp", "--devices"] + counts,
+                                capture_output=True, text=True, timeout=200, cwd=ROOT, env=env_child)
+            line = [ln for ln in ch.stdout.splitlines() if ln.startswith("{")]
+            out["single_process_multi_gpu_2e24"] = json.loads(line[-1]) if ch.returncode == 0 and line else {"error": "rc %d: %s" % (ch.returncode, ch.stderr[-300:])}
+        except Exception as e:  # noqa: BLE001
+            out["single_process_multi_gpu_2e24"] = {"error": repr(e)[:300]}
     if rank == 0:
         full = [ms for g, ms in _GC_LOG if g == 2]
         out["host_gc"] = {"collections": len(_GC_LOG), "full_collections": len(full), "longest_ms": round(max([ms for _, ms in _GC_LOG], default=0.0), 2),
                           "note": "cyclic-GC runs of this interpreter during the whole bench (outside the timed loops, which run with the collector "
                                   "off): a full collection with torch imported is what put single 38-64 ms calls into round 4's table-mode legs"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     return 0
 
 
