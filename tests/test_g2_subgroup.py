@@ -57,7 +57,7 @@ def test_subgroup_points_pass_and_a_cofactor_point_fails_on_host(lib):
 
 
 def test_the_membership_test_is_sound_for_bn254():
-    """api.hip g2_in_subgroup: P in G2 <=> f(psi) P == 0 with f = (x + 1) + x X + x X^2 - 2 x X^3.  psi satisfies chi = X^2 - t X + q on all of
+    """scalar_mul.hip g2_in_subgroup: P in G2 <=> f(psi) P == 0 with f = (x + 1) + x X + x X^2 - 2 x X^3.  psi satisfies chi = X^2 - t X + q on all of
     E'(Fq2), so f(psi) P == 0 implies Res(f, chi) P == 0; the order of P then divides gcd(Res, #E'(Fq2)) -- which is r: a point that passes
     is in the subgroup, and a member passes because r | Res means f(q) == 0 mod r for psi's eigenvalue q.  The same for rounds 3-4's X - 6 x^2."""
     import math
