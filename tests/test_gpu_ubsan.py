@@ -1,5 +1,5 @@
 """The host side of the library under UndefinedBehaviorSanitizer WITH device work: a slice of the GPU suite -- the multiexp entry points
-with their error paths, the streamed and multi-device host-buffer calls (copy threads, pools, caches, per-stream scratch: the ~3000 lines of
+with their error paths, the streamed and multi-device host-buffer calls (copy threads, pools, caches, per-stream scratch: api.hip +
 host_entry.hip), several host threads at once, the prover's eight calls in flight, the ceremony rows and the NTT table cache -- runs once more in a child
 process over tools/bin/libmi355zk_ubsan.so (`make ubsan`: every translation unit's host code instrumented, -fno-sanitize-recover, so the first
 signed overflow / misaligned access / out-of-range shift / bad enum aborts the child).  The AddressSanitizer build covers the host-only paths in the
