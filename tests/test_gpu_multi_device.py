@@ -368,3 +368,41 @@ def test_each_device_keeps_only_the_slice_its_cell_consumes(zk, multi):
     assert np.array_equal(O.G1.to_affine(zk.multiexp(w, (b, 0), dm, scalars).wait()), O.G1.to_affine(want))
     assert lib.mi355zk_bases_cache_info(b.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 1 and d.value == m * 64
     zk.unpin_bases(None)
+
+
+def test_invalidate_reaches_every_slice_of_an_implicitly_cached_vector():
+    """under MI355ZK_BASES_CACHE_IMPLICIT=1 (every vector treated as pinned) a multi-device call caches one SLICE per device of a vector
+    that is in no pin list; mi355zk_bases_cache_invalidate(vector) must reach all of them -- round 5 left the slices on devices 1 .. N-1 cached, to be
+    caught by the sampled fingerprint only.  The implicit mode is read once per process, so this runs in a child: cache the slices over three logical
+    devices, see them all under the vector's name, rewrite the vector in place, invalidate, see none, and get the new vector's result."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, ctypes as C
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ["MI355ZK_BASES_CACHE_IMPLICIT"] = "1"; os.environ["MI355ZK_MULTI_MIN_LOG"] = "6"
+import inputs, oracle_lib as O
+import phase2_bn254_amd as zk
+lib = zk.lib.load()
+w = zk.Worker(devices=[0, 0, 0])
+n = 3000
+bases = inputs.bases_progression_cpu(1, n, seed=4701)
+scalars = inputs.random_scalars(n, seed=4702)
+d, t = C.c_size_t(0), C.c_size_t(0)
+rc, want = O.G1.multiexp(bases, scalars, threads=4)
+got = zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars).wait()
+assert rc == 0 and np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+assert lib.mi355zk_bases_cache_info(bases.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 1 and d.value == n * 64, d.value   # all three slices answer to the vector
+bases[:] = inputs.bases_progression_cpu(1, n, seed=4703)      # the caller rewrites its vector in place ...
+lib.mi355zk_bases_cache_invalidate(bases.ctypes.data_as(C.c_void_p))   # ... and says so
+assert lib.mi355zk_bases_cache_info(bases.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(t)) == 0, d.value
+rc, want = O.G1.multiexp(bases, scalars, threads=4)
+got = zk.multiexp(w, (bases, 0), zk.FullDensity(), scalars).wait()
+assert rc == 0 and np.array_equal(O.G1.to_affine(got), O.G1.to_affine(want))
+print("implicit-slices-ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "implicit-slices-ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
